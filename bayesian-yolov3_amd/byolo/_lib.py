@@ -1,0 +1,85 @@
+"""ctypes binding of libbyolo.so (include/byolo.h).  No fallback: if the HIP library is missing
+the import fails loudly -- there is no CPU / eager path in the product."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbyolo.so")
+
+OK, ERR_ARG, ERR_STATE, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4
+DET_STANDARD, DET_ALEATORIC, DET_EPISTEMIC = 0, 1, 2
+NMS_AGNOSTIC, NMS_TWO_CLASS = 0, 1
+NORM_BN, NORM_DROPOUT = 1, 2
+
+
+class ByoloError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libbyolo error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Cfg(ctypes.Structure):
+    _fields_ = [("img_h", ctypes.c_int32), ("img_w", ctypes.c_int32), ("img_c", ctypes.c_int32),
+                ("cls_cnt", ctypes.c_int32), ("drop_prob", ctypes.c_float), ("max_out", ctypes.c_int32),
+                ("iou_thresh", ctypes.c_float), ("nms_mode", ctypes.c_int32), ("keep_all_outputs", ctypes.c_int32)]
+
+
+_i32, _i64, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+_vp, _cp, _sz, _u64 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64
+_P = ctypes.POINTER
+
+# name -> (restype, argtypes); this table IS the Python view of include/byolo.h and is checked against
+# the header by tests/test_abi.py
+PROTOTYPES = {
+    "byolo_create": (_i32, [_P(Cfg), _i32, _P(_vp)]),
+    "byolo_destroy": (_i32, [_vp]),
+    "byolo_last_error": (_cp, [_vp]),
+    "byolo_version": (_cp, []),
+    "byolo_add_conv": (_i32, [_vp, _cp, _i32, _i32, _i32, _i32]),
+    "byolo_add_residual": (_i32, [_vp, _i32]),
+    "byolo_add_route": (_i32, [_vp, _P(_i32), _i32]),
+    "byolo_add_upsample": (_i32, [_vp]),
+    "byolo_add_stack": (_i32, [_vp, _i32]),
+    "byolo_add_detection": (_i32, [_vp, _cp, _i32, _P(_f32)]),
+    "byolo_mark_backbone_end": (_i32, [_vp]),
+    "byolo_num_params": (_i32, [_vp]),
+    "byolo_param_info": (_i32, [_vp, _i32, _P(_cp), _P(_i32), _P(_i64)]),
+    "byolo_set_param": (_i32, [_vp, _cp, _vp, _i64]),
+    "byolo_get_param": (_i32, [_vp, _cp, _vp, _i64]),
+    "byolo_finalize": (_i32, [_vp]),
+    "byolo_num_layers": (_i32, [_vp]),
+    "byolo_num_boxes": (_i32, [_vp, _P(_i64), _P(_i32)]),
+    "byolo_workspace_bytes": (_i32, [_vp, _i32, _i32, _P(_sz)]),
+    "byolo_forward": (_i32, [_vp, _vp, _i32, _i32, _u64, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "byolo_layer_output": (_i32, [_vp, _i32, _P(_vp), _P(_i64)]),
+    "byolo_decode": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _P(_f32), _i32, _vp, _i64, _i64, _vp]),
+    "byolo_nms_workspace_bytes": (_sz, [_i32, _i64]),
+    "byolo_sort_nms": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "byolo_calibrate_bn": (_i32, [_vp, _vp, _i32, _vp, _sz, _vp]),
+    "byolo_set_profiling": (_i32, [_vp, _i32]),
+    "byolo_stage_ms": (_i32, [_vp, _P(_f32)]),
+    "byolo_flops": (_i32, [_vp, _i32, _i32, _P(ctypes.c_double)]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libbyolo.so not found at %s -- build it with `python bayesian-yolov3_amd/csrc/build.py` "
+            "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(handle, rc):
+    if rc < 0:
+        msg = lib.byolo_last_error(handle)
+        raise ByoloError(rc, msg.decode("utf-8", "replace") if msg else "?")
+    return rc

@@ -1,0 +1,247 @@
+"""Engine: thin object wrapper over the C-ABI handle (include/byolo.h).
+
+PyTorch-ROCm is used here only as plumbing: device buffers (workspace, outputs), the current HIP
+stream and torch.distributed.  All compute happens inside libbyolo.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, Cfg
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Engine:
+    """One handle == one graph on one device (not thread-safe; one per device/thread)."""
+
+    def __init__(self, img_size, cls_cnt, drop_prob=0.1, max_out=1000, iou_thresh=0.5,
+                 nms_mode=_lib.NMS_AGNOSTIC, keep_all_outputs=False, device=0):
+        h, w, c = [int(v) for v in img_size]
+        self.cfg = Cfg(h, w, c, int(cls_cnt), float(drop_prob), int(max_out), float(iou_thresh),
+                       int(nms_mode), int(bool(keep_all_outputs)))
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        rc = lib.byolo_create(ctypes.byref(self.cfg), self.device, ctypes.byref(self._h))
+        if rc < 0:
+            msg = lib.byolo_last_error(None)
+            raise _lib.ByoloError(rc, msg.decode() if msg else "?")
+        self._ws = None
+        self._ws_key = None
+        self.finalized = False
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib.byolo_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- graph construction (lib_yolo/model.py ModelBuilder.make_*) -------------------------
+    def add_conv(self, scope, filters, ksize, stride, norm_flags):
+        return check(self._h, lib.byolo_add_conv(self._h, scope.encode(), filters, ksize, stride, norm_flags))
+
+    def add_residual(self, shortcut):
+        return check(self._h, lib.byolo_add_residual(self._h, shortcut))
+
+    def add_route(self, routes):
+        arr = (ctypes.c_int32 * len(routes))(*[int(r) for r in routes])
+        return check(self._h, lib.byolo_add_route(self._h, arr, len(routes)))
+
+    def add_upsample(self):
+        return check(self._h, lib.byolo_add_upsample(self._h))
+
+    def add_stack(self, src):
+        return check(self._h, lib.byolo_add_stack(self._h, int(src)))
+
+    def add_detection(self, scope, kind, priors_hw):
+        flat = [float(v) for p in priors_hw for v in p]
+        assert len(flat) == 6, "exactly 3 priors (h, w) per detection layer"
+        arr = (ctypes.c_float * 6)(*flat)
+        return check(self._h, lib.byolo_add_detection(self._h, scope.encode(), int(kind), arr))
+
+    def mark_backbone_end(self):
+        check(self._h, lib.byolo_mark_backbone_end(self._h))
+
+    # ---- parameters ------------------------------------------------------------------------------
+    def param_shapes(self):
+        """Ordered {tf variable name: shape} in TF creation order."""
+        out = {}
+        n = check(self._h, lib.byolo_num_params(self._h))
+        name = ctypes.c_char_p()
+        nd = ctypes.c_int32()
+        shp = (ctypes.c_int64 * 4)()
+        for i in range(n):
+            check(self._h, lib.byolo_param_info(self._h, i, ctypes.byref(name), ctypes.byref(nd), shp))
+            out[name.value.decode()] = tuple(int(shp[k]) for k in range(nd.value))
+        return out
+
+    def set_param(self, name, value):
+        a = np.ascontiguousarray(value, dtype=np.float32)
+        check(self._h, lib.byolo_set_param(self._h, name.encode(), a.ctypes.data, a.size))
+
+    def get_param(self, name, shape):
+        a = np.empty(shape, dtype=np.float32)
+        check(self._h, lib.byolo_get_param(self._h, name.encode(), a.ctypes.data, a.size))
+        return a
+
+    def set_params(self, params, strict=True):
+        shapes = self.param_shapes()
+        for k, shp in shapes.items():
+            if k in params:
+                v = np.asarray(params[k])
+                if tuple(v.shape) != tuple(shp):
+                    raise ValueError("variable %s: shape %s != %s" % (k, v.shape, shp))
+                self.set_param(k, v)
+            elif strict:
+                raise KeyError("missing variable %s" % k)
+
+    def get_params(self):
+        return {k: self.get_param(k, s) for k, s in self.param_shapes().items()}
+
+    def finalize(self):
+        check(self._h, lib.byolo_finalize(self._h))
+        self.finalized = True
+
+    # ---- shapes / cost ----------------------------------------------------------------------------
+    def num_layers(self):
+        return check(self._h, lib.byolo_num_layers(self._h))
+
+    def num_boxes(self):
+        n = ctypes.c_int64()
+        d = ctypes.c_int32()
+        check(self._h, lib.byolo_num_boxes(self._h, ctypes.byref(n), ctypes.byref(d)))
+        return int(n.value), int(d.value)
+
+    def workspace_bytes(self, B, T=1):
+        s = ctypes.c_size_t()
+        check(self._h, lib.byolo_workspace_bytes(self._h, int(B), int(T), ctypes.byref(s)))
+        return int(s.value)
+
+    def flops(self, B, T=1):
+        f = ctypes.c_double()
+        check(self._h, lib.byolo_flops(self._h, int(B), int(T), ctypes.byref(f)))
+        return float(f.value)
+
+    @property
+    def out_cap(self):
+        return self.cfg.max_out * (2 if self.cfg.nms_mode == _lib.NMS_TWO_CLASS else 1)
+
+    # ---- run ------------------------------------------------------------------------------------------
+    def _workspace(self, B, T):
+        torch = _torch()
+        need = self.workspace_bytes(B, T)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device="cuda:%d" % self.device)
+        return self._ws
+
+    def _check_img(self, img):
+        torch = _torch()
+        if not (isinstance(img, torch.Tensor) and img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()):
+            raise TypeError("img must be a contiguous float32 CUDA tensor [B,H,W,C]")
+        if tuple(img.shape[1:]) != (self.cfg.img_h, self.cfg.img_w, self.cfg.img_c):
+            raise ValueError("img shape %s does not match %s" % (tuple(img.shape), (self.cfg.img_h, self.cfg.img_w, self.cfg.img_c)))
+        if img.device.index != self.device:
+            raise ValueError("img is on cuda:%s, engine on cuda:%d" % (img.device.index, self.device))
+
+    def forward(self, img, T=1, seed=0, dropout_on=True, want_boxes=False, want_nms=True, out=None):
+        """One sess.run of the reference (inference_epistemic.py:76).  Returns a dict of device
+        tensors: rows [B,cap,D], kept [B,cap] int32, count [B,2] int32 and (want_boxes) boxes [B,N,D].
+        Everything is enqueued on torch's current stream; no host synchronisation."""
+        torch = _torch()
+        self._check_img(img)
+        B = int(img.shape[0])
+        ws = self._workspace(B, T)
+        N, D = self.num_boxes()
+        dev = img.device
+        res = out if out is not None else {}
+        boxes = rows = kept = count = None
+        if want_boxes:
+            boxes = res.get("boxes")
+            if boxes is None:
+                boxes = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+        if want_nms:
+            cap = self.out_cap
+            rows, kept, count = res.get("rows"), res.get("kept"), res.get("count")
+            if rows is None:
+                rows = torch.empty((B, cap, D), dtype=torch.float32, device=dev)
+                kept = torch.empty((B, cap), dtype=torch.int32, device=dev)
+                count = torch.empty((B, 2), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._h, lib.byolo_forward(self._h, p(img), B, int(T), ctypes.c_uint64(int(seed) & (2**64 - 1)),
+                                         int(bool(dropout_on)), p(ws), ws.numel(), p(boxes), p(rows), p(kept),
+                                         p(count), ctypes.c_void_p(stream)))
+        return dict(boxes=boxes, rows=rows, kept=kept, count=count)
+
+    def layer_output(self, idx):
+        """Copy of layer `idx`'s output after a forward (needs keep_all_outputs=True)."""
+        torch = _torch()
+        ptr = ctypes.c_void_p()
+        shp = (ctypes.c_int64 * 4)()
+        check(self._h, lib.byolo_layer_output(self._h, int(idx), ctypes.byref(ptr), shp))
+        shape = tuple(int(s) for s in shp)
+        base = self._ws.data_ptr()
+        off = ptr.value - base
+        n = int(np.prod(shape))
+        torch.cuda.synchronize(self.device)
+        return self._ws[off:off + 4 * n].view(torch.float32).reshape(shape).clone()
+
+    def calibrate_bn(self, img):
+        self._check_img(img)
+        torch = _torch()
+        B = int(img.shape[0])
+        ws = self._workspace(B, 1)
+        stream = torch.cuda.current_stream(img.device).cuda_stream
+        check(self._h, lib.byolo_calibrate_bn(self._h, ctypes.c_void_p(img.data_ptr()), B,
+                                              ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(stream)))
+
+    def set_profiling(self, on):
+        check(self._h, lib.byolo_set_profiling(self._h, int(bool(on))))
+
+    def stage_ms(self):
+        ms = (ctypes.c_float * 4)()
+        check(self._h, lib.byolo_stage_ms(self._h, ms))
+        return dict(backbone=ms[0], heads=ms[1], decode=ms[2], sort_nms=ms[3])
+
+    # ---- staged tail (parity tests; also the eager `nms(...)` helpers of inference_*.py) -------------
+    def decode(self, kind, raw, B, T, priors_hw, layer_id, boxes, box_base):
+        torch = _torch()
+        S, lh, lw, F = raw.shape
+        assert S == B * T and raw.is_cuda and raw.dtype == torch.float32 and raw.is_contiguous()
+        arr = (ctypes.c_float * 6)(*[float(v) for p in priors_hw for v in p])
+        stream = torch.cuda.current_stream(raw.device).cuda_stream
+        check(self._h, lib.byolo_decode(self._h, int(kind), ctypes.c_void_p(raw.data_ptr()), int(B), int(T), int(lh),
+                                        int(lw), arr, int(layer_id), ctypes.c_void_p(boxes.data_ptr()),
+                                        int(boxes.shape[1]), int(box_base), ctypes.c_void_p(stream)))
+
+    def sort_nms(self, boxes, obj_idx, cls_start_idx, nms_mode=None, max_out=None, iou_thresh=None):
+        """tf.image.non_max_suppression + tf.gather per image on boxes [B,N,D] (device tensor)."""
+        torch = _torch()
+        assert boxes.is_cuda and boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.dim() == 3
+        B, N, D = boxes.shape
+        nms_mode = self.cfg.nms_mode if nms_mode is None else nms_mode
+        max_out = self.cfg.max_out if max_out is None else max_out
+        iou_thresh = self.cfg.iou_thresh if iou_thresh is None else iou_thresh
+        cap = max_out * (2 if nms_mode == _lib.NMS_TWO_CLASS else 1)
+        wsb = int(lib.byolo_nms_workspace_bytes(B, N))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=boxes.device)
+        rows = torch.empty((B, cap, D), dtype=torch.float32, device=boxes.device)
+        kept = torch.empty((B, cap), dtype=torch.int32, device=boxes.device)
+        count = torch.empty((B, 2), dtype=torch.int32, device=boxes.device)
+        stream = torch.cuda.current_stream(boxes.device).cuda_stream
+        check(self._h, lib.byolo_sort_nms(self._h, ctypes.c_void_p(boxes.data_ptr()), B, N, D, int(obj_idx),
+                                          int(cls_start_idx), int(nms_mode), int(max_out), float(iou_thresh),
+                                          ctypes.c_void_p(ws.data_ptr()), wsb, ctypes.c_void_p(rows.data_ptr()),
+                                          ctypes.c_void_p(kept.data_ptr()), ctypes.c_void_p(count.data_ptr()),
+                                          ctypes.c_void_p(stream)))
+        return dict(rows=rows, kept=kept, count=count)

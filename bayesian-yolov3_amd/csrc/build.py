@@ -1,0 +1,34 @@
+"""Build libbyolo.so (gfx950 only) in-tree: bayesian-yolov3_amd/byolo/libbyolo.so.
+
+    python bayesian-yolov3_amd/csrc/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
+gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "byolo", "libbyolo.so")
+SRCS = ["byolo_api.hip", "conv_kernels.hip", "tail_kernels.hip"]
+DEPS = SRCS + ["byolo_kernels.h", "byolo_rng.h", os.path.join("..", "..", "include", "byolo.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-result"]
+
+
+def build(force=False, verbose=False):
+    out = os.path.abspath(OUT)
+    newest = max(os.path.getmtime(os.path.join(HERE, d)) for d in DEPS)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(HERE, s) for s in SRCS] + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,809 @@
+// byolo_api.hip -- implementation of include/byolo.h: graph builder (mirror of
+// lib_yolo/model.py ModelBuilder), parameter store, BN folding + weight packing, liveness-based
+// workspace planner and the forward driver that lowers the reference's layer list to fused
+// gfx950 kernel launches on the caller's stream.
+//
+// Lowering rules (what the TF graph of lib_yolo/yolov3.py:518-628 becomes):
+//   conv -> [dropout] -> bn -> leaky                      one conv_igemm launch (fused epilogue)
+//   conv3x3 followed by residual(-3)                      same launch, residual added in the epilogue
+//   upsample / route / stack_feature_map                  never materialised: they become the operand
+//                                                          view (two sources, x>>1 indexing, s/T
+//                                                          sample broadcast) of the consuming conv
+//   detection conv (+bias) -> split -> decode             conv_igemm (bias epilogue) + one decode launch
+//                                                          writing rows at their concat_bbox offset
+//   concat_bbox -> non_max_suppression -> gather          sort_keys + nms launches
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/byolo.h"
+#include "byolo_kernels.h"
+#include "byolo_rng.h"
+
+using namespace byk;
+
+namespace {
+
+enum Op { OP_CONV, OP_RESIDUAL, OP_ROUTE, OP_UPSAMPLE, OP_STACK, OP_DETECTION };
+
+struct Param {
+    std::string name;
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    int64_t count() const { int64_t c = 1; for (auto s : shape) c *= s; return c; }
+};
+
+struct Layer {
+    Op op;
+    std::string scope;
+    int filters = 0, ksize = 0, stride = 1, norm = 0;
+    int prev = -1;                 // implicit input (previous layer; -1 = image)
+    int ref[2] = {-1, -1};         // explicit absolute refs (shortcut / routes / stack src)
+    int nref = 0;
+    int det_kind = 0, det_id = 0;
+    float priors[6] = {0, 0, 0, 0, 0, 0};
+    // inferred output
+    int C = 0, H = 0, W = 0;
+    bool stacked = false;
+    // params
+    int p_kernel = -1, p_bias = -1, p_gamma = -1, p_beta = -1, p_mean = -1, p_var = -1;
+    int drop_ordinal = -1;
+    int Cin = 0;
+    // lowering
+    bool materialized = false;     // owns an activation tensor
+    int out_tensor = -1;           // layer index whose tensor receives this conv's output
+    int fused_residual = -1;       // residual layer fused into this conv's epilogue
+    // packed weights (offsets in floats into the device blob)
+    size_t w_off = 0, scale_off = 0, shift_off = 0;
+    int tile = 0, Npad = 0;
+    bool direct = false;
+    int64_t box_base = 0;
+};
+
+struct Src { int layer; int C; int sh; bool tile; };
+struct View { Src s[2]; int n = 0; };
+
+struct Step { int layer; View in; };
+
+struct Plan {
+    int B = -1, T = -1;
+    std::vector<int64_t> off;      // per layer tensor offset in bytes (-1: none)
+    size_t arena = 0, boxes_off = 0, nms_off = 0, stats_off = 0, total = 0;
+};
+
+}  // namespace
+
+struct byolo {
+    byolo_cfg cfg;
+    int device = 0;
+    std::string err;
+    std::vector<Layer> layers;
+    std::vector<Param> params;
+    std::map<std::string, int> pindex;
+    int n_dropout = 0, n_det = 0;
+    int backbone_end = -1;
+    bool finalized = false;        // weights folded, packed and uploaded
+    bool lowered = false;          // graph frozen and lowered to steps (host only)
+    std::vector<Step> steps;
+    std::vector<int> last_use;     // per layer tensor: index of the last step reading it
+    float* d_blob = nullptr;       // packed weights + scale/shift
+    size_t blob_floats = 0;
+    float* d_ones = nullptr; float* d_zeros = nullptr; int maxC = 0;
+    int64_t n_boxes = 0; int row_len = 0, obj_idx = 0, cls_start = 0;
+    Plan plan;
+    void* last_ws = nullptr;
+    bool profiling = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+static thread_local std::string g_err;
+
+static int32_t fail(byolo_t* h, int32_t code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_err = buf;
+    return code;
+}
+#define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return fail(h, BYOLO_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* byolo_version(void) { return "byolo 0.1 (gfx950, fp32 MFMA)"; }
+
+extern "C" const char* byolo_last_error(const byolo_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** out) {
+    if (!cfg || !out) return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: null argument");
+    if (cfg->img_h <= 0 || cfg->img_w <= 0 || cfg->img_c <= 0)
+        return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: invalid image size");
+    // lib_yolo/yolov3.py:207-208: input size must be a multiple of the biggest stride
+    if (cfg->img_h % 32 || cfg->img_w % 32)
+        return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: full_img_size must be a multiple of 32 (yolov3.py:207-208)");
+    if (cfg->cls_cnt < 1) return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: cls_cnt < 1");
+    if (cfg->max_out < 1 || cfg->max_out > 2048) return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: max_out out of [1,2048]");
+    if (!(cfg->drop_prob >= 0.f && cfg->drop_prob < 1.f)) return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: drop_prob");
+    byolo_t* h = new (std::nothrow) byolo();
+    if (!h) return fail(nullptr, BYOLO_ERR_NOMEM, "byolo_create: out of host memory");
+    h->cfg = *cfg;
+    h->device = device;
+    *out = h;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_destroy(byolo_t* h) {
+    if (!h) return BYOLO_OK;
+    if (h->d_blob || h->d_ones || h->ev[0]) {
+        (void)hipSetDevice(h->device);
+        if (h->d_blob) (void)hipFree(h->d_blob);
+        if (h->d_ones) (void)hipFree(h->d_ones);
+        if (h->d_zeros) (void)hipFree(h->d_zeros);
+        for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    }
+    delete h;
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph construction
+// ------------------------------------------------------------------------------------------------
+static int add_param(byolo_t* h, const std::string& name, std::vector<int64_t> shape, float fill) {
+    if (h->pindex.count(name)) return -1;
+    Param p; p.name = name; p.shape = std::move(shape);
+    p.data.assign((size_t)p.count(), fill);
+    h->params.push_back(std::move(p));
+    h->pindex[name] = (int)h->params.size() - 1;
+    return (int)h->params.size() - 1;
+}
+
+static int resolve_ref(const byolo_t* h, int r) {        // reference indexing: negative = from the end
+    const int n = (int)h->layers.size();
+    const int a = r < 0 ? n + r : r;
+    return (a < 0 || a >= n) ? -2 : a;
+}
+
+static void input_shape(const byolo_t* h, int prev, int& C, int& H, int& W, bool& stacked) {
+    if (prev < 0) { C = h->cfg.img_c; H = h->cfg.img_h; W = h->cfg.img_w; stacked = false; }
+    else { const Layer& l = h->layers[prev]; C = l.C; H = l.H; W = l.W; stacked = l.stacked; }
+}
+
+static int32_t begin_add(byolo_t* h, const char* what) {
+    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "%s: null handle", what);
+    if (h->lowered) return fail(h, BYOLO_ERR_STATE, "%s: graph is frozen after byolo_finalize", what);
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_add_conv(byolo_t* h, const char* scope, int32_t filters, int32_t ksize, int32_t stride,
+                                  int32_t norm_flags) {
+    int32_t rc = begin_add(h, "byolo_add_conv"); if (rc) return rc;
+    // lib_yolo/layers.py:546-547: assert kernel_size in [1,3], strides in [1,2]
+    if (!scope || !(ksize == 1 || ksize == 3)) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: invalid kernel size");
+    if (!(stride == 1 || stride == 2)) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: invalid strides");
+    if (stride == 2 && ksize != 3) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: invalid kernel size (layers.py:629)");
+    if (filters < 1) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: filters < 1");
+    if (!(norm_flags & BYOLO_NORM_BN)) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: BN-less conv layers are not on this path");
+    Layer l; l.op = OP_CONV; l.scope = scope; l.filters = filters; l.ksize = ksize; l.stride = stride; l.norm = norm_flags;
+    l.prev = (int)h->layers.size() - 1;
+    int C, H, W; bool st; input_shape(h, l.prev, C, H, W, st);
+    if (stride == 2 && ((H | W) & 1)) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: stride 2 needs even input size");
+    l.Cin = C; l.C = filters; l.H = H / stride; l.W = W / stride; l.stacked = st;
+    const std::string s(scope);
+    l.p_kernel = add_param(h, s + "/conv2d/kernel", {ksize, ksize, C, filters}, 0.f);
+    l.p_gamma = add_param(h, s + "/batch_normalization/gamma", {filters}, 1.f);
+    l.p_beta = add_param(h, s + "/batch_normalization/beta", {filters}, 0.f);
+    l.p_mean = add_param(h, s + "/batch_normalization/moving_mean", {filters}, 0.f);
+    l.p_var = add_param(h, s + "/batch_normalization/moving_variance", {filters}, 1.f);
+    if (l.p_kernel < 0 || l.p_gamma < 0) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: duplicate scope '%s'", scope);
+    if (norm_flags & BYOLO_NORM_DROPOUT) l.drop_ordinal = h->n_dropout++;
+    h->layers.push_back(l);
+    return (int32_t)h->layers.size() - 1;
+}
+
+extern "C" int32_t byolo_add_residual(byolo_t* h, int32_t shortcut) {
+    int32_t rc = begin_add(h, "byolo_add_residual"); if (rc) return rc;
+    Layer l; l.op = OP_RESIDUAL; l.prev = (int)h->layers.size() - 1;
+    const int a = resolve_ref(h, shortcut);
+    if (a < 0 || l.prev < 0) return fail(h, BYOLO_ERR_ARG, "byolo_add_residual: bad shortcut %d", shortcut);
+    const Layer& x = h->layers[l.prev]; const Layer& s = h->layers[a];
+    if (x.C != s.C || x.H != s.H || x.W != s.W || x.stacked != s.stacked)
+        return fail(h, BYOLO_ERR_ARG, "byolo_add_residual: shape mismatch");
+    l.ref[0] = a; l.nref = 1; l.C = x.C; l.H = x.H; l.W = x.W; l.stacked = x.stacked;
+    h->layers.push_back(l);
+    return (int32_t)h->layers.size() - 1;
+}
+
+extern "C" int32_t byolo_add_route(byolo_t* h, const int32_t* routes, int32_t n) {
+    int32_t rc = begin_add(h, "byolo_add_route"); if (rc) return rc;
+    // lib_yolo/layers.py:584-585
+    if (!routes || n >= 3) return fail(h, BYOLO_ERR_ARG, "byolo_add_route: too many routes");
+    if (n < 1) return fail(h, BYOLO_ERR_ARG, "byolo_add_route: too few routes");
+    Layer l; l.op = OP_ROUTE; l.prev = (int)h->layers.size() - 1; l.nref = n;
+    for (int i = 0; i < n; ++i) {
+        l.ref[i] = resolve_ref(h, routes[i]);
+        if (l.ref[i] < 0) return fail(h, BYOLO_ERR_ARG, "byolo_add_route: bad route %d", routes[i]);
+    }
+    const Layer& a = h->layers[l.ref[0]];
+    l.C = a.C; l.H = a.H; l.W = a.W; l.stacked = a.stacked;
+    if (n == 2) {
+        const Layer& b = h->layers[l.ref[1]];
+        if (a.H != b.H || a.W != b.W || a.stacked != b.stacked)
+            return fail(h, BYOLO_ERR_ARG, "byolo_add_route: concat shape mismatch");
+        l.C = a.C + b.C;
+    }
+    h->layers.push_back(l);
+    return (int32_t)h->layers.size() - 1;
+}
+
+extern "C" int32_t byolo_add_upsample(byolo_t* h) {
+    int32_t rc = begin_add(h, "byolo_add_upsample"); if (rc) return rc;
+    Layer l; l.op = OP_UPSAMPLE; l.prev = (int)h->layers.size() - 1;
+    if (l.prev < 0) return fail(h, BYOLO_ERR_ARG, "byolo_add_upsample: no input");
+    const Layer& x = h->layers[l.prev];
+    l.C = x.C; l.H = 2 * x.H; l.W = 2 * x.W; l.stacked = x.stacked;
+    h->layers.push_back(l);
+    return (int32_t)h->layers.size() - 1;
+}
+
+extern "C" int32_t byolo_add_stack(byolo_t* h, int32_t src) {
+    int32_t rc = begin_add(h, "byolo_add_stack"); if (rc) return rc;
+    Layer l; l.op = OP_STACK; l.prev = (int)h->layers.size() - 1;
+    const int a = resolve_ref(h, src);
+    if (a < 0) return fail(h, BYOLO_ERR_ARG, "byolo_add_stack: bad source %d", src);
+    const Layer& x = h->layers[a];
+    if (x.stacked) return fail(h, BYOLO_ERR_ARG, "byolo_add_stack: source is already stacked");
+    l.ref[0] = a; l.nref = 1; l.C = x.C; l.H = x.H; l.W = x.W; l.stacked = true;
+    h->layers.push_back(l);
+    return (int32_t)h->layers.size() - 1;
+}
+
+static void row_layout(int kind, int C, int& D, int& obj, int& cls) {
+    // lib_yolo/yolov3.py:183-184 / :321-322 / :464-465
+    if (kind == BYOLO_DET_STANDARD) { D = 5 + C; obj = 4; cls = 5; }
+    else if (kind == BYOLO_DET_ALEATORIC) { D = 14 + C; obj = 9; cls = 11; }
+    else { D = 21 + C; obj = 14; cls = 17; }
+}
+
+extern "C" int32_t byolo_add_detection(byolo_t* h, const char* scope, int32_t kind, const float* priors_hw) {
+    int32_t rc = begin_add(h, "byolo_add_detection"); if (rc) return rc;
+    if (!scope || !priors_hw || kind < 0 || kind > 2) return fail(h, BYOLO_ERR_ARG, "byolo_add_detection: bad argument");
+    Layer l; l.op = OP_DETECTION; l.scope = scope; l.prev = (int)h->layers.size() - 1; l.det_kind = kind;
+    if (l.prev < 0) return fail(h, BYOLO_ERR_ARG, "byolo_add_detection: no input");
+    int C, H, W; bool st; input_shape(h, l.prev, C, H, W, st);
+    const int cc = h->cfg.cls_cnt;
+    l.filters = kind == BYOLO_DET_STANDARD ? 3 * (5 + cc) : 3 * 2 * (5 + cc);     // layers.py:601 / :609
+    l.ksize = 1; l.stride = 1; l.Cin = C; l.C = l.filters; l.H = H; l.W = W; l.stacked = st;
+    memcpy(l.priors, priors_hw, sizeof l.priors);
+    l.det_id = h->n_det++;
+    int D, obj, cls; row_layout(kind, cc, D, obj, cls);
+    if (h->row_len && h->row_len != D) return fail(h, BYOLO_ERR_ARG, "byolo_add_detection: mixed detection kinds");
+    h->row_len = D; h->obj_idx = obj; h->cls_start = cls;
+    l.box_base = h->n_boxes;
+    h->n_boxes += (int64_t)3 * H * W;
+    const std::string s(scope);
+    l.p_kernel = add_param(h, s + "/conv2d/kernel", {1, 1, C, l.filters}, 0.f);
+    l.p_bias = add_param(h, s + "/conv2d/bias", {l.filters}, 0.f);
+    if (l.p_kernel < 0 || l.p_bias < 0) return fail(h, BYOLO_ERR_ARG, "byolo_add_detection: duplicate scope '%s'", scope);
+    h->layers.push_back(l);
+    return (int32_t)h->layers.size() - 1;
+}
+
+extern "C" int32_t byolo_mark_backbone_end(byolo_t* h) {
+    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "null handle");
+    h->backbone_end = (int)h->layers.size();
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameters
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t byolo_num_params(const byolo_t* h) { return h ? (int32_t)h->params.size() : BYOLO_ERR_ARG; }
+
+extern "C" int32_t byolo_param_info(const byolo_t* h, int32_t i, const char** name, int32_t* ndim, int64_t shape[4]) {
+    if (!h || i < 0 || i >= (int)h->params.size()) return fail(const_cast<byolo_t*>(h), BYOLO_ERR_ARG, "byolo_param_info: bad index");
+    const Param& p = h->params[i];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = (int32_t)p.shape.size();
+    if (shape) for (size_t k = 0; k < 4; ++k) shape[k] = k < p.shape.size() ? p.shape[k] : 1;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_set_param(byolo_t* h, const char* name, const float* data, int64_t count) {
+    if (!h || !name || !data) return fail(h, BYOLO_ERR_ARG, "byolo_set_param: null argument");
+    auto it = h->pindex.find(name);
+    if (it == h->pindex.end()) return fail(h, BYOLO_ERR_ARG, "byolo_set_param: unknown variable '%s'", name);
+    Param& p = h->params[it->second];
+    if (count != p.count()) return fail(h, BYOLO_ERR_ARG, "byolo_set_param: '%s' expects %lld values, got %lld", name,
+                                        (long long)p.count(), (long long)count);
+    memcpy(p.data.data(), data, sizeof(float) * (size_t)count);
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_get_param(const byolo_t* h, const char* name, float* data, int64_t count) {
+    byolo_t* hh = const_cast<byolo_t*>(h);
+    if (!h || !name || !data) return fail(hh, BYOLO_ERR_ARG, "byolo_get_param: null argument");
+    auto it = h->pindex.find(name);
+    if (it == h->pindex.end()) return fail(hh, BYOLO_ERR_ARG, "byolo_get_param: unknown variable '%s'", name);
+    const Param& p = h->params[it->second];
+    if (count != p.count()) return fail(hh, BYOLO_ERR_ARG, "byolo_get_param: size mismatch for '%s'", name);
+    memcpy(data, p.data.data(), sizeof(float) * (size_t)count);
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lowering
+// ------------------------------------------------------------------------------------------------
+static bool resolve_view(const byolo_t* h, int idx, View& v, std::string& why) {
+    if (idx < 0) { v.n = 1; v.s[0] = {-1, h->cfg.img_c, 0, false}; return true; }
+    const Layer& l = h->layers[idx];
+    switch (l.op) {
+        case OP_CONV: case OP_DETECTION: case OP_RESIDUAL:
+            if (!l.materialized) { why = "layer " + std::to_string(idx) + " is fused away but referenced"; return false; }
+            v.n = 1; v.s[0] = {idx, l.C, 0, false}; return true;
+        case OP_ROUTE: {
+            if (l.nref == 1) return resolve_view(h, l.ref[0], v, why);
+            View a, b;
+            if (!resolve_view(h, l.ref[0], a, why) || !resolve_view(h, l.ref[1], b, why)) return false;
+            if (a.n != 1 || b.n != 1) { why = "nested concat"; return false; }
+            v.n = 2; v.s[0] = a.s[0]; v.s[1] = b.s[0]; return true;
+        }
+        case OP_UPSAMPLE:
+            if (!resolve_view(h, l.prev, v, why)) return false;
+            for (int i = 0; i < v.n; ++i) { if (v.s[i].sh) { why = "double upsample"; return false; } v.s[i].sh = 1; }
+            return true;
+        case OP_STACK:
+            if (!resolve_view(h, l.ref[0], v, why)) return false;
+            for (int i = 0; i < v.n; ++i) v.s[i].tile = true;
+            return true;
+    }
+    return false;
+}
+
+static int32_t lower(byolo_t* h) {
+    const int n = (int)h->layers.size();
+    if (!n) return fail(h, BYOLO_ERR_STATE, "byolo_finalize: empty graph");
+    if (!h->n_det) return fail(h, BYOLO_ERR_STATE, "byolo_finalize: no detection layer (model.py:190: assert len(det_layers) > 0)");
+    // reference counts
+    std::vector<int> refs(n, 0);
+    for (int i = 0; i < n; ++i) {
+        const Layer& l = h->layers[i];
+        if ((l.op == OP_CONV || l.op == OP_DETECTION || l.op == OP_RESIDUAL || l.op == OP_UPSAMPLE) && l.prev >= 0) refs[l.prev]++;
+        for (int k = 0; k < l.nref; ++k) refs[l.ref[k]]++;
+    }
+    for (auto& l : h->layers) { l.materialized = false; l.out_tensor = -1; l.fused_residual = -1; }
+    for (int i = 0; i < n; ++i) {
+        Layer& l = h->layers[i];
+        if (l.op == OP_CONV || l.op == OP_DETECTION) { l.materialized = true; l.out_tensor = i; }
+    }
+    for (int i = 0; i < n; ++i) {
+        Layer& l = h->layers[i];
+        if (l.op != OP_RESIDUAL) continue;
+        Layer& c = h->layers[l.prev];
+        if (c.op == OP_CONV && refs[l.prev] == 1 && c.fused_residual < 0 && l.ref[0] != l.prev) {
+            c.materialized = false; c.fused_residual = i; c.out_tensor = i; l.materialized = true; l.out_tensor = i;
+        } else {
+            return fail(h, BYOLO_ERR_ARG, "byolo_finalize: residual layer %d cannot be fused into a producing conv", i);
+        }
+    }
+    h->steps.clear();
+    h->last_use.assign(n, -1);
+    for (int i = 0; i < n; ++i) {
+        Layer& l = h->layers[i];
+        if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
+        Step st; st.layer = i;
+        std::string why;
+        if (!resolve_view(h, l.prev, st.in, why)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d: %s", i, why.c_str());
+        int ctot = 0;
+        for (int k = 0; k < st.in.n; ++k) {
+            ctot += st.in.s[k].C;
+            const Src& s = st.in.s[k];
+            const bool src_stacked = s.layer >= 0 && h->layers[s.layer].stacked;
+            if (l.stacked && !src_stacked && !s.tile) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d mixes stacked and unstacked inputs", i);
+        }
+        if (ctot != l.Cin) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d channel mismatch", i);
+        l.direct = (l.Cin % 32) != 0;
+        if (l.direct && (st.in.n != 1 || st.in.s[0].sh || (l.filters % 8) || l.op == OP_DETECTION))
+            return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d: unsupported small-Cin convolution", i);
+        if (st.in.n == 2 && (st.in.s[0].C % 32)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d: concat split not a multiple of 32", i);
+        const int step_idx = (int)h->steps.size();
+        for (int k = 0; k < st.in.n; ++k) if (st.in.s[k].layer >= 0) h->last_use[st.in.s[k].layer] = step_idx;
+        if (l.fused_residual >= 0) h->last_use[h->layers[l.fused_residual].ref[0]] = step_idx;
+        h->steps.push_back(st);
+    }
+    h->maxC = 1;
+    for (const auto& l : h->layers) h->maxC = std::max(h->maxC, l.C);
+    h->lowered = true;
+    return BYOLO_OK;
+}
+
+static float* dptr(const byolo_t* h, size_t off) { return h->d_blob + off; }
+
+static void fold_layer(const byolo_t* h, const Layer& l, std::vector<float>& scale, std::vector<float>& shift) {
+    const int N = l.filters;
+    scale.resize(N); shift.resize(N);
+    if (l.op == OP_DETECTION) {
+        const float* b = h->params[l.p_bias].data.data();
+        for (int c = 0; c < N; ++c) { scale[c] = 1.f; shift[c] = b[c]; }
+        return;
+    }
+    const float* g = h->params[l.p_gamma].data.data();
+    const float* be = h->params[l.p_beta].data.data();
+    const float* m = h->params[l.p_mean].data.data();
+    const float* v = h->params[l.p_var].data.data();
+    for (int c = 0; c < N; ++c) {                              // layers.py:510-518, eps 1e-5
+        const float inv = g[c] * (1.0f / sqrtf(v[c] + 1e-5f));
+        scale[c] = inv; shift[c] = be[c] - m[c] * inv;
+    }
+}
+
+extern "C" int32_t byolo_finalize(byolo_t* h) {
+    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_finalize: null handle");
+    if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    // layout of the device blob
+    size_t off = 0; const int maxC = h->maxC;
+    for (auto& st : h->steps) {
+        Layer& l = h->layers[st.layer];
+        const int K = l.ksize * l.ksize * l.Cin, N = l.filters;
+        if (l.direct) { l.tile = -1; l.Npad = N; l.w_off = off; off += align_up((size_t)K * N, 64); }
+        else {
+            l.tile = conv_pick_tile(N);
+            const int bn = conv_tile_bn(l.tile);
+            l.Npad = (N + bn - 1) / bn * bn;
+            l.w_off = off; off += align_up((size_t)K * l.Npad, 64);
+        }
+        l.scale_off = off; off += align_up((size_t)N, 64);
+        l.shift_off = off; off += align_up((size_t)N, 64);
+    }
+    std::vector<float> blob(off, 0.f);
+    std::vector<float> sc, sf;
+    for (auto& st : h->steps) {
+        const Layer& l = h->layers[st.layer];
+        const int K = l.ksize * l.ksize * l.Cin, N = l.filters;
+        const float* w = h->params[l.p_kernel].data.data();     // HWIO == [K][N], k = (ky*ks + kx)*Cin + c
+        float* dst = blob.data() + l.w_off;
+        if (l.direct) memcpy(dst, w, sizeof(float) * (size_t)K * N);
+        else {
+            for (int k = 0; k < K; ++k) {
+                const int kt = k >> 5, kk = k & 31;
+                const float* wr = w + (size_t)k * N;
+                float* d = dst + ((size_t)kt * l.Npad) * 32 + kk;
+                for (int nn = 0; nn < N; ++nn) d[(size_t)nn * 32] = wr[nn];
+            }
+        }
+        fold_layer(h, l, sc, sf);
+        memcpy(blob.data() + l.scale_off, sc.data(), sizeof(float) * N);
+        memcpy(blob.data() + l.shift_off, sf.data(), sizeof(float) * N);
+    }
+    if (h->d_blob && h->blob_floats != off) { HIPCHK(h, hipFree(h->d_blob)); h->d_blob = nullptr; }
+    if (!h->d_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, sizeof(float) * off));
+    h->blob_floats = off;
+    HIPCHK(h, hipMemcpy(h->d_blob, blob.data(), sizeof(float) * off, hipMemcpyHostToDevice));
+    if (!h->d_ones) {
+        std::vector<float> ones((size_t)maxC, 1.f);
+        HIPCHK(h, hipMalloc((void**)&h->d_ones, sizeof(float) * maxC));
+        HIPCHK(h, hipMalloc((void**)&h->d_zeros, sizeof(float) * maxC));
+        HIPCHK(h, hipMemcpy(h->d_ones, ones.data(), sizeof(float) * maxC, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemset(h->d_zeros, 0, sizeof(float) * maxC));
+    }
+    h->finalized = true;
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace planning (liveness-based first-fit; 288 GB HBM is not a reason to thrash the caches)
+// ------------------------------------------------------------------------------------------------
+static int64_t tensor_bytes(const byolo_t* h, int layer, int B, int T) {
+    const Layer& l = h->layers[layer];
+    const int64_t S = l.stacked ? (int64_t)B * T : B;
+    return (int64_t)align_up((size_t)(S * l.H * l.W * l.C) * sizeof(float), 256);
+}
+
+static void make_plan(byolo_t* h, int B, int T) {
+    Plan& p = h->plan;
+    if (p.B == B && p.T == T) return;
+    const int n = (int)h->layers.size();
+    p.B = B; p.T = T; p.off.assign(n, -1);
+    struct Blk { int64_t off, size; };
+    std::vector<Blk> free_list;
+    int64_t end = 0;
+    auto alloc = [&](int64_t sz) -> int64_t {
+        for (size_t i = 0; i < free_list.size(); ++i) {
+            if (free_list[i].size >= sz) {
+                const int64_t o = free_list[i].off;
+                free_list[i].off += sz; free_list[i].size -= sz;
+                if (!free_list[i].size) free_list.erase(free_list.begin() + i);
+                return o;
+            }
+        }
+        if (!free_list.empty() && free_list.back().off + free_list.back().size == end) {   // grow the tail block
+            const int64_t o = free_list.back().off; end = o + sz; free_list.pop_back(); return o;
+        }
+        const int64_t o = end; end += sz; return o;
+    };
+    auto release = [&](int64_t off, int64_t sz) {
+        Blk b{off, sz};
+        auto it = std::lower_bound(free_list.begin(), free_list.end(), b, [](const Blk& x, const Blk& y) { return x.off < y.off; });
+        it = free_list.insert(it, b);
+        if (it + 1 != free_list.end() && it->off + it->size == (it + 1)->off) { it->size += (it + 1)->size; free_list.erase(it + 1); }
+        if (it != free_list.begin() && (it - 1)->off + (it - 1)->size == it->off) { (it - 1)->size += it->size; free_list.erase(it); }
+    };
+    for (int si = 0; si < (int)h->steps.size(); ++si) {
+        const Layer& l = h->layers[h->steps[si].layer];
+        const int t = l.out_tensor;
+        p.off[t] = alloc(tensor_bytes(h, t, B, T));
+        if (h->cfg.keep_all_outputs) continue;
+        for (int k = 0; k < n; ++k)
+            if (p.off[k] >= 0 && h->last_use[k] == si) release(p.off[k], tensor_bytes(h, k, B, T));
+        if (h->last_use[t] < 0 && l.op != OP_DETECTION) release(p.off[t], tensor_bytes(h, t, B, T));   // dead output
+    }
+    // detection raw outputs must survive until their decode (same step) -> they are released one step
+    // late by construction (last_use == -1 handled below): keep them simple: never reuse det outputs.
+    p.arena = align_up((size_t)end, 256);
+    p.boxes_off = p.arena;
+    size_t o = p.boxes_off + align_up((size_t)B * h->n_boxes * h->row_len * sizeof(float), 256);
+    p.nms_off = o; o += align_up(nms_workspace_bytes(B, h->n_boxes), 256);
+    p.stats_off = o; o += align_up((size_t)1024 * 2 * h->maxC * sizeof(double) + 2 * h->maxC * sizeof(float), 256);
+    p.total = o;
+}
+
+extern "C" int32_t byolo_num_layers(const byolo_t* h) { return h ? (int32_t)h->layers.size() : BYOLO_ERR_ARG; }
+
+extern "C" int32_t byolo_num_boxes(const byolo_t* h, int64_t* n, int32_t* d) {
+    if (!h) return BYOLO_ERR_ARG;
+    if (n) *n = h->n_boxes;
+    if (d) *d = h->row_len;
+    return BYOLO_OK;
+}
+
+static int32_t check_run(byolo_t* h, int32_t B, int32_t T, const char* what, bool need_device = true) {
+    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "%s: null handle", what);
+    if (need_device && !h->finalized) return fail(h, BYOLO_ERR_STATE, "%s: call byolo_finalize first", what);
+    if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
+    if (B < 1 || T < 1) return fail(h, BYOLO_ERR_ARG, "%s: B and T must be >= 1", what);
+    for (const auto& l : h->layers) {
+        const int64_t S = l.stacked ? (int64_t)B * T : B;
+        if (S * l.H * l.W >= (int64_t)1 << 31) return fail(h, BYOLO_ERR_ARG, "%s: B*T*h*w exceeds 2^31 pixels", what);
+    }
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t* out) {
+    int32_t rc = check_run(h, B, T, "byolo_workspace_bytes", false); if (rc) return rc;
+    if (!out) return fail(h, BYOLO_ERR_ARG, "byolo_workspace_bytes: null out");
+    make_plan(h, B, T);
+    *out = h->plan.total;
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char* ws, int B, int T, ConvParams& p) {
+    const Layer& l = h->layers[st.layer];
+    memset(&p, 0, sizeof p);
+    const float* srcs[2] = {nullptr, nullptr};
+    int Cs[2] = {0, 0}, Hs[2] = {1, 1}, Wsz[2] = {1, 1}, sh[2] = {0, 0}, sdiv[2] = {1, 1};
+    for (int k = 0; k < st.in.n; ++k) {
+        const Src& s = st.in.s[k];
+        if (s.layer < 0) { srcs[k] = d_img; Hs[k] = h->cfg.img_h; Wsz[k] = h->cfg.img_w; }
+        else { srcs[k] = reinterpret_cast<const float*>(ws + h->plan.off[s.layer]); Hs[k] = h->layers[s.layer].H; Wsz[k] = h->layers[s.layer].W; }
+        Cs[k] = s.C; sh[k] = s.sh; sdiv[k] = s.tile ? T : 1;
+    }
+    p.src0 = srcs[0]; p.src1 = srcs[1] ? srcs[1] : srcs[0];
+    p.C0 = Cs[0]; p.C1 = Cs[1];
+    p.Hs0 = Hs[0]; p.Ws0 = Wsz[0]; p.Hs1 = Hs[1]; p.Ws1 = Wsz[1];
+    p.sh0 = sh[0]; p.sh1 = sh[1]; p.sdiv0 = sdiv[0]; p.sdiv1 = sdiv[1];
+    p.Hin = Hs[0] << sh[0]; p.Win = Wsz[0] << sh[0];
+    p.Hout = l.H; p.Wout = l.W;
+    p.ksize = l.ksize; p.stride = l.stride; p.pad = l.ksize == 3 ? 1 : 0;
+    const int64_t S = l.stacked ? (int64_t)B * T : B;
+    p.M = (int)(S * l.H * l.W);
+    p.N = l.filters; p.Npad = l.Npad; p.ldc = l.filters;
+    p.cin_tiles = l.Cin / 32; p.KT = l.ksize * l.ksize * p.cin_tiles;
+    p.wpk = dptr(h, l.w_off); p.scale = dptr(h, l.scale_off); p.shift = dptr(h, l.shift_off);
+    p.dst = reinterpret_cast<float*>(ws + h->plan.off[l.out_tensor]);
+    p.inv_keep = 1.f;
+}
+
+static int32_t run_decode(byolo_t* h, char* ws, float* boxes, int B, int T, hipStream_t st) {
+    for (const auto& l : h->layers) {
+        if (l.op != OP_DETECTION) continue;
+        DecodeParams d; memset(&d, 0, sizeof d);
+        d.raw = reinterpret_cast<const float*>(ws + h->plan.off[l.out_tensor]);
+        d.boxes = boxes; d.lh = l.H; d.lw = l.W; d.C = h->cfg.cls_cnt;
+        d.n_total = h->n_boxes; d.box_base = l.box_base; d.layer_id = l.det_id;
+        for (int k = 0; k < 3; ++k) { d.ph[k] = l.priors[2 * k]; d.pw[k] = l.priors[2 * k + 1]; }
+        if (l.det_kind == BYOLO_DET_EPISTEMIC) { d.B = B; d.T = l.stacked ? T : 1; }
+        else { d.B = l.stacked ? B * T : B; d.T = 1; }
+        if (l.det_kind != BYOLO_DET_EPISTEMIC && l.stacked && T > 1)
+            return fail(h, BYOLO_ERR_ARG, "byolo_forward: non-epistemic decode of a stacked (T>1) detection layer");
+        HIPCHK(h, launch_decode(l.det_kind, d, st));
+    }
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
+                                 void* d_workspace, size_t workspace_bytes, float* d_boxes, float* d_rows,
+                                 int32_t* d_kept, int32_t* d_count, void* stream) {
+    int32_t rc = check_run(h, B, T, "byolo_forward"); if (rc) return rc;
+    if (!d_img || !d_workspace) return fail(h, BYOLO_ERR_ARG, "byolo_forward: null image or workspace");
+    if ((d_rows || d_kept || d_count) && !(d_rows && d_kept && d_count))
+        return fail(h, BYOLO_ERR_ARG, "byolo_forward: d_rows, d_kept and d_count go together");
+    make_plan(h, B, T);
+    if (workspace_bytes < h->plan.total)
+        return fail(h, BYOLO_ERR_NOMEM, "byolo_forward: workspace %zu < required %zu bytes", workspace_bytes, h->plan.total);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(d_workspace);
+    h->last_ws = d_workspace;
+    if (h->profiling) {
+        for (auto& e : h->ev) if (!e) HIPCHK(h, hipEventCreate(&e));
+        HIPCHK(h, hipEventRecord(h->ev[0], st));
+    }
+    bool backbone_marked = false;
+    for (const Step& s : h->steps) {
+        const Layer& l = h->layers[s.layer];
+        if (h->profiling && !backbone_marked && h->backbone_end >= 0 && s.layer >= h->backbone_end) {
+            HIPCHK(h, hipEventRecord(h->ev[1], st)); backbone_marked = true;
+        }
+        ConvParams p; fill_conv(h, s, d_img, ws, B, T, p);
+        if (l.op == OP_CONV) {
+            p.flags = EPI_LEAKY;
+            if (l.drop_ordinal >= 0 && dropout_on) {
+                const byolo_drop_keys k = byolo_layer_keys(seed, (uint32_t)l.drop_ordinal, (double)h->cfg.drop_prob);
+                p.flags |= EPI_DROPOUT; p.k0 = k.k0; p.k1 = k.k1; p.thr = k.thr;
+                p.inv_keep = 1.0f / (1.0f - h->cfg.drop_prob);
+            }
+            if (l.fused_residual >= 0) {
+                p.flags |= EPI_RESIDUAL;
+                p.residual = reinterpret_cast<const float*>(ws + h->plan.off[h->layers[l.fused_residual].ref[0]]);
+            }
+        }
+        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, l.tile, st));
+    }
+    if (h->profiling) { if (!backbone_marked) HIPCHK(h, hipEventRecord(h->ev[1], st)); HIPCHK(h, hipEventRecord(h->ev[2], st)); }
+    float* boxes = d_boxes ? d_boxes : reinterpret_cast<float*>(ws + h->plan.boxes_off);
+    if (d_boxes || d_rows) { rc = run_decode(h, ws, boxes, B, T, st); if (rc) return rc; }
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[3], st));
+    if (d_rows) {
+        NmsParams n; memset(&n, 0, sizeof n);
+        n.boxes = boxes; n.B = B; n.N = h->n_boxes; n.D = h->row_len; n.obj_idx = h->obj_idx; n.cls_start = h->cls_start;
+        n.two_class = h->cfg.nms_mode == BYOLO_NMS_TWO_CLASS; n.max_out = h->cfg.max_out; n.iou_thr = h->cfg.iou_thresh;
+        n.ws = ws + h->plan.nms_off; n.ws_bytes = nms_workspace_bytes(B, h->n_boxes);
+        n.rows = d_rows; n.kept = d_kept; n.count = d_count;
+        if (n.two_class && h->cfg.cls_cnt != 2) return fail(h, BYOLO_ERR_ARG, "byolo_forward: 2-class NMS needs cls_cnt == 2");
+        HIPCHK(h, launch_sort_nms(n, st));
+    }
+    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[4], st)); h->ev_valid = true; }
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_layer_output(const byolo_t* h, int32_t idx, const float** d_ptr, int64_t shape[4]) {
+    byolo_t* hh = const_cast<byolo_t*>(h);
+    if (!h || idx < 0 || idx >= (int)h->layers.size()) return fail(hh, BYOLO_ERR_ARG, "byolo_layer_output: bad index");
+    if (!h->cfg.keep_all_outputs) return fail(hh, BYOLO_ERR_STATE, "byolo_layer_output: handle created without keep_all_outputs");
+    if (!h->last_ws || h->plan.B < 0) return fail(hh, BYOLO_ERR_STATE, "byolo_layer_output: no forward has run");
+    const Layer& l = h->layers[idx];
+    if (!l.materialized) return fail(hh, BYOLO_ERR_ARG, "byolo_layer_output: layer %d has no tensor of its own (fused or a view)", idx);
+    if (d_ptr) *d_ptr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->last_ws) + h->plan.off[idx]);
+    if (shape) { shape[0] = l.stacked ? (int64_t)h->plan.B * h->plan.T : h->plan.B; shape[1] = l.H; shape[2] = l.W; shape[3] = l.C; }
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// staged tail entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t byolo_decode(byolo_t* h, int32_t kind, const float* d_raw, int32_t B, int32_t T, int32_t lh, int32_t lw,
+                                const float* priors_hw, int32_t layer_id, float* d_boxes, int64_t n_total,
+                                int64_t box_base, void* stream) {
+    if (!h || !d_raw || !d_boxes || !priors_hw) return fail(h, BYOLO_ERR_ARG, "byolo_decode: null argument");
+    if (kind < 0 || kind > 2 || B < 1 || T < 1 || lh < 1 || lw < 1) return fail(h, BYOLO_ERR_ARG, "byolo_decode: bad argument");
+    if (kind != BYOLO_DET_EPISTEMIC && T != 1) return fail(h, BYOLO_ERR_ARG, "byolo_decode: T > 1 only for the epistemic decode");
+    HIPCHK(h, hipSetDevice(h->device));
+    DecodeParams d; memset(&d, 0, sizeof d);
+    d.raw = d_raw; d.boxes = d_boxes; d.B = B; d.T = T; d.lh = lh; d.lw = lw; d.C = h->cfg.cls_cnt;
+    d.n_total = n_total; d.box_base = box_base; d.layer_id = layer_id;
+    for (int k = 0; k < 3; ++k) { d.ph[k] = priors_hw[2 * k]; d.pw[k] = priors_hw[2 * k + 1]; }
+    hipError_t e = launch_decode(kind, d, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? BYOLO_ERR_ARG : BYOLO_ERR_HIP,
+                                     "byolo_decode: %s (cls_cnt %d supported: 1,2,3,4,8,80)", hipGetErrorString(e), d.C);
+    return BYOLO_OK;
+}
+
+extern "C" size_t byolo_nms_workspace_bytes(int32_t B, int64_t N) { return nms_workspace_bytes(B, N); }
+
+extern "C" int32_t byolo_sort_nms(byolo_t* h, const float* d_boxes, int32_t B, int64_t N, int32_t D, int32_t obj_idx,
+                                  int32_t cls_start_idx, int32_t nms_mode, int32_t max_out, float iou_thresh,
+                                  void* d_sort_ws, size_t ws_bytes, float* d_rows, int32_t* d_kept, int32_t* d_count,
+                                  void* stream) {
+    if (!h || !d_boxes || !d_sort_ws || !d_rows || !d_kept || !d_count) return fail(h, BYOLO_ERR_ARG, "byolo_sort_nms: null argument");
+    if (B < 1 || N < 1 || D < 5 || obj_idx < 4 || obj_idx >= D) return fail(h, BYOLO_ERR_ARG, "byolo_sort_nms: bad shape");
+    if (nms_mode == BYOLO_NMS_TWO_CLASS && (cls_start_idx < 0 || cls_start_idx + 1 >= D)) return fail(h, BYOLO_ERR_ARG, "byolo_sort_nms: bad cls_start_idx");
+    if (max_out < 1 || max_out > 2048) return fail(h, BYOLO_ERR_ARG, "byolo_sort_nms: max_out out of [1,2048]");
+    if (ws_bytes < nms_workspace_bytes(B, N)) return fail(h, BYOLO_ERR_NOMEM, "byolo_sort_nms: workspace too small");
+    HIPCHK(h, hipSetDevice(h->device));
+    NmsParams n; memset(&n, 0, sizeof n);
+    n.boxes = d_boxes; n.B = B; n.N = N; n.D = D; n.obj_idx = obj_idx; n.cls_start = cls_start_idx;
+    n.two_class = nms_mode == BYOLO_NMS_TWO_CLASS; n.max_out = max_out; n.iou_thr = iou_thresh;
+    n.ws = d_sort_ws; n.ws_bytes = ws_bytes; n.rows = d_rows; n.kept = d_kept; n.count = d_count;
+    HIPCHK(h, launch_sort_nms(n, reinterpret_cast<hipStream_t>(stream)));
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// data-dependent BN initialisation for synthetic weights
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B, void* d_workspace, size_t workspace_bytes,
+                                      void* stream) {
+    int32_t rc = check_run(h, B, 1, "byolo_calibrate_bn"); if (rc) return rc;
+    if (!d_img || !d_workspace) return fail(h, BYOLO_ERR_ARG, "byolo_calibrate_bn: null argument");
+    make_plan(h, B, 1);
+    if (workspace_bytes < h->plan.total) return fail(h, BYOLO_ERR_NOMEM, "byolo_calibrate_bn: workspace %zu < %zu", workspace_bytes, h->plan.total);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(d_workspace);
+    double* d_tmp = reinterpret_cast<double*>(ws + h->plan.stats_off);
+    float* d_mean = reinterpret_cast<float*>(ws + h->plan.stats_off + (size_t)1024 * 2 * h->maxC * sizeof(double));
+    float* d_var = d_mean + h->maxC;
+    std::vector<float> sc, sf;
+    for (const Step& s : h->steps) {
+        Layer& l = h->layers[s.layer];
+        ConvParams p; fill_conv(h, s, d_img, ws, B, 1, p);
+        if (l.op == OP_DETECTION) { HIPCHK(h, launch_conv_igemm(p, l.tile, st)); continue; }
+        p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = 0;             // raw conv output
+        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, l.tile, st));
+        const int N = l.filters;
+        HIPCHK(h, launch_channel_stats(p.dst, p.M, N, d_mean, d_var, d_tmp, st));
+        HIPCHK(h, hipMemcpyAsync(h->params[l.p_mean].data.data(), d_mean, sizeof(float) * N, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(h->params[l.p_var].data.data(), d_var, sizeof(float) * N, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        fold_layer(h, l, sc, sf);
+        HIPCHK(h, hipMemcpyAsync(dptr(h, l.scale_off), sc.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(dptr(h, l.shift_off), sf.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        const float* res = l.fused_residual >= 0
+            ? reinterpret_cast<const float*>(ws + h->plan.off[h->layers[l.fused_residual].ref[0]]) : nullptr;
+        HIPCHK(h, launch_bn_act_inplace(p.dst, p.M, N, dptr(h, l.scale_off), dptr(h, l.shift_off), res, 1, st));
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling / cost model
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t byolo_set_profiling(byolo_t* h, int32_t on) {
+    if (!h) return BYOLO_ERR_ARG;
+    h->profiling = on != 0; h->ev_valid = false;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_stage_ms(byolo_t* h, float ms[4]) {
+    if (!h || !ms) return BYOLO_ERR_ARG;
+    if (!h->ev_valid) return fail(h, BYOLO_ERR_STATE, "byolo_stage_ms: no profiled forward");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(h->ev[4]));
+    for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops) {
+    if (!h || !flops || B < 1 || T < 1) return BYOLO_ERR_ARG;
+    double f = 0;
+    for (const auto& l : h->layers) {
+        if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
+        const double S = l.stacked ? (double)B * T : B;
+        f += 2.0 * S * l.H * l.W * (double)(l.ksize * l.ksize * l.Cin) * l.filters;
+    }
+    *flops = f;
+    return BYOLO_OK;
+}

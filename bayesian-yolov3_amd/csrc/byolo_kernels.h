@@ -1,0 +1,75 @@
+// byolo_kernels.h -- host-callable launchers of the gfx950 kernels (internal; the public
+// boundary is include/byolo.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace byk {
+
+enum : int { EPI_LEAKY = 1, EPI_DROPOUT = 2, EPI_RESIDUAL = 4 };
+
+// One fused convolution  dst = [residual +] leaky( mask * (conv(src) * scale [/keep]) + shift )
+// as an implicit GEMM  M = S*Hout*Wout (pixels), N = cout, K = ksize^2 * (C0 + C1).
+// The input is the channel concat of up to two NHWC sources, each optionally read through a
+// nearest x2 upsample (sh = 1) and/or a T-fold batch tile (sdiv = T): the reference's
+// tf.image.resize_nearest_neighbor / tf.concat(axis=3) / tf.concat([x]*T, axis=0)
+// (lib_yolo/layers.py:578-597) are never materialised.
+struct ConvParams {
+    const float* src0; const float* src1;
+    const float* wpk;                 // packed weights [K/32][Npad][32]   (direct kernel: HWIO as is)
+    const float* scale; const float* shift;   // per output channel
+    const float* residual;            // [M][ldc] or null
+    float* dst;                       // [M][ldc]
+    int C0, C1;                       // channels of the two sources (C1 == 0: single source)
+    int Hs0, Ws0, Hs1, Ws1;           // physical spatial size of each source
+    int sh0, sh1;                     // upsample shift per source (0 | 1)
+    int sdiv0, sdiv1;                 // sample divisor per source (1 | T)
+    int Hin, Win, Hout, Wout;         // logical conv input / output size
+    int ksize, stride, pad;
+    int M, N, Npad, ldc;
+    int KT, cin_tiles;                // K/32, (C0+C1)/32
+    int flags;                        // EPI_*
+    float inv_keep;                   // 1/(1-p) when EPI_DROPOUT
+    uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
+};
+
+// tile configuration ids
+enum : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };
+int conv_tile_bn(int tile);           // BN of a tile config
+int conv_pick_tile(int N);            // tile config for cout = N
+hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st);
+hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st);   // small-cin (stem) direct conv
+
+// ---- calibration helpers -------------------------------------------------------------------
+// per-channel mean / population variance of x [M][C]  -> stats [2][C] (double accumulation)
+hipError_t launch_channel_stats(const float* x, int64_t M, int C, float* d_mean, float* d_var, double* d_tmp,
+                                hipStream_t st);
+// in place: x = [residual +] leaky(x * scale + shift)
+hipError_t launch_bn_act_inplace(float* x, int64_t M, int C, const float* scale, const float* shift,
+                                 const float* residual, int leaky, hipStream_t st);
+// scale = gamma * rsqrt(var + eps), shift = beta - mean * scale   (device-side fold)
+hipError_t launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                          float* scale, float* shift, int C, hipStream_t st);
+
+// ---- tail ------------------------------------------------------------------------------------
+struct DecodeParams {
+    const float* raw;        // [S, lh, lw, 3*blk]
+    float* boxes;            // [B, n_total, D]
+    int B, T, lh, lw, C;     // C = cls_cnt
+    int64_t n_total, box_base;
+    float ph[3], pw[3];
+    int layer_id;
+};
+hipError_t launch_decode(int kind, const DecodeParams& p, hipStream_t st);
+
+size_t nms_workspace_bytes(int B, int64_t N);
+struct NmsParams {
+    const float* boxes;      // [B, N, D]
+    int B; int64_t N; int D, obj_idx, cls_start;
+    int two_class, max_out; float iou_thr;
+    void* ws; size_t ws_bytes;
+    float* rows; int32_t* kept; int32_t* count;
+};
+hipError_t launch_sort_nms(const NmsParams& p, hipStream_t st);
+
+}  // namespace byk

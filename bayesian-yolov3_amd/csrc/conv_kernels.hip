@@ -1,0 +1,358 @@
+// conv_kernels.hip -- K1..K5 of SURVEY.md section 2.1 as ONE fused implicit-GEMM kernel family for
+// gfx950 (CDNA4), exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, per call, the reference's op chain of lib_yolo/layers.py:545-575
+//   tf.layers.conv2d(no bias) -> tf.layers.dropout -> tf.layers.batch_normalization -> leaky_relu
+// plus, folded into the operand loader / epilogue, layers.py:505-507 (residual add), :578-580
+// (nearest x2 upsample), :583-592 (channel concat), :595-597 (T-fold batch tile), :533-537
+// (darknet stride-2 padding) and :600-613 (detection conv + bias).
+//
+// GEMM view: M = S*Hout*Wout output pixels, N = cout, K = ksize^2 * Cin, NHWC activations
+// (a K-slice of 32 channels of one tap is 128 contiguous bytes per pixel), weights pre-packed at
+// byolo_finalize() as [K/32][Npad][32] so a block's B tile is one contiguous BN*128-byte read.
+// Block = 256 threads = 4 wave64; block tile BM x BN x 32, each wave owns TM x TN tiles of 32x32
+// accumulated in registers; operands staged global -> VGPR -> LDS (row stride 36 floats: the
+// ds_read_b128 fragment reads and the ds_write_b128 staging writes are bank-conflict free),
+// double-buffered so the loads of K-tile t+1 are in flight under the MFMAs of tile t.
+// The K order inside a 32-slice is permuted (lane-half h of MFMA step j consumes k = 8q+4h+j) so
+// that every lane fetches its four A (and B) operands of four MFMA steps with ONE ds_read_b128.
+#include <hip/hip_runtime.h>
+#include "byolo_kernels.h"
+#include "byolo_rng.h"
+
+namespace byk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BK = 32;
+static constexpr int LDS_LD = 36;        // floats per staged row (32 + 4 pad)
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // Blocks are dispatched round-robin over the 8 XCDs (bid % 8); give each XCD a contiguous
+    // range of logical tiles so neighbouring tiles (same A rows / same weights) share its L2.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_LD = BM * 8 / 256;          // float4 loads per thread per A tile
+    constexpr int B_LD = BN * 8 / 256;          // float4 loads per thread per B tile
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1, "tile config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                            // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;          // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x;
+    const int n_tiles = p.Npad / BN;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = logical % n_tiles, tile_m = logical / n_tiles;
+
+    // ---- per-thread A-row bookkeeping (4 rows at BM = 128) ---------------------------------
+    const int a_q = tid & 7;
+    int a_iy0[A_LD], a_ix0[A_LD], a_s0[A_LD], a_s1[A_LD];
+    const int hw = p.Hout * p.Wout;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int m = tile_m * BM + (tid >> 3) + 32 * j;
+        if (m < p.M) {
+            const int s = m / hw, rem = m - s * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_iy0[j] = oy * p.stride - p.pad;
+            a_ix0[j] = ox * p.stride - p.pad;
+            a_s0[j] = s / p.sdiv0;
+            a_s1[j] = s / p.sdiv1;
+        } else {
+            a_iy0[j] = -(1 << 28);              // every tap out of bounds -> zeros
+            a_ix0[j] = 0; a_s0[j] = 0; a_s1[j] = 0;
+        }
+    }
+
+    f32x4 a_reg[A_LD], b_reg[B_LD];
+
+    auto load_tile = [&](int kt) {
+        const int tap = kt / p.cin_tiles;
+        int cc = (kt - tap * p.cin_tiles) * BK;
+        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        const float* src; int C, Hs, Ws, sh; bool second;
+        if (cc < p.C0) { src = p.src0; C = p.C0; Hs = p.Hs0; Ws = p.Ws0; sh = p.sh0; second = false; }
+        else { src = p.src1; C = p.C1; Hs = p.Hs1; Ws = p.Ws1; sh = p.sh1; cc -= p.C0; second = true; }
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
+                const int s = second ? a_s1[j] : a_s0[j];
+                const size_t off = (((size_t)s * Hs + (iy >> sh)) * Ws + (ix >> sh)) * C + cc + a_q * 4;
+                v = *reinterpret_cast<const f32x4*>(src + off);
+            }
+            a_reg[j] = v;
+        }
+        const float* wsrc = p.wpk + ((size_t)kt * p.Npad + (size_t)tile_n * BN) * BK;
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            b_reg[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(tid + 256 * j) * 4);
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * LDS_LD;
+        float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j)
+            *reinterpret_cast<f32x4*>(a + ((tid >> 3) + 32 * j) * LDS_LD + a_q * 4) = a_reg[j];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int idx = tid + 256 * j;
+            *reinterpret_cast<f32x4*>(b + (idx >> 3) * LDS_LD + (idx & 7) * 4) = b_reg[j];
+        }
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < p.KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < p.KT) load_tile(kt + 1);          // global loads in flight under the MFMAs
+
+        const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + li) * LDS_LD + lh * 4;
+        const float* b = Bs + buf * BN * LDS_LD + (wn * TN * 32 + li) * LDS_LD + lh * 4;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_LD + kq * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_LD + kq * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+
+        if (kt + 1 < p.KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue: [dropout mask] * scale, + shift, leaky, [+ residual] ------------------
+    // C/D map of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = tile_n * BN + wn * TN * 32 + j * 32 + li;
+        const bool n_ok = n < p.N;
+        const float sc = n_ok ? p.scale[n] * (do_drop ? p.inv_keep : 1.f) : 0.f;
+        const float sf = n_ok ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = tile_m * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n_ok && m < p.M) {
+                    float v = acc[i][j][r] * sc;
+                    if (do_drop) {
+                        const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+                        if (!byolo_keep(idx, p.k0, p.k1, p.thr)) v = 0.f;
+                    }
+                    v += sf;
+                    if (do_leaky) v = fmaxf(v, 0.1f * v);
+                    const size_t o = (size_t)m * p.ldc + n;
+                    if (do_res) v += p.residual[o];
+                    p.dst[o] = v;
+                }
+            }
+        }
+    }
+}
+
+int conv_tile_bn(int tile) { return tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32); }
+
+int conv_pick_tile(int N) {
+    if (N > 64) return TILE_128x128;
+    if (N > 32) return TILE_128x64;
+    return TILE_128x32;
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    const int grid = ((p.M + BM - 1) / BM) * (p.Npad / BN);
+    auto k = conv_igemm_kernel<BM, BN, WM, WN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st) {
+    switch (tile) {
+        case TILE_128x128: return launch_cfg<128, 128, 2, 2>(p, st);
+        case TILE_128x64:  return launch_cfg<128, 64, 2, 2>(p, st);
+        default:           return launch_cfg<128, 32, 4, 1>(p, st);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct convolution for tiny Cin (the 3-channel stem, lib_yolo/darknet.py:10): HBM-bound
+// (writes 128 B per pixel, reads 12 B), so plain VALU FMAs: thread = (pixel, group of 8 output
+// channels); weights (HWIO, k*k*Cin x cout) broadcast from LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];    // [K][N]
+    const int Cin = p.C0, K = p.ksize * p.ksize * Cin, N = p.N;
+    for (int i = threadIdx.x; i < K * N; i += blockDim.x) wl[i] = p.wpk[i];
+    __syncthreads();
+    const int groups = N >> 3;
+    const int64_t total = (int64_t)p.M * groups;
+    const int hw = p.Hout * p.Wout;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(gid / groups), g = (int)(gid - (int64_t)m * groups);
+        const int s = m / hw, rem = m - s * hw;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+        for (int ky = 0; ky < p.ksize; ++ky) {
+            const int iy = oy * p.stride - p.pad + ky;
+            for (int kx = 0; kx < p.ksize; ++kx) {
+                const int ix = ox * p.stride - p.pad + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                const float* px = p.src0 + (((size_t)(s / p.sdiv0) * p.Hs0 + (ok ? iy : 0)) * p.Ws0 + (ok ? ix : 0)) * Cin;
+                for (int c = 0; c < Cin; ++c) {
+                    const float x = ok ? px[c] : 0.f;
+                    const float* w = wl + ((ky * p.ksize + kx) * Cin + c) * N + g * 8;
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) acc[o] = fmaf(x, w[o], acc[o]);
+                }
+            }
+        }
+        float out[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int n = g * 8 + o;
+            float v = acc[o] * p.scale[n];
+            if (p.flags & EPI_DROPOUT) {
+                v *= p.inv_keep;
+                if (!byolo_keep((uint64_t)m * (uint64_t)N + (uint64_t)n, p.k0, p.k1, p.thr)) v = 0.f;
+            }
+            v += p.shift[n];
+            if (p.flags & EPI_LEAKY) v = fmaxf(v, 0.1f * v);
+            if (p.flags & EPI_RESIDUAL) v += p.residual[(size_t)m * p.ldc + n];
+            out[o] = v;
+        }
+        float* d = p.dst + (size_t)m * p.ldc + g * 8;
+        if ((p.ldc & 3) == 0) {
+            *reinterpret_cast<f32x4*>(d) = f32x4{out[0], out[1], out[2], out[3]};
+            *reinterpret_cast<f32x4*>(d + 4) = f32x4{out[4], out[5], out[6], out[7]};
+        } else {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) d[o] = out[o];
+        }
+    }
+}
+
+hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st) {
+    const int K = p.ksize * p.ksize * p.C0;
+    const size_t lds = (size_t)K * p.N * sizeof(float);
+    const int64_t total = (int64_t)p.M * (p.N >> 3);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// calibration helpers (byolo_calibrate_bn): per-channel batch statistics, device-side BN fold,
+// in-place BN + leaky [+ residual].  Not on the inference hot path.
+// ---------------------------------------------------------------------------------------------
+__global__ void channel_stats_partial(const float* x, int64_t M, int C, double* tmp /*[blocks][2][C]*/) {
+    // block handles a strided set of rows; thread c-strided over channels
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+            const double v = x[m * C + c];
+            s += v; q += v * v;
+        }
+        tmp[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
+        tmp[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+    }
+}
+__global__ void channel_stats_final(const double* tmp, int blocks, int64_t M, int C, float* mean, float* var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < blocks; ++b) { s += tmp[((size_t)b * 2) * C + c]; q += tmp[((size_t)b * 2 + 1) * C + c]; }
+    const double mu = s / (double)M;
+    double v = q / (double)M - mu * mu;
+    if (v < 0) v = 0;
+    mean[c] = (float)mu; var[c] = (float)v;
+}
+static constexpr int STATS_BLOCKS = 1024;
+hipError_t launch_channel_stats(const float* x, int64_t M, int C, float* d_mean, float* d_var, double* d_tmp,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(channel_stats_partial, dim3(STATS_BLOCKS), dim3(256), 0, st, x, M, C, d_tmp);
+    hipLaunchKernelGGL(channel_stats_final, dim3((C + 255) / 256), dim3(256), 0, st, d_tmp, STATS_BLOCKS, M, C,
+                       d_mean, d_var);
+    return hipGetLastError();
+}
+
+__global__ void fold_bn_kernel(const float* g, const float* b, const float* m, const float* v, float eps,
+                               float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float inv = g[c] * (1.0f / sqrtf(v[c] + eps));
+    scale[c] = inv;
+    shift[c] = b[c] - m[c] * inv;
+}
+hipError_t launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                          float* scale, float* shift, int C, hipStream_t st) {
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mean, var, eps, scale,
+                       shift, C);
+    return hipGetLastError();
+}
+
+__global__ void bn_act_inplace_kernel(float* x, int64_t total, int C, const float* scale, const float* shift,
+                                      const float* residual, int leaky) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float v = x[i] * scale[c] + shift[c];
+        if (leaky) v = fmaxf(v, 0.1f * v);
+        if (residual) v += residual[i];
+        x[i] = v;
+    }
+}
+hipError_t launch_bn_act_inplace(float* x, int64_t M, int C, const float* scale, const float* shift,
+                                 const float* residual, int leaky, hipStream_t st) {
+    const int64_t total = M * C;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_act_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, total, C, scale, shift,
+                       residual, leaky);
+    return hipGetLastError();
+}
+
+}  // namespace byk

@@ -1,0 +1,493 @@
+// tail_kernels.hip -- anchor decode (K6), MC-sample aggregation + decode (K7), score sort (K8) and
+// greedy NMS + gather (K9) of SURVEY.md section 2.1, as wavefront-level gfx950 kernels.
+//
+//   decode_std / decode_ale : lib_yolo/layers.py:11-84 (split) + :191-346 (decode) + :349-358 (entropies)
+//   decode_epi              : lib_yolo/layers.py:361-411 (T-reduction) + :414-502 (decode)
+//   all three write rows straight at their concat_bbox position (inference_epistemic.py:173-184,
+//   inference_aleatoric.py:181-192): n = base(layer) + prior*lh*lw + row*lw + col
+//   sort_keys + nms         : tf.image.non_max_suppression(boxes[:, :4], boxes[:, obj_idx], 1000) + tf.gather
+//                             (inference_epistemic.py:99-128 incl. the commented 2-class variant)
+// HBM-bound / dependency-bound byte work: no MFMA here.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "byolo_kernels.h"
+
+namespace byk {
+
+// ------------------------------------------------------------------------------------------------
+// element-wise maths (IEEE semantics kept: 0*log(0) = NaN exactly like the reference, App. D.2)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float logistic_entropy_(float s) {          // layers.py:349-353
+    const float no_obj = (1.0f - s) * logf(1.0f - s);
+    const float obj = s * logf(s);
+    return -(no_obj + obj);
+}
+template <int C>
+__device__ __forceinline__ void softmax_(const float* x, float* p) {   // tf.nn.softmax (max-subtracted)
+    float mx = x[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] = expf(x[c] - mx); sum += p[c]; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = p[c] / sum;
+}
+template <int C>
+__device__ __forceinline__ float softmax_entropy_(const float* p) {    // layers.py:356-358
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) s += p[c] * logf(p[c]);
+    return -s;
+}
+__device__ __forceinline__ void corners_(float tx, float ty, float tw, float th, int col, int row, int lw, int lh,
+                                         float pw, float ph, float* o /*y0,x0,y1,x1*/) {
+    // layers.py:237-249 / :316-328 / :471-483
+    const float x = ((float)col + sigmoidf_(tx)) / (float)lw;
+    const float y = ((float)row + sigmoidf_(ty)) / (float)lh;
+    const float w = expf(tw) * pw, h = expf(th) * ph;
+    const float w2 = w / 2, h2 = h / 2;
+    o[0] = y - h2; o[1] = x - w2; o[2] = y + h2; o[3] = x + w2;
+}
+
+// thread <-> (image b, cell, prior p), prior fastest: a wave reads 64 * blk contiguous floats.
+template <int C>
+__global__ void decode_std_kernel(const DecodeParams p) {
+    constexpr int BLK = 5 + C, D = 5 + C;
+    const int cells = p.lh * p.lw;
+    const int64_t total = (int64_t)p.B * cells * 3;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int pr = (int)(gid % 3);
+        const int64_t bc = gid / 3;
+        const int cell = (int)(bc % cells), b = (int)(bc / cells);
+        const float* d = p.raw + (size_t)bc * (3 * BLK) + pr * BLK;
+        float v[BLK];
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) v[i] = d[i];
+        float out[D];
+        corners_(v[0], v[1], v[2], v[3], cell % p.lw, cell / p.lw, p.lw, p.lh, p.pw[pr], p.ph[pr], out);
+        out[4] = sigmoidf_(v[4]);
+        softmax_<C>(v + 5, out + 5);
+        float* o = p.boxes + ((size_t)b * p.n_total + p.box_base + (size_t)pr * cells + cell) * D;
+#pragma unroll
+        for (int i = 0; i < D; ++i) o[i] = out[i];
+    }
+}
+
+template <int C>
+__global__ void decode_ale_kernel(const DecodeParams p) {
+    constexpr int BLK = 2 * (5 + C), D = 14 + C;
+    const int cells = p.lh * p.lw;
+    const int64_t total = (int64_t)p.B * cells * 3;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int pr = (int)(gid % 3);
+        const int64_t bc = gid / 3;
+        const int cell = (int)(bc % cells), b = (int)(bc / cells);
+        const float* d = p.raw + (size_t)bc * (3 * BLK) + pr * BLK;
+        float v[BLK];
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) v[i] = d[i];
+        // [x,y,w,h, logvar x4, obj, log_obj_std, cls xC, log_cls_std xC]   (layers.py:41-84)
+        float out[D];
+        corners_(v[0], v[1], v[2], v[3], cell % p.lw, cell / p.lw, p.lw, p.lh, p.pw[pr], p.ph[pr], out);
+        float prod = 1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { out[4 + i] = expf(v[4 + i]); }
+        prod = ((out[4] * out[5]) * out[6]) * out[7];                   // tf.reduce_prod
+        out[8] = prod;
+        const float obj = sigmoidf_(v[8]);
+        out[9] = obj;
+        out[10] = logistic_entropy_(obj);
+        softmax_<C>(v + 10, out + 11);
+        out[11 + C] = softmax_entropy_<C>(out + 11);
+        out[12 + C] = (float)p.layer_id;
+        out[13 + C] = (float)pr;
+        float* o = p.boxes + ((size_t)b * p.n_total + p.box_base + (size_t)pr * cells + cell) * D;
+#pragma unroll
+        for (int i = 0; i < D; ++i) o[i] = out[i];
+    }
+}
+
+// 4x4 determinant by LU with partial pivoting (what tf.linalg.det does via Eigen PartialPivLU)
+__device__ __forceinline__ float det4_(float a[4][4]) {
+    float det = 1.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int piv = k; float best = fabsf(a[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r) { const float v = fabsf(a[r][k]); if (v > best) { best = v; piv = r; } }
+        if (piv != k) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float t = a[k][c]; a[k][c] = a[piv][c]; a[piv][c] = t; }
+            det = -det;
+        }
+        const float d = a[k][k];
+        det *= d;
+        if (d != 0.f) {
+#pragma unroll
+            for (int r = k + 1; r < 4; ++r) {
+                const float f = a[r][k] / d;
+#pragma unroll
+                for (int c = k + 1; c < 4; ++c) a[r][c] -= f * a[k][c];
+            }
+        }
+    }
+    return det;
+}
+
+// One lane per (image, cell, prior): a single pass over the image's T samples keeps
+// 4 + 10 + 4 + 1 + 1 + C + 1 running sums in registers.
+template <int C>
+__global__ void decode_epi_kernel(const DecodeParams p) {
+    constexpr int BLK = 2 * (5 + C), D = 21 + C;
+    const int cells = p.lh * p.lw;
+    const int64_t total = (int64_t)p.B * cells * 3;
+    const size_t sample_stride = (size_t)cells * 3 * BLK;
+    const float invT = 1.0f / (float)p.T;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int pr = (int)(gid % 3);
+        const int64_t bc = gid / 3;
+        const int cell = (int)(bc % cells), b = (int)(bc / cells);
+        const float* d0 = p.raw + ((size_t)b * p.T) * sample_stride + (size_t)cell * (3 * BLK) + pr * BLK;
+        float s_loc[4] = {0, 0, 0, 0}, s_ll[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s_var[4] = {0, 0, 0, 0};
+        float s_obj = 0.f, s_objH = 0.f, s_cls[C], s_clsH = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) s_cls[c] = 0.f;
+        for (int t = 0; t < p.T; ++t) {
+            const float* d = d0 + (size_t)t * sample_stride;
+            float v[BLK];
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) v[i] = d[i];
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s_loc[i] += v[i];
+                s_var[i] += expf(v[4 + i]);
+#pragma unroll
+                for (int j = i; j < 4; ++j) s_ll[q++] += v[i] * v[j];
+            }
+            const float obj = sigmoidf_(v[8]);
+            s_obj += obj;
+            s_objH += logistic_entropy_(obj);
+            float pc[C];
+            softmax_<C>(v + 10, pc);
+#pragma unroll
+            for (int c = 0; c < C; ++c) s_cls[c] += pc[c];
+            s_clsH += softmax_entropy_<C>(pc);
+        }
+        float ev[4], cov[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ev[i] = s_loc[i] * invT;
+        {
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = i; j < 4; ++j) {
+                    const float c = s_ll[q++] * invT - ev[i] * ev[j];   // E[l l^T] - E[l]E[l]^T (layers.py:383)
+                    cov[i][j] = c; cov[j][i] = c;
+                }
+        }
+        float out[D];
+        corners_(ev[0], ev[1], ev[2], ev[3], cell % p.lw, cell / p.lw, p.lw, p.lh, p.pw[pr], p.ph[pr], out);
+        float ale_sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[4 + i] = cov[i][i];
+            const float a = s_var[i] * invT;
+            out[8 + i] = a;
+            ale_sum += a;
+        }
+        out[12] = det4_(cov);
+        out[13] = ale_sum;
+        const float obj_mean = s_obj * invT;
+        const float objH = logistic_entropy_(obj_mean);
+        out[14] = obj_mean;
+        out[15] = objH - s_objH * invT;
+        out[16] = objH;
+        float cm[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { cm[c] = s_cls[c] * invT; out[17 + c] = cm[c]; }
+        const float clsH = softmax_entropy_<C>(cm);
+        out[17 + C] = clsH - s_clsH * invT;
+        out[18 + C] = clsH;
+        out[19 + C] = (float)p.layer_id;
+        out[20 + C] = (float)pr;
+        float* o = p.boxes + ((size_t)b * p.n_total + p.box_base + (size_t)pr * cells + cell) * D;
+#pragma unroll
+        for (int i = 0; i < D; ++i) o[i] = out[i];
+    }
+}
+
+template <int C>
+static hipError_t launch_decode_c(int kind, const DecodeParams& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.B * p.lh * p.lw * 3;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (kind == 0) hipLaunchKernelGGL(decode_std_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else if (kind == 1) hipLaunchKernelGGL(decode_ale_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(decode_epi_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode(int kind, const DecodeParams& p, hipStream_t st) {
+    switch (p.C) {
+        case 1: return launch_decode_c<1>(kind, p, st);
+        case 2: return launch_decode_c<2>(kind, p, st);
+        case 3: return launch_decode_c<3>(kind, p, st);
+        case 4: return launch_decode_c<4>(kind, p, st);
+        case 8: return launch_decode_c<8>(kind, p, st);
+        case 80: return launch_decode_c<80>(kind, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: per-image sort of (score desc, index asc) as 64-bit keys, bitonic, one 1024-thread
+// workgroup per image; sub-sequences of SORT_CH keys are sorted in LDS, only strides >= SORT_CH go
+// through global memory (L2-resident).
+// ------------------------------------------------------------------------------------------------
+static constexpr int SORT_THREADS = 1024;
+static constexpr int SORT_CH = 4096;                        // u64 keys per LDS chunk (32 KiB)
+
+static inline int64_t next_pow2(int64_t n) { int64_t p = 1; while (p < n) p <<= 1; return p; }
+static inline int64_t sort_np(int64_t N) { const int64_t p = next_pow2(N); return p < SORT_CH ? SORT_CH : p; }
+
+size_t nms_workspace_bytes(int B, int64_t N) {
+    return (size_t)B * (size_t)sort_np(N) * sizeof(unsigned long long) + (size_t)B * 16;
+}
+
+__device__ __forceinline__ unsigned int score_key(float f) {
+    // ascending key == descending score; NaN and scores <= -FLT_MAX are not candidates
+    // (TF: `score > std::numeric_limits<float>::lowest()`), they sort last.
+    if (!(f > -FLT_MAX)) return 0xFFFFFFFFu;
+    unsigned int u = __float_as_uint(f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~u;
+}
+
+__device__ __forceinline__ void ce(unsigned long long& a, unsigned long long& b, bool up) {
+    if ((a > b) == up) { const unsigned long long t = a; a = b; b = t; }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_keys_kernel(const float* boxes, int64_t N, int D, int obj_idx,
+                                                                 int64_t NP, unsigned long long* keys_all,
+                                                                 int* n_valid_all) {
+    __shared__ unsigned long long sk[SORT_CH];
+    __shared__ int s_valid;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned long long* keys = keys_all + (size_t)b * NP;
+    const float* bx = boxes + (size_t)b * N * D;
+    if (tid == 0) s_valid = 0;
+    __syncthreads();
+    int local_valid = 0;
+    const int64_t nch = NP / SORT_CH;
+    // phase 1: build keys and fully sort each chunk in LDS (direction by global index)
+    for (int64_t ch = 0; ch < nch; ++ch) {
+        for (int i = tid; i < SORT_CH; i += SORT_THREADS) {
+            const int64_t g = ch * SORT_CH + i;
+            unsigned long long k = ~0ull;
+            if (g < N) {
+                const unsigned int sk32 = score_key(bx[(size_t)g * D + obj_idx]);
+                if (sk32 != 0xFFFFFFFFu) { k = ((unsigned long long)sk32 << 32) | (unsigned int)g; ++local_valid; }
+            }
+            sk[i] = k;
+        }
+        __syncthreads();
+        for (int k = 2; k <= SORT_CH; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < SORT_CH / 2; t += SORT_THREADS) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const bool up = (((ch * SORT_CH + i) & k) == 0);
+                    ce(sk[i], sk[i + j], up);
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < SORT_CH; i += SORT_THREADS) keys[ch * SORT_CH + i] = sk[i];
+        __syncthreads();
+    }
+    // phase 2: merge across chunks
+    for (int64_t k = 2 * (int64_t)SORT_CH; k <= NP; k <<= 1) {
+        for (int64_t j = k >> 1; j >= SORT_CH; j >>= 1) {
+            for (int64_t t = tid; t < NP / 2; t += SORT_THREADS) {
+                const int64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const bool up = ((i & k) == 0);
+                unsigned long long a = keys[i], c = keys[i + j];
+                if ((a > c) == up) { keys[i] = c; keys[i + j] = a; }
+            }
+            __syncthreads();
+        }
+        for (int64_t ch = 0; ch < nch; ++ch) {
+            for (int i = tid; i < SORT_CH; i += SORT_THREADS) sk[i] = keys[ch * SORT_CH + i];
+            __syncthreads();
+            const bool up = (((ch * SORT_CH) & k) == 0);
+            for (int j = SORT_CH >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < SORT_CH / 2; t += SORT_THREADS) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    ce(sk[i], sk[i + j], up);
+                }
+                __syncthreads();
+            }
+            for (int i = tid; i < SORT_CH; i += SORT_THREADS) keys[ch * SORT_CH + i] = sk[i];
+            __syncthreads();
+        }
+    }
+    atomicAdd(&s_valid, local_valid);
+    __syncthreads();
+    if (tid == 0) n_valid_all[b] = s_valid;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9: greedy NMS, one 1024-thread workgroup per image, candidates in sorted order, 1024 per round:
+//   phase A  every lane tests its candidate against all boxes kept in earlier rounds (LDS broadcast)
+//   phase B  the 16 waves take turns: intra-wave 64x64 suppression bit-matrix, serial resolve over
+//            the 64 candidates with readlane, kept boxes appended to the LDS list, the later waves
+//            then test against just those.
+// IoU is evaluated operation-for-operation as TensorFlow's IOU() in float32 with single rounding
+// (__f*_rn: no FMA contraction), std::min/std::max NaN semantics -> kept indices bit-exact.
+// ------------------------------------------------------------------------------------------------
+static constexpr int NMS_THREADS = 1024;
+static constexpr int NMS_MAXK = 2048;                        // max_out limit per class pass
+
+struct NBox { float y0, x0, y1, x1, area; };
+
+__device__ __forceinline__ float smin_(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float smax_(float a, float b) { return (a < b) ? b : a; }
+
+__device__ __forceinline__ NBox make_box(float b0, float b1, float b2, float b3) {
+    NBox r;
+    r.y0 = smin_(b0, b2); r.x0 = smin_(b1, b3);
+    r.y1 = smax_(b0, b2); r.x1 = smax_(b1, b3);
+    r.area = __fmul_rn(__fsub_rn(r.y1, r.y0), __fsub_rn(r.x1, r.x0));
+    return r;
+}
+__device__ __forceinline__ bool iou_gt(const NBox& i, const NBox& j, float thr) {
+    if (i.area <= 0.f || j.area <= 0.f) return false;        // IoU = 0
+    const float iy0 = smax_(i.y0, j.y0), ix0 = smax_(i.x0, j.x0);
+    const float iy1 = smin_(i.y1, j.y1), ix1 = smin_(i.x1, j.x1);
+    const float inter = __fmul_rn(smax_(__fsub_rn(iy1, iy0), 0.f), smax_(__fsub_rn(ix1, ix0), 0.f));
+    const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(i.area, j.area), inter));
+    return iou > thr;
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* boxes, int64_t N, int D, int obj_idx,
+                                                          int cls_start, int two_class, int max_out, float thr,
+                                                          int64_t NP, const unsigned long long* keys_all,
+                                                          const int* n_valid_all, float* rows, int32_t* kept,
+                                                          int32_t* count) {
+    __shared__ float k_y0[NMS_MAXK], k_x0[NMS_MAXK], k_y1[NMS_MAXK], k_x1[NMS_MAXK], k_ar[NMS_MAXK];
+    __shared__ int k_idx[2 * NMS_MAXK];
+    __shared__ float w_y0[64], w_x0[64], w_y1[64], w_x1[64], w_ar[64];
+    __shared__ int s_nk;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* bx = boxes + (size_t)b * N * D;
+    const unsigned long long* keys = keys_all + (size_t)b * NP;
+    const int n_valid = n_valid_all[b];
+    const int npass = two_class ? 2 : 1;
+    int out_base = 0, first_cnt = 0;
+
+    for (int pass = 0; pass < npass; ++pass) {
+        if (tid == 0) s_nk = 0;
+        __syncthreads();
+        int nk_cur = 0;                                      // register copy of s_nk, uniform across the block
+        for (int base = 0; base < n_valid && nk_cur < max_out; base += NMS_THREADS) {
+            const int i = base + tid;
+            bool alive = i < n_valid;
+            int idx = -1;
+            NBox me = {0, 0, 0, 0, 0};
+            if (alive) {
+                idx = (int)(keys[i] & 0xFFFFFFFFull);
+                const float* r = bx + (size_t)idx * D;
+                me = make_box(r[0], r[1], r[2], r[3]);
+                if (two_class) {
+                    const float c0 = r[cls_start], c1 = r[cls_start + 1];
+                    alive = (pass == 0) ? (c0 > c1) : (c1 > c0);      // strict; ties dropped (:108-110)
+                }
+            }
+            // phase A: against everything kept in earlier rounds
+            for (int k = 0; k < nk_cur; ++k) {
+                if (alive) {
+                    const NBox kb = {k_y0[k], k_x0[k], k_y1[k], k_x1[k], k_ar[k]};
+                    if (iou_gt(me, kb, thr)) alive = false;
+                }
+            }
+            // phase B: the 16 waves take turns
+            for (int sub = 0; sub < NMS_THREADS / 64 && nk_cur < max_out; ++sub) {
+                if (wave == sub) {
+                    const unsigned long long alive_mask = __ballot(alive);
+                    if (alive_mask) {
+                        w_y0[lane] = me.y0; w_x0[lane] = me.x0; w_y1[lane] = me.y1; w_x1[lane] = me.x1; w_ar[lane] = me.area;
+                        unsigned long long supp = 0ull;      // bit e: earlier live candidate e overlaps me
+                        for (int e = 0; e < 64; ++e) {
+                            if (e < lane && ((alive_mask >> e) & 1ull) && alive) {
+                                const NBox ob = {w_y0[e], w_x0[e], w_y1[e], w_x1[e], w_ar[e]};
+                                if (iou_gt(me, ob, thr)) supp |= (1ull << e);
+                            }
+                        }
+                        const unsigned int supp_lo = (unsigned int)supp, supp_hi = (unsigned int)(supp >> 32);
+                        unsigned long long keptmask = 0ull;
+                        int room = max_out - nk_cur;
+                        for (int e = 0; e < 64 && room > 0; ++e) {       // serial greedy resolve (uniform)
+                            if ((alive_mask >> e) & 1ull) {
+                                const unsigned long long se =
+                                    ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)supp_hi, e) << 32) |
+                                    (unsigned int)__builtin_amdgcn_readlane((int)supp_lo, e);
+                                if ((se & keptmask) == 0ull) { keptmask |= (1ull << e); --room; }
+                            }
+                        }
+                        if ((keptmask >> lane) & 1ull) {
+                            const int pos = nk_cur + __popcll(keptmask & ((1ull << lane) - 1ull));
+                            k_y0[pos] = me.y0; k_x0[pos] = me.x0; k_y1[pos] = me.y1; k_x1[pos] = me.x1; k_ar[pos] = me.area;
+                            k_idx[out_base + pos] = idx;
+                        }
+                        if (lane == 0) s_nk = nk_cur + __popcll(keptmask);
+                    }
+                }
+                __syncthreads();
+                const int nk_new = s_nk;
+                if (wave > sub && alive) {
+                    for (int k = nk_cur; k < nk_new; ++k) {
+                        const NBox kb = {k_y0[k], k_x0[k], k_y1[k], k_x1[k], k_ar[k]};
+                        if (iou_gt(me, kb, thr)) { alive = false; break; }
+                    }
+                }
+                nk_cur = nk_new;
+                __syncthreads();                             // nobody still reads s_nk / w_* when the next wave writes
+            }
+        }
+        if (pass == 0) first_cnt = nk_cur;
+        out_base += nk_cur;
+        __syncthreads();
+    }
+    // gather rows (tf.gather) + zero fill
+    const int cap = max_out * npass;
+    float* ro = rows + (size_t)b * cap * D;
+    int32_t* ko = kept + (size_t)b * cap;
+    for (int e = tid; e < cap * D; e += NMS_THREADS) {
+        const int k = e / D, c = e - k * D;
+        ro[e] = (k < out_base) ? bx[(size_t)k_idx[k] * D + c] : 0.f;
+    }
+    for (int k = tid; k < cap; k += NMS_THREADS) ko[k] = (k < out_base) ? k_idx[k] : -1;
+    if (tid == 0) { count[2 * b] = out_base; count[2 * b + 1] = first_cnt; }
+}
+
+hipError_t launch_sort_nms(const NmsParams& p, hipStream_t st) {
+    if (p.max_out > NMS_MAXK || p.max_out < 1) return hipErrorInvalidValue;
+    const int64_t NP = sort_np(p.N);
+    if (p.ws_bytes < nms_workspace_bytes(p.B, p.N)) return hipErrorInvalidValue;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(p.ws);
+    int* n_valid = reinterpret_cast<int*>(keys + (size_t)p.B * NP);
+    hipLaunchKernelGGL(sort_keys_kernel, dim3(p.B), dim3(SORT_THREADS), 0, st, p.boxes, p.N, p.D, p.obj_idx, NP, keys,
+                       n_valid);
+    hipLaunchKernelGGL(nms_kernel, dim3(p.B), dim3(NMS_THREADS), 0, st, p.boxes, p.N, p.D, p.obj_idx, p.cls_start,
+                       p.two_class, p.max_out, p.iou_thr, NP, keys, n_valid, p.rows, p.kept, p.count);
+    return hipGetLastError();
+}
+
+}  // namespace byk

@@ -1,0 +1,157 @@
+/* byolo.h -- C-ABI of libbyolo.so: the MI355X-native (gfx950) Bayesian-YOLOv3 inference path.
+ *
+ * The reference (flkraus/bayesian-yolov3) has no FFI / plugin / operator interface: its hot path
+ * sits behind Python function-level interfaces on top of the TensorFlow-1.x graph API.  This
+ * header is therefore the boundary a maintainer would bind if the path were native: one entry
+ * point per reference interface, each citing the reference symbol (file:line, relative to the
+ * reference tree) it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns int32 status: 0 = BYOLO_OK, negative = error; a message is
+ *     available from byolo_last_error(handle) (handle-less failures: byolo_last_error(NULL));
+ *   - no C++ exception crosses the ABI; no torch / HIP C++ types in signatures; `stream` is a
+ *     hipStream_t passed as void* (NULL = the default stream);
+ *   - all `d_*` pointers are CALLER-OWNED DEVICE memory (e.g. PyTorch-ROCm tensors); the library
+ *     never frees them and never retains them past the call;  `h_*` pointers are host memory;
+ *   - the library owns only the packed weights it uploads in byolo_finalize();
+ *   - a handle is bound to one device and is not thread-safe: one handle per device/thread;
+ *   - all tensors are float32, activations NHWC, convolution kernels HWIO
+ *     (lib_yolo/layers.py:550, tf.layers.conv2d defaults), images in [0,1)
+ *     (lib_yolo/dataset_utils.py:6-11).
+ */
+#ifndef BYOLO_H_
+#define BYOLO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BYOLO_API __attribute__((visibility("default")))
+
+#define BYOLO_OK 0
+#define BYOLO_ERR_ARG (-1)      /* invalid argument / graph construction error (reference: assert) */
+#define BYOLO_ERR_STATE (-2)    /* call order violated (e.g. forward before finalize)             */
+#define BYOLO_ERR_HIP (-3)      /* HIP runtime error                                              */
+#define BYOLO_ERR_NOMEM (-4)    /* workspace too small                                            */
+
+typedef struct byolo byolo_t;
+
+/* decode kinds == the three detection-layer factories of lib_yolo/model.py:107 / :132 / :157 */
+enum { BYOLO_DET_STANDARD = 0, BYOLO_DET_ALEATORIC = 1, BYOLO_DET_EPISTEMIC = 2 };
+/* inference_epistemic.py:99-102 (class-agnostic) and :104-126 (commented-out 2-class variant) */
+enum { BYOLO_NMS_AGNOSTIC = 0, BYOLO_NMS_TWO_CLASS = 1 };
+/* normaliser list of lib_yolo/layers.py:556-571 */
+enum { BYOLO_NORM_BN = 1, BYOLO_NORM_DROPOUT = 2 };
+
+typedef struct byolo_cfg {
+    int32_t img_h, img_w, img_c;  /* config['full_img_size'] (yolov3.py:207-208: h, w % 32 == 0)   */
+    int32_t cls_cnt;              /* config['cls_cnt']                                              */
+    float   drop_prob;            /* 0.1 hard-coded at lib_yolo/yolov3.py:462                       */
+    int32_t max_out;              /* 1000: tf.image.non_max_suppression(.., 1000)                   */
+    float   iou_thresh;           /* 0.5: TF default                                                */
+    int32_t nms_mode;             /* BYOLO_NMS_*                                                    */
+    int32_t keep_all_outputs;     /* 1 = no activation-buffer reuse, every layer readable (tests)   */
+} byolo_cfg;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+BYOLO_API int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** out);
+BYOLO_API int32_t byolo_destroy(byolo_t* h);
+BYOLO_API const char* byolo_last_error(const byolo_t* h);
+BYOLO_API const char* byolo_version(void);
+
+/* ---- graph construction: one call per ModelBuilder.make_* (lib_yolo/model.py:52-185).
+ * Each returns the new layer's index (>= 0) in the reference's `ModelBuilder.__layers` numbering
+ * (model.py:40-41) or a negative error.  Layer references (`shortcut`, `routes`, `src`) follow
+ * the reference: negative = relative to the end of the list, non-negative = absolute. ---------- */
+
+/* make_conv_layer / make_downsample_layer / make_darknet_conv_layer / make_darknet_downsample_layer
+ * (model.py:52-81 -> layers.conv, lib_yolo/layers.py:545-575): conv(no bias) -> [dropout] -> BN
+ * (eps 1e-5) -> leaky-ReLU(0.1).  stride 2 = pad(1,1)+VALID (layers.py:533-537, :616-635).
+ * `scope` = TF variable scope of the layer ("darknet53/conv_3", ...): names its variables
+ * "<scope>/conv2d/kernel", "<scope>/batch_normalization/{gamma,beta,moving_mean,moving_variance}". */
+BYOLO_API int32_t byolo_add_conv(byolo_t* h, const char* scope, int32_t filters, int32_t ksize, int32_t stride,
+                       int32_t norm_flags);
+/* make_residual_layer (model.py:91-94, layers.py:505-507) */
+BYOLO_API int32_t byolo_add_residual(byolo_t* h, int32_t shortcut);
+/* make_route_layer (model.py:83-86, layers.py:583-592): 1 route = identity, 2 = channel concat */
+BYOLO_API int32_t byolo_add_route(byolo_t* h, const int32_t* routes, int32_t n_routes);
+/* make_upsample_layer (model.py:101-105, layers.py:578-580): nearest x2 */
+BYOLO_API int32_t byolo_add_upsample(byolo_t* h);
+/* make_stack_feature_map_layer (model.py:88-89, layers.py:595-597): tile T x on the batch axis;
+ * T is a run-time argument of byolo_forward.  Sample order: s = img*T + t. */
+BYOLO_API int32_t byolo_add_stack(byolo_t* h, int32_t src);
+/* make_detection_layer{,_aleatoric,_aleatoric_epistemic} (model.py:107-185): 1x1 conv + bias,
+ * linear (layers.py:600-613), then split + decode (layers.py:11-84, :191-502).  priors_hw = the 3
+ * (h, w) priors of this stride; layer_id = len(det_layers) so far (model.py:141, :167). */
+BYOLO_API int32_t byolo_add_detection(byolo_t* h, const char* scope, int32_t kind, const float* priors_hw /*[3][2]*/);
+
+/* `self.__darknet53_layer_cnt = mb.layer_cnt()` (lib_yolo/yolov3.py:246): everything added so far
+ * is the backbone (used for load_darknet53_weights and for the per-stage timers). */
+BYOLO_API int32_t byolo_mark_backbone_end(byolo_t* h);
+
+/* ---- parameters: tf.train.Saver.restore / darknet.load_darknet_weights
+ * (inference_epistemic.py:58, lib_yolo/darknet.py:42-122) ------------------------------------ */
+BYOLO_API int32_t byolo_num_params(const byolo_t* h);
+BYOLO_API int32_t byolo_param_info(const byolo_t* h, int32_t i, const char** name, int32_t* ndim, int64_t shape[4]);
+BYOLO_API int32_t byolo_set_param(byolo_t* h, const char* name, const float* h_data, int64_t count);
+BYOLO_API int32_t byolo_get_param(const byolo_t* h, const char* name, float* h_data, int64_t count);
+/* fold BN (+ 1/keep_prob) into per-channel scale/shift, repack kernels for the MFMA tiles, upload.
+ * May be called again after further byolo_set_param calls. */
+BYOLO_API int32_t byolo_finalize(byolo_t* h);
+
+/* ---- run: one sess.run([nms_op]) (inference_epistemic.py:76, inference_aleatoric.py:75) ------ */
+BYOLO_API int32_t byolo_num_layers(const byolo_t* h);
+BYOLO_API int32_t byolo_num_boxes(const byolo_t* h, int64_t* n_boxes, int32_t* row_len);   /* N, D of concat_bbox */
+BYOLO_API int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t* out);
+/* d_img [B,H,W,C] NHWC fp32.  T = MC samples (1 for graphs without stack layers).
+ * Outputs (any may be NULL to skip that stage's export):
+ *   d_boxes   [B,N,D]               pre-NMS rows in concat_bbox order (inference_*.py concat_bbox)
+ *   d_rows    [B,max_out*(1|2),D]   NMS-kept rows, score order (2-class: ped rows then rider rows)
+ *   d_kept    [B,max_out*(1|2)]     int32 global box indices of the kept rows
+ *   d_count   [B,2]                 int32 {total kept, kept in first class (== total if agnostic)}
+ * seed: dropout stream (see csrc/byolo_rng.h); dropout is active iff the layer has
+ * BYOLO_NORM_DROPOUT and `dropout_on` != 0 (standard_test_dropout=True quirk, layers.py:567-568). */
+BYOLO_API int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
+                      void* d_workspace, size_t workspace_bytes,
+                      float* d_boxes, float* d_rows, int32_t* d_kept, int32_t* d_count, void* stream);
+/* After a forward with keep_all_outputs: device pointer + NHWC shape of layer `idx`'s output
+ * (the reference's model.layers[idx], model.py:191); for detection layers the raw conv output
+ * (DetLayer.raw_output, model.py:241). */
+BYOLO_API int32_t byolo_layer_output(const byolo_t* h, int32_t idx, const float** d_ptr, int64_t shape[4]);
+
+/* ---- staged tail entry points (parity tests on oracle-provided inputs) ------------------------ */
+/* decode one detection layer: d_raw [S,lh,lw,F] -> rows written at their concat_bbox position in
+ * d_boxes [B,N_total,D] starting at box offset `box_base`; kind as above; EPISTEMIC reduces every
+ * image's T samples (S = B*T). */
+BYOLO_API int32_t byolo_decode(byolo_t* h, int32_t kind, const float* d_raw, int32_t B, int32_t T, int32_t lh, int32_t lw,
+                     const float* priors_hw /*[3][2] host*/, int32_t layer_id, float* d_boxes,
+                     int64_t n_total, int64_t box_base, void* stream);
+/* tf.image.non_max_suppression + tf.gather per image on d_boxes [B,N,D] (scores = column obj_idx).
+ * d_sort_ws: >= byolo_nms_workspace_bytes(B, N). */
+BYOLO_API size_t  byolo_nms_workspace_bytes(int32_t B, int64_t N);
+BYOLO_API int32_t byolo_sort_nms(byolo_t* h, const float* d_boxes, int32_t B, int64_t N, int32_t D, int32_t obj_idx,
+                       int32_t cls_start_idx, int32_t nms_mode, int32_t max_out, float iou_thresh,
+                       void* d_sort_ws, size_t ws_bytes,
+                       float* d_rows, int32_t* d_kept, int32_t* d_count, void* stream);
+
+/* ---- synthetic-weight support: data-dependent BN initialisation (no reference counterpart;
+ * replaces "train the network" for benchmarking with random-init weights): runs the graph on
+ * d_img with dropout off, sets every BN's moving_mean/variance to the batch statistics of its conv
+ * output layer by layer, re-folds.  Read the result back with byolo_get_param. */
+BYOLO_API int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B, void* d_workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* ---- profiling hooks: per-stage device time of the LAST forward (hipEvents on `stream`);
+ * enable with byolo_set_profiling(h, 1).  stage: 0 backbone, 1 heads, 2 decode, 3 sort+nms. */
+BYOLO_API int32_t byolo_set_profiling(byolo_t* h, int32_t on);
+BYOLO_API int32_t byolo_stage_ms(byolo_t* h, float ms[4]);
+/* analytic cost of one forward: conv FLOPs (2*MAC, graph as written) for B images x T samples */
+BYOLO_API int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BYOLO_H_ */

@@ -1,0 +1,62 @@
+"""Oracle (test infrastructure): numpy restatement of the build-defined MC-dropout RNG.
+
+The reference never seeds its dropout (`lib_yolo/layers.py:521-524` calls
+``tf.layers.dropout(rate, training=True)`` with no seed anywhere in the tree), so its MC
+samples are irreproducible.  The build therefore DEFINES the Bernoulli stream as a pure
+function of ``(seed, dropout_layer_ordinal, element_index)`` and implements the same function
+bit-exactly here (numpy, uint32 wrap-around arithmetic) and on the device
+(``bayesian-yolov3_amd/csrc/byolo_rng.h``).
+
+  element_index = linear NHWC index into the dropout input tensor [S, h, w, cout]
+                  (S = images*T, sample s = img*T + t), as uint64
+  dropout_layer_ordinal = 0..14, order of the dropout calls in one forward
+                  (`lib_yolo/yolov3.py:544-548`, `:575-579`, `:606-610`)
+  keep  <=>  hash < floor((1 - drop_prob) * 2^32)
+"""
+import numpy as np
+
+_M1 = np.uint32(0x21F0AAAD)
+_M2 = np.uint32(0x735A2D97)
+_GOLD = np.uint32(0x9E3779B9)
+
+
+def mix32(x):
+    """lowbias32-style avalanche hash on uint32 arrays (wrap-around arithmetic)."""
+    x = np.asarray(x, dtype=np.uint32).copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint32(16)
+        x *= _M1
+        x ^= x >> np.uint32(15)
+        x *= _M2
+        x ^= x >> np.uint32(15)
+    return x
+
+
+def layer_keys(seed, layer):
+    """Per-(seed, dropout layer) key pair; computed on the host in the product too."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    layer = int(layer) & 0xFFFFFFFF
+    lo = np.uint32(seed & 0xFFFFFFFF)
+    hi = np.uint32(seed >> 32)
+    with np.errstate(over="ignore"):
+        k0 = mix32(np.uint32(lo ^ (_GOLD * np.uint32(layer + 1))))
+        k1 = mix32(np.uint32(hi + k0 + np.uint32(layer)))
+    return np.uint32(k0), np.uint32(k1)
+
+
+def keep_threshold(drop_prob):
+    # drop_prob travels through the C-ABI as float32 (byolo_cfg.drop_prob); the threshold is
+    # computed from that float32 value in double precision (csrc/byolo_rng.h: byolo_layer_keys)
+    return np.uint32(int((1.0 - float(np.float32(drop_prob))) * 4294967296.0))
+
+
+def keep_mask(seed, layer, shape, drop_prob=0.1, offset=0):
+    """Boolean keep-mask for a dropout input of NHWC `shape` (element order = C order)."""
+    n = int(np.prod(shape))
+    idx = np.arange(offset, offset + n, dtype=np.uint64)
+    k0, k1 = layer_keys(seed, layer)
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        h = mix32(mix32(lo + k0) ^ (hi + k1))
+    return (h < keep_threshold(drop_prob)).reshape(shape)
