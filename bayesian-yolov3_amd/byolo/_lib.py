@@ -58,11 +58,17 @@ PROTOTYPES = {
     "byolo_calibrate_bn": (_i32, [_vp, _vp, _i32, _vp, _sz, _vp]),
     "byolo_set_profiling": (_i32, [_vp, _i32]),
     "byolo_stage_ms": (_i32, [_vp, _P(_f32)]),
+    "byolo_num_steps": (_i32, [_vp]),
+    "byolo_step_profile": (_i32, [_vp, _i32, _P(_i32), _P(_i32), _P(_i64), _P(_f32)]),
     "byolo_flops": (_i32, [_vp, _i32, _i32, _P(ctypes.c_double)]),
 }
 
 
 def _load():
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; device pointers and HIP streams are handed from
+    # torch to libbyolo, so both MUST live in the same HIP runtime instance: import torch first, the
+    # dynamic linker then resolves libbyolo's NEEDED libamdhip64.so.7 to the already-loaded one.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "libbyolo.so not found at %s -- build it with `python bayesian-yolov3_amd/csrc/build.py` "

@@ -205,8 +205,22 @@ class Engine:
         check(self._h, lib.byolo_calibrate_bn(self._h, ctypes.c_void_p(img.data_ptr()), B,
                                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(stream)))
 
-    def set_profiling(self, on):
-        check(self._h, lib.byolo_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, level):
+        """0 off, 1 per-stage hipEvents, 2 additionally one hipEvent per conv launch."""
+        check(self._h, lib.byolo_set_profiling(self._h, int(level)))
+
+    def step_profile(self):
+        """Per conv launch of the last forward (profiling level 2): list of dicts
+        {layer, variant (tile BN or -1 = direct), M, N, K, ms, flops}."""
+        n = check(self._h, lib.byolo_num_steps(self._h))
+        out = []
+        layer, var, ms = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_float()
+        mnk = (ctypes.c_int64 * 3)()
+        for i in range(n):
+            check(self._h, lib.byolo_step_profile(self._h, i, ctypes.byref(layer), ctypes.byref(var), mnk, ctypes.byref(ms)))
+            out.append(dict(layer=layer.value, variant=var.value, M=int(mnk[0]), N=int(mnk[1]), K=int(mnk[2]),
+                            ms=float(ms.value), flops=2.0 * mnk[0] * mnk[1] * mnk[2]))
+        return out
 
     def stage_ms(self):
         ms = (ctypes.c_float * 4)()

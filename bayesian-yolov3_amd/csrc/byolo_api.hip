@@ -99,9 +99,12 @@ struct byolo {
     int64_t n_boxes = 0; int row_len = 0, obj_idx = 0, cls_start = 0;
     Plan plan;
     void* last_ws = nullptr;
-    bool profiling = false;
+    int profiling = 0;             // 0 off, 1 stage events, 2 + one event per conv launch
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
+    std::vector<hipEvent_t> step_ev;   // steps + 1 events (level 2)
+    std::vector<int64_t> step_M;       // M of each launch in the last forward
+    bool step_valid = false;
 };
 
 static thread_local std::string g_err;
@@ -142,12 +145,13 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
 
 extern "C" int32_t byolo_destroy(byolo_t* h) {
     if (!h) return BYOLO_OK;
-    if (h->d_blob || h->d_ones || h->ev[0]) {
+    if (h->d_blob || h->d_ones || h->ev[0] || !h->step_ev.empty()) {
         (void)hipSetDevice(h->device);
         if (h->d_blob) (void)hipFree(h->d_blob);
         if (h->d_ones) (void)hipFree(h->d_ones);
         if (h->d_zeros) (void)hipFree(h->d_zeros);
         for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+        for (auto& e : h->step_ev) (void)hipEventDestroy(e);
     }
     delete h;
     return BYOLO_OK;
@@ -649,13 +653,20 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         for (auto& e : h->ev) if (!e) HIPCHK(h, hipEventCreate(&e));
         HIPCHK(h, hipEventRecord(h->ev[0], st));
     }
+    const bool per_step = h->profiling >= 2;
+    if (per_step) {
+        while (h->step_ev.size() < h->steps.size() + 1) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->step_ev.push_back(e); }
+        h->step_M.assign(h->steps.size(), 0);
+    }
     bool backbone_marked = false;
-    for (const Step& s : h->steps) {
+    for (size_t si = 0; si < h->steps.size(); ++si) {
+        const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
         if (h->profiling && !backbone_marked && h->backbone_end >= 0 && s.layer >= h->backbone_end) {
             HIPCHK(h, hipEventRecord(h->ev[1], st)); backbone_marked = true;
         }
         ConvParams p; fill_conv(h, s, d_img, ws, B, T, p);
+        if (per_step) { HIPCHK(h, hipEventRecord(h->step_ev[si], st)); h->step_M[si] = p.M; }
         if (l.op == OP_CONV) {
             p.flags = EPI_LEAKY;
             if (l.drop_ordinal >= 0 && dropout_on) {
@@ -670,6 +681,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         }
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, l.tile, st));
     }
+    if (per_step) { HIPCHK(h, hipEventRecord(h->step_ev[h->steps.size()], st)); h->step_valid = true; }
     if (h->profiling) { if (!backbone_marked) HIPCHK(h, hipEventRecord(h->ev[1], st)); HIPCHK(h, hipEventRecord(h->ev[2], st)); }
     float* boxes = d_boxes ? d_boxes : reinterpret_cast<float*>(ws + h->plan.boxes_off);
     if (d_boxes || d_rows) { rc = run_decode(h, ws, boxes, B, T, st); if (rc) return rc; }
@@ -783,7 +795,28 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
 // ------------------------------------------------------------------------------------------------
 extern "C" int32_t byolo_set_profiling(byolo_t* h, int32_t on) {
     if (!h) return BYOLO_ERR_ARG;
-    h->profiling = on != 0; h->ev_valid = false;
+    h->profiling = on < 0 ? 0 : (on > 2 ? 2 : on); h->ev_valid = false; h->step_valid = false;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_num_steps(const byolo_t* h) {
+    if (!h) return BYOLO_ERR_ARG;
+    if (!h->lowered) return fail(const_cast<byolo_t*>(h), BYOLO_ERR_STATE, "byolo_num_steps: graph not lowered yet");
+    return (int32_t)h->steps.size();
+}
+
+extern "C" int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms) {
+    if (!h || i < 0 || i >= (int)h->steps.size()) return fail(h, BYOLO_ERR_ARG, "byolo_step_profile: bad index");
+    if (!h->step_valid) return fail(h, BYOLO_ERR_STATE, "byolo_step_profile: no forward with profiling level 2");
+    const Layer& l = h->layers[h->steps[i].layer];
+    if (layer) *layer = h->steps[i].layer;
+    if (variant) *variant = l.direct ? -1 : conv_tile_bn(l.tile);
+    if (mnk) { mnk[0] = h->step_M[i]; mnk[1] = l.filters; mnk[2] = (int64_t)l.ksize * l.ksize * l.Cin; }
+    if (ms) {
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipEventSynchronize(h->step_ev[i + 1]));
+        HIPCHK(h, hipEventElapsedTime(ms, h->step_ev[i], h->step_ev[i + 1]));
+    }
     return BYOLO_OK;
 }
 

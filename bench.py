@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of BASELINE.json: img/s of epistemic (MC-dropout) inference at
+T=30, 608x608 ("configs[3]", the configuration the metric is quoted on; 8 images per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+Darknet-53 once per image, the three heads on B*T MC samples (dropout masks from the counter RNG),
+per-box T-reduction + decode, sort + NMS, and (N > 1) ONE RCCL all-gather of the padded box lists.
+Weights are random-init with BN statistics calibrated on the device (no checkpoints, no network).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, the 128x128-tile fp32-MFMA
+implicit-GEMM conv (conv_igemm_kernel<128,128,2,2>): algorithmic FLOPs (2*M*N*K per launch, graph as
+written -- SURVEY.md section 8d) of all its launches in the timed region divided by their device time,
+measured with hipEvents recorded around every launch on the launch stream (byolo_step_profile).
+`cpu_baseline` is the oracle's CPU restatement (PyTorch/oneDNN, NOT TensorFlow) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "bayesian-yolov3_amd"))
+
+CONFIGS = {   # BASELINE.json configs[1..4]  (per-GPU batch)
+    2: dict(variant="yolov3_aleatoric", H=416, W=416, B=8, T=1, nms=0),
+    3: dict(variant="bayesian_yolov3_aleatoric", H=416, W=416, B=16, T=10, nms=0),
+    4: dict(variant="bayesian_yolov3_aleatoric", H=608, W=608, B=8, T=30, nms=0),
+    5: dict(variant="bayesian_yolov3_aleatoric", H=1024, W=1024, B=1, T=50, nms=1),
+}
+PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def build(cfg, device):
+    from lib_yolo import yolov3, model
+    from byolo import synth
+    import torch
+    config = {"full_img_size": [cfg["H"], cfg["W"], 3], "crop": False, "cls_cnt": 2, "priors": yolov3.ECP_9_PRIORS,
+              "aleatoric_loss": False, "inference_mode": True, "T": cfg["T"], "implicit_background_class": True,
+              "engine_options": {"nms_mode": cfg["nms"], "device": device}}
+    yolo = getattr(yolov3, cfg["variant"])(config)
+    m = yolo.init_model(inputs=model.Placeholder((None, cfg["H"], cfg["W"], 3)), training=False).get_model()
+    eng = m.engine
+    eng.set_params(synth.base_params(eng.param_shapes(), cfg["variant"], 2, seed=7))
+    eng.finalize()
+    calib = torch.from_numpy(synth.synthetic_images(2, cfg["H"], cfg["W"], seed=999)).to("cuda:%d" % device)
+    eng.calibrate_bn(calib)           # same calibration frames on every rank -> identical weights
+    del calib
+    return m
+
+
+def cpu_baseline(cfg, params, n_img=1):
+    """Oracle (CPU restatement, unfused op sequence, same NMS) timed on the host cores."""
+    import numpy as np
+    import torch
+    from oracle import cpu_ref
+    from byolo import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    imgs = synth.synthetic_images(n_img, cfg["H"], cfg["W"], seed=1234)
+    tp = cpu_ref.to_torch_params(params)
+    t0 = time.time()
+    with torch.no_grad():
+        boxes, _ = cpu_ref.detect_boxes(tp, imgs, cfg["variant"], T=cfg["T"], seed=42)
+        cpu_ref.nms_batch(boxes, cfg["variant"], two_class=bool(cfg["nms"]))
+    dt = time.time() - t0
+    return {"value": n_img / dt, "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "%d image(s) %dx%d T=%d, CPU restatement (PyTorch/oneDNN fp32, not TensorFlow), %.1f s"
+                      % (n_img, cfg["H"], cfg["W"], cfg["T"], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="no per-launch hipEvents in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from byolo import synth, dist as bdist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (MI355X); there is no CPU path in the product")
+    rank, local, world = bdist.init()
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % args.gpus
+    device = local if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    m = build(cfg, device)
+    eng = m.engine
+    B, T = cfg["B"], cfg["T"]
+    x = torch.from_numpy(synth.synthetic_images(B, cfg["H"], cfg["W"], seed=1234, first_index=rank * B)).to("cuda:%d" % device)
+    N, D = eng.num_boxes()
+    cap = eng.out_cap
+    out = {"rows": torch.empty((B, cap, D), device=x.device), "kept": torch.empty((B, cap), dtype=torch.int32, device=x.device),
+           "count": torch.empty((B, 2), dtype=torch.int32, device=x.device)}
+
+    def step(i):
+        r = eng.forward(x, T=T, seed=1000 + i, dropout_on=True, want_boxes=False, want_nms=True, out=out)
+        if world > 1:
+            return bdist.allgather_boxes(r["rows"], r["kept"], r["count"], world)
+        return r["rows"], r["kept"], r["count"]
+
+    prof = not args.no_profile
+    for i in range(args.warmup):
+        step(i)
+    eng.set_profiling(2 if prof else 0)
+    acc = {}                      # variant -> [flops, ms, launches]
+    stage = {"backbone": 0.0, "heads": 0.0, "decode": 0.0, "sort_nms": 0.0}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+        if prof:
+            # reading the events waits for this step only; the timed region stays back-to-back
+            for s in eng.step_profile():
+                a = acc.setdefault(s["variant"], [0.0, 0.0, 0])
+                a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1
+            for k, v in eng.stage_ms().items():
+                stage[k] += v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=x.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        flops_img = eng.flops(1, T)
+        line = {
+            "metric": "img/s at T=%d MC-dropout, %dx%d" % (T, cfg["H"], cfg["W"]),
+            "value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: %s %dx%d T=%d, %d images/GPU (global batch %d), "
+                                   "class-%s NMS max_out=1000, random-init weights with device-calibrated BN"
+                                   % (args.config - 1, cfg["variant"], cfg["H"], cfg["W"], T, B, B * world,
+                                      "wise 2-class" if cfg["nms"] else "agnostic"),
+                       "images_per_gpu": B, "T": T, "img_size": [cfg["H"], cfg["W"]], "parallelism": "dp%d" % world,
+                       "gflop_per_image": flops_img / 1e9},
+        }
+        if prof and 128 in acc:
+            f, ms, n = acc[128]
+            tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for a in acc.values())
+            ach = f / (ms * 1e-3)
+            line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                                "frac": ach / PEAK_FP32_MFMA, "traffic": None,
+                                "kernel": "conv_igemm_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)",
+                                "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
+                                "all_conv_achieved": tot_f / (tot_ms * 1e-3) / 1e12,
+                                "end_to_end_frac": (imgs / dt) * flops_img / (world * PEAK_FP32_MFMA)}
+            line["stage_ms_per_step"] = {k: v / args.steps for k, v in stage.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(cfg, eng.get_params())
+            except Exception as e:          # the CPU leg must never cost the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": "failed: %r" % (e,)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

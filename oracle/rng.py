@@ -50,6 +50,33 @@ def keep_threshold(drop_prob):
     return np.uint32(int((1.0 - float(np.float32(drop_prob))) * 4294967296.0))
 
 
+def keep_mask_torch(seed, layer, shape, drop_prob=0.1, offset=0, chunk=1 << 24):
+    """Same function evaluated with torch (multi-threaded; int64 lanes holding 32-bit values) for
+    the large tensors of the CPU baseline.  Bit-identical to keep_mask (tests/test_oracle.py)."""
+    import torch
+    n = int(np.prod(shape))
+    k0, k1 = (int(v) for v in layer_keys(seed, layer))
+    thr = int(keep_threshold(drop_prob))
+    M = 0xFFFFFFFF
+    out = torch.empty(n, dtype=torch.bool)
+
+    def mix(x):
+        x = x ^ (x >> 16)
+        x = (x * 0x21F0AAAD) & M
+        x = x ^ (x >> 15)
+        x = (x * 0x735A2D97) & M
+        return x ^ (x >> 15)
+
+    for lo_i in range(0, n, chunk):
+        hi_i = min(n, lo_i + chunk)
+        idx = torch.arange(offset + lo_i, offset + hi_i, dtype=torch.int64)
+        lo = idx & M
+        hi = idx >> 32
+        h = mix(mix((lo + k0) & M) ^ ((hi + k1) & M))
+        out[lo_i:hi_i] = h < thr
+    return out.reshape(shape)
+
+
 def keep_mask(seed, layer, shape, drop_prob=0.1, offset=0):
     """Boolean keep-mask for a dropout input of NHWC `shape` (element order = C order)."""
     n = int(np.prod(shape))
