@@ -840,3 +840,35 @@ extern "C" int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops) 
     *flops = f;
     return BYOLO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// host utility for the input feed: CRC-32C (Castagnoli) as used by the TFRecord framing the
+// reference's tf.data pipeline reads (lib_yolo/dataset_utils.py:188-199: TFRecordDataset).
+// Slicing-by-8, tables built on first use.
+// ------------------------------------------------------------------------------------------------
+extern "C" uint32_t byolo_crc32c(const void* data, size_t n) {
+    static uint32_t tab[8][256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            tab[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xFF];
+        init = true;
+    }
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    uint32_t crc = 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= crc;
+        crc = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^
+              tab[3][hi & 0xFF] ^ tab[2][(hi >> 8) & 0xFF] ^ tab[1][(hi >> 16) & 0xFF] ^ tab[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) crc = (crc >> 8) ^ tab[0][(crc ^ *p++) & 0xFF];
+    return crc ^ 0xFFFFFFFFu;
+}

@@ -156,6 +156,10 @@ BYOLO_API int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int3
 /* analytic cost of one forward: conv FLOPs (2*MAC, graph as written) for B images x T samples */
 BYOLO_API int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops);
 
+/* ---- input feed helper (host only): CRC-32C of the TFRecord framing read by the reference's
+ * tf.data.TFRecordDataset (lib_yolo/dataset_utils.py:188-199); returns the raw (unmasked) CRC. */
+BYOLO_API uint32_t byolo_crc32c(const void* h_data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,30 @@
+"""Worker for tests/test_dist_cpu.py: world_size-2 gloo run of the N>1 path (sharding + the single
+all-gather of the padded box lists)."""
+import os
+import sys
+
+
+def main(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "bayesian-yolov3_amd"))
+    import torch
+    import torch.distributed as dist
+    from byolo import dist as bdist
+    r, l, w = bdist.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    Bl, cap, D = 3, 5, 23
+    g = torch.Generator().manual_seed(100 + rank)
+    rows = torch.rand((Bl, cap, D), generator=g)
+    kept = torch.randint(-1, 22743, (Bl, cap), generator=g, dtype=torch.int32)
+    count = torch.randint(0, cap, (Bl, 2), generator=g, dtype=torch.int32)
+    g_rows, g_kept, g_count = bdist.allgather_boxes(rows, kept, count, world)
+    torch.save({"rows": rows, "kept": kept, "count": count, "g_rows": g_rows, "g_kept": g_kept, "g_count": g_count,
+                "shard": bdist.shard_range(7, rank, world)}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])

@@ -1,0 +1,161 @@
+"""Entry points (rows a15-a19 of SURVEY.md section 8): ECP mapping and detect.py post-filter of the
+PRODUCT against the golden dicts produced by the reference's own functions; TFRecord/PNG feed; and, on
+the GPU, the full `inference(config)` / `do_it(...)` drivers against the oracle."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden, make_config, golden_params, assert_close
+
+VARIANTS = ("yolov3", "yolov3_aleatoric", "bayesian_yolov3_aleatoric")
+SCRIPTS = {"yolov3": "inference_standard_yolov3", "yolov3_aleatoric": "inference_aleatoric",
+           "bayesian_yolov3_aleatoric": "inference_epistemic"}
+
+
+class _M:
+    def __init__(self, variant):
+        from oracle import cpu_ref
+        self.D, self.obj_idx, self.cls_start_idx = cpu_ref.row_layout(variant, 2)
+        self.cls_cnt = 2
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_bbox_to_ecp_format_matches_reference(variant):
+    mod = __import__(SCRIPTS[variant])
+    g = golden("ecp_dicts.json")[variant]
+    rows = np.asarray(g["rows"], dtype=np.float32)
+    for case in g["cases"]:
+        cfg = {"implicit_background_class": case["implicit_background_class"]}
+        for r, want in zip(rows, case["dicts"]):
+            got = mod.bbox_to_ecp_format(r, g["img_size"], _M(variant), cfg)
+            assert json.loads(json.dumps(got, default=lambda x: x.tolist())) == want
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_detect_postfilter_matches_reference(variant):
+    import detect
+    g = golden("detect_post.json")[variant]
+    rows = np.asarray(g["rows"], dtype=np.float32)
+    m = _M(variant)
+    filt = detect.filter_boxes(rows, m.obj_idx, g["thresh"])
+    assert len(filt) == g["n_filtered"]
+    ok = [r for r, bad in zip(filt, g["ibc_raises"]) if not bad]
+    for r, bad in zip(filt, g["ibc_raises"]):
+        if bad:
+            with pytest.raises(IndexError):
+                detect.preproces_boxes([1024, 1920, 3], [r], m.obj_idx, m.cls_start_idx, 2, {"implicit_background_class": True})
+    conv = lambda L: json.loads(json.dumps(L, default=lambda x: x.item() if hasattr(x, "item") else x))
+    got = detect.preproces_boxes([1024, 1920, 3], ok, m.obj_idx, m.cls_start_idx, 2, {"implicit_background_class": True},
+                                 cls_mapping={1: "ped", 2: "rider"})
+    assert conv(got) == g["pre_ibc"]
+    got = detect.preproces_boxes([1024, 1920, 3], filt, m.obj_idx, m.cls_start_idx, 2, {"implicit_background_class": False})
+    assert conv(got) == g["pre_noibc"]
+
+
+def _png(img_u8):
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(img_u8).save(b, format="PNG")
+    return b.getvalue()
+
+
+def _make_records(tmp_path, n, H=64, W=96, shards=2):
+    from lib_yolo import dataset_utils as du
+    rng = np.random.default_rng(0)
+    imgs, names, per = [], [], [[] for _ in range(shards)]
+    for i in range(n):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        name = "city_%03d.png" % i
+        per[i % shards].append(du.make_example({"image/encoded": _png(img), "image/filename": name,
+                                                "image/height": H, "image/width": W}))
+        imgs.append(img); names.append(name)
+    for s in range(shards):
+        du.write_tfrecords(str(tmp_path / ("ecp-day-val-%05d-of-%05d" % (s, shards))), per[s])
+    return imgs, names
+
+
+def test_tfrecord_feed(tmp_path):
+    from lib_yolo import dataset_utils as du
+    from byolo._lib import lib
+    assert lib.byolo_crc32c(b"123456789", 9) == 0xE3069283          # CRC-32C check value
+    imgs, names = _make_records(tmp_path, 5)
+    cfg = make_config("x", 64, 96, batch_size=2, data={"file_pattern": str(tmp_path / "ecp-day-val-*-of-*")})
+    ds = du.TestingDataset(cfg)
+    assert ds.placeholder.shape == (2, 64, 96, 3)
+    batches = list(ds)
+    assert [len(b[1]) for b in batches] == [2, 2, 1]
+    got_names = [n for b in batches for n in b[1]]
+    assert got_names == names                                       # interleave(cycle 2, block 1) of 2 shards
+    got = np.concatenate([b[0] for b in batches])
+    assert got.dtype == np.float32 and got.max() <= 1.0
+    for a, u8 in zip(got, imgs):
+        assert np.array_equal(a, u8.astype(np.float32) * np.float32(1.0 / 255.0))
+    # corruption is detected
+    p = str(tmp_path / "ecp-day-val-00000-of-00002")
+    raw = bytearray(open(p, "rb").read()); raw[40] ^= 0xFF
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(IOError, match="CRC"):
+        list(du.read_tfrecords(p))
+    ex = du.parse_example(du.make_example({"a": b"xyz", "n": -3, "s": "str"}))
+    assert ex == {"a": [b"xyz"], "n": [-3], "s": [b"str"]}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_inference_driver_end_to_end(variant, tmp_path):
+    """`inference(config)` writes one ECP JSON per image; contents == oracle on the same inputs."""
+    import torch
+    from oracle import cpu_ref
+    mod = __import__(SCRIPTS[variant])
+    imgs, names = _make_records(tmp_path, 3)
+    # checkpoint: the golden weights saved by TF variable name
+    ck = tmp_path / "checkpoints" / "run"
+    ck.mkdir(parents=True)
+    params = golden_params(variant)
+    np.savez(str(ck / "model-1234.npz"), **params)
+    cfg = make_config(variant, 64, 96, T=3, batch_size=2, checkpoint_path=str(tmp_path / "checkpoints"), run_id="run",
+                      step="last", seed=10, data={"file_pattern": str(tmp_path / "ecp-day-val-*-of-*")},
+                      out_path=str(tmp_path / "out" / "run"))
+    mod.inference(cfg)
+    out_dir = str(tmp_path / "out" / "run_1234")
+    assert sorted(os.listdir(out_dir)) == sorted(n.replace(".png", ".json") for n in names)
+    x = np.stack([i.astype(np.float32) * np.float32(1 / 255.) for i in imgs])
+    tp = cpu_ref.to_torch_params(params)
+    D, obj, cs = cpu_ref.row_layout(variant, 2)
+    for bi, (lo, hi) in enumerate(((0, 2), (2, 3))):             # the driver's batches; seed = 10 + step
+        boxes, _ = cpu_ref.detect_boxes(tp, x[lo:hi], variant, T=3, seed=10 + bi + 1)
+        for k, (rows, keep) in enumerate(cpu_ref.nms_batch(boxes, variant)):
+            got = json.load(open(os.path.join(out_dir, names[lo + k].replace(".png", ".json"))))["children"]
+            assert len(got) == len(rows)
+            want = [cpu_ref.bbox_to_ecp(r, [64, 96, 3], variant, 2, True) for r in rows]
+            assert set(got[0]) == set(want[0])
+            key = lambda d: (round(d["y0"], 2), round(d["x0"], 2))
+            for g_, w_ in zip(sorted(got, key=key), sorted(want, key=key)):
+                assert g_["identity"] == w_["identity"]
+                for f in ("y0", "x0", "y1", "x1", "score"):
+                    assert abs(g_[f] - w_[f]) <= 1e-4 * max(1.0, abs(w_[f])) * (96 if f[0] in "xy" else 1)
+
+
+@pytest.mark.gpu
+def test_detect_do_it(tmp_path):
+    import detect
+    from lib_yolo import yolov3
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    files = []
+    for i in range(2):
+        p = str(tmp_path / ("img%d.png" % i))
+        Image.fromarray(rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)).save(p)
+        files.append(p)
+    cfg = make_config("x", 64, 96, T=3, weights="synthetic", crop_img_size=[64, 96, 3])
+    for cls in (yolov3.yolov3, yolov3.yolov3_aleatoric, yolov3.bayesian_yolov3_aleatoric):
+        c = dict(cfg)
+        if cls is yolov3.yolov3:      # 7-column rows + implicit background class -> the reference's IndexError (detect.py:51)
+            c["implicit_background_class"] = False
+        res = detect.do_it(files, 0.0, c, cls, {1: "ped", 2: "rider"} if cls is not yolov3.yolov3 else None)
+        assert set(res) == set(files)
+        for boxes in res.values():
+            assert boxes and all(0 <= b["y0"] <= 64 and 0 <= b["x1"] <= 96 for b in boxes)

@@ -1,0 +1,169 @@
+"""Host logic without a GPU: the reference-shaped Python API (lib_yolo mirror), graph construction
+and lowering errors, variable / layer naming, workspace planning, cost model, Darknet loader."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import make_config, build_model, golden
+
+VARIANTS = ("yolov3", "yolov3_aleatoric", "bayesian_yolov3_aleatoric")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_names_match_reference(variant, fwd_meta):
+    """Variable names (creation order) and layer tensor names as the reference produced them."""
+    yolo, m = build_model(variant, 64, 96)
+    meta = fwd_meta[variant]
+    assert list(m.engine.param_shapes()) == meta["var_names"]
+    assert len(m.layers) == meta["n_layers"] == m.engine.num_layers()
+    mine = [l.name for l in m.layers]
+    for a, b in zip(mine, meta["layer_names"]):
+        # op-type suffixes of view layers are cosmetic; conv / residual / detection names are load-bearing
+        if "LeakyRelu" in b or "detection" in b or "residual" in b:
+            assert a == b
+    assert (m.obj_idx, m.cls_start_idx) == {"yolov3": (4, 5), "yolov3_aleatoric": (9, 11)}.get(variant, (14, 17))
+    assert [(d.h, d.w, d.downsample) for d in m.det_layers] == [(2, 3, 32), (4, 6, 16), (8, 12, 8)]
+    assert m.engine.num_boxes() == (378, {"yolov3": 7, "yolov3_aleatoric": 16}.get(variant, 23))
+    assert m.matches_blueprint(yolo.blueprint)
+    assert m.dn_out.index == 74 and m.det_net_1_out.name == "det_net_1/detection/conv2d/BiasAdd:0"
+
+
+def test_flops_match_baseline_table():
+    """BASELINE.md section 2 (GFLOP per image, conv FLOPs as written)."""
+    for variant, hw, T, want in (("yolov3", 416, 1, 65.30), ("yolov3_aleatoric", 416, 1, 65.35),
+                                 ("bayesian_yolov3_aleatoric", 416, 10, 212.20), ("bayesian_yolov3_aleatoric", 608, 30, 1150.34),
+                                 ("bayesian_yolov3_aleatoric", 1024, 50, 5240.29)):
+        _, m = build_model(variant, hw, hw, T=T)
+        assert abs(m.engine.flops(1, T) / 1e9 - want) < 0.01, (variant, hw, T)
+    _, m = build_model("bayesian_yolov3_aleatoric", 608, 608, T=30)
+    assert m.engine.num_boxes() == (22743, 23)
+
+
+def test_config_contract():
+    from lib_yolo import yolov3, model
+    # required keys (yolov3.py:315, :456, :461, :467)
+    cfg = make_config("x", 64, 64)
+    for cls, key in ((yolov3.yolov3_aleatoric, "aleatoric_loss"), (yolov3.bayesian_yolov3_aleatoric, "aleatoric_loss"),
+                     (yolov3.bayesian_yolov3_aleatoric, "inference_mode"), (yolov3.bayesian_yolov3_aleatoric, "T")):
+        c = dict(cfg); del c[key]
+        with pytest.raises(KeyError):
+            cls(c)
+    with pytest.raises(AssertionError):                         # % 32 (yolov3.py:207)
+        yolov3.yolov3(make_config("x", 100, 64))
+    y = yolov3.yolov3(cfg)
+    with pytest.raises(AssertionError, match="Call init_model first"):
+        y.get_model()
+    y.init_model(model.Placeholder((1, 64, 64, 3)), training=False)
+    with pytest.raises(Exception, match="only be initialized once"):
+        y.init_model(model.Placeholder((1, 64, 64, 3)), training=False)
+    with pytest.raises(NotImplementedError):
+        yolov3.yolov3(cfg).init_model(model.Placeholder((1, 64, 64, 3)), training=True)
+    # Bayesian model outside inference mode: plain dropout network with the aleatoric decode, no stacking
+    _, m = build_model("bayesian_yolov3_aleatoric", 64, 64, inference_mode=False)
+    assert len(m.layers) == 104 and m.T == 1 and all(d.kind == 1 for d in m.det_layers)
+
+
+def test_crop_rescales_and_mutates_priors():
+    """model.py:10-15 incl. the in-place mutation of the shared table (App. D.13)."""
+    from lib_yolo import yolov3, model
+    table = copy.deepcopy(yolov3.ECP_9_PRIORS)
+    cfg = make_config("x", 128, 256, priors=table, crop=True, crop_img_size=[64, 64, 3])
+    h0 = table[32][0].h
+    img_size, pri = model.img_size_and_priors_if_crop(cfg)
+    assert img_size == [64, 64, 3] and pri is table
+    assert table[32][0].h == h0 * 2.0 and abs(table[8][2].w - yolov3.ECP_9_PRIORS[8][2].w * 4.0) < 1e-12
+
+
+def test_graph_errors():
+    from byolo import Engine, ByoloError
+    e = Engine((64, 64, 3), 2)
+    with pytest.raises(ByoloError, match="invalid kernel size"):
+        e.add_conv("a", 8, 5, 1, 1)
+    with pytest.raises(ByoloError, match="invalid strides"):
+        e.add_conv("a", 8, 3, 3, 1)
+    with pytest.raises(ByoloError, match="too many routes"):
+        e.add_route([0, 0, 0])
+    with pytest.raises(ByoloError, match="too few routes"):
+        e.add_route([])
+    i0 = e.add_conv("a", 32, 3, 1, 1)
+    with pytest.raises(ByoloError, match="duplicate scope"):
+        e.add_conv("a", 32, 3, 1, 1)
+    i1 = e.add_conv("b", 64, 3, 2, 1)
+    with pytest.raises(ByoloError, match="shape mismatch"):
+        e.add_residual(0)
+    with pytest.raises(ByoloError, match="bad route"):
+        e.add_route([17])
+    assert (i0, i1) == (0, 1)
+    with pytest.raises(ByoloError, match="no detection layer"):
+        e.workspace_bytes(1, 1)
+    e.add_detection("d/detection", 1, [(0.1, 0.1)] * 3)
+    with pytest.raises(ByoloError, match="mixed detection kinds"):
+        e.add_detection("d2/detection", 0, [(0.1, 0.1)] * 3)
+    assert e.workspace_bytes(2, 1) > 0
+    with pytest.raises(ByoloError, match="frozen"):
+        e.add_upsample()
+    with pytest.raises(ByoloError, match="unknown variable"):
+        e.set_param("nope", np.zeros(3))
+    with pytest.raises(ByoloError, match="expects"):
+        e.set_param("a/conv2d/kernel", np.zeros(3))
+    # a residual whose producer is shared cannot be folded into a conv epilogue
+    e2 = Engine((64, 64, 3), 2)
+    e2.add_conv("a", 32, 3, 1, 1); e2.add_conv("b", 32, 1, 1, 1); e2.add_residual(0); e2.add_route([1])
+    e2.add_detection("d/detection", 0, [(0.1, 0.1)] * 3)
+    with pytest.raises(ByoloError, match="cannot be fused"):
+        e2.workspace_bytes(1, 1)
+
+
+def test_forward_requires_finalize_and_device_tensors():
+    import torch
+    from byolo import ByoloError
+    _, m = build_model("yolov3", 64, 64)
+    with pytest.raises(TypeError):
+        m.engine.forward(torch.zeros((1, 64, 64, 3)))            # CPU tensor: no CPU path in the product
+
+
+def test_workspace_plan():
+    v = "bayesian_yolov3_aleatoric"
+    _, keep = build_model(v, 608, 608, T=30, engine_options={"keep_all_outputs": True})
+    _, reuse = build_model(v, 608, 608, T=30)
+    a, b = keep.engine.workspace_bytes(8, 30), reuse.engine.workspace_bytes(8, 30)
+    assert b < a / 2                                              # liveness-based reuse pays
+    assert reuse.engine.workspace_bytes(4, 30) < b < reuse.engine.workspace_bytes(8, 50)
+    biggest = 240 * 76 * 76 * 256 * 4                             # head-3 3x3 output at config 4
+    assert b >= 2 * biggest and b < 6e9
+
+
+def test_darknet_weight_loader(tmp_path):
+    """lib_yolo/darknet.py:42-122: header, [beta, gamma, mean, var] then kernel as [cout,cin,kh,kw]."""
+    yolo, m = build_model("yolov3", 64, 64)
+    shapes = m.engine.param_shapes()
+    names = [n for n in shapes if n.startswith("darknet53/")]
+    rng = np.random.default_rng(0)
+    want = {}
+    blob = [np.array([0, 2, 0, 0, 0], dtype=np.int32).tobytes()]
+    scopes = []
+    for n in names:
+        s = n.rsplit("/", 2)[0]
+        if s not in scopes:
+            scopes.append(s)
+    for s in scopes:
+        for v in ("beta", "gamma", "moving_mean", "moving_variance"):
+            k = "%s/batch_normalization/%s" % (s, v)
+            want[k] = rng.standard_normal(shapes[k]).astype(np.float32)
+            blob.append(want[k].tobytes())
+        k = s + "/conv2d/kernel"
+        w = rng.standard_normal(shapes[k]).astype(np.float32)            # HWIO
+        want[k] = w
+        blob.append(np.ascontiguousarray(w.transpose(3, 2, 0, 1)).tobytes())   # darknet: [n, c, h, w]
+    path = tmp_path / "darknet53.conv.74"
+    path.write_bytes(b"".join(blob))
+    assigned = yolo.load_darknet53_weights(str(path))
+    assert len(assigned) == 52 * 5
+    for k, w in want.items():
+        assert np.array_equal(m.engine.get_param(k, shapes[k]), w), k
+    # a truncated file trips the reference's `assert ptr == len(weights)` ... from the other side
+    (tmp_path / "short").write_bytes(b"".join(blob)[:-400])
+    with pytest.raises((AssertionError, ValueError)):
+        yolo2, _ = build_model("yolov3", 64, 64)
+        yolo2.load_darknet53_weights(str(tmp_path / "short"))

@@ -159,7 +159,7 @@ def test_nms_two_class():
 
 def test_rng_definition():
     """The dropout stream: known answers + torch fast path == numpy definition + offset semantics."""
-    assert int(rng.keep_threshold(0.1)) == 3865470559       # floor((1 - float32(0.1)) * 2^32)
+    assert int(rng.keep_threshold(0.1)) == 3865470560       # (1 - float32(0.1)) * 2^32 = 2^32 - 13421773 * 32, exact
     k0, k1 = rng.layer_keys(42, 0)
     assert (int(k0), int(k1)) == (int(rng.mix32(np.uint32(42 ^ 0x9E3779B9))), int(rng.mix32(np.uint32((0 + int(k0) + 0) & 0xFFFFFFFF))))
     m = rng.keep_mask(42, 3, (4, 5, 6, 32))
