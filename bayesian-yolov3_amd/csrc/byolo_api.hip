@@ -615,6 +615,7 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.cin_tiles = l.Cin / 32; p.KT = l.ksize * l.ksize * p.cin_tiles;
     p.wpk = dptr(h, l.w_off); p.scale = dptr(h, l.scale_off); p.shift = dptr(h, l.shift_off);
     p.dst = reinterpret_cast<float*>(ws + h->plan.off[l.out_tensor]);
+    p.zeros = h->d_zeros;
     p.inv_keep = 1.f;
 }
 

@@ -19,6 +19,7 @@ struct ConvParams {
     const float* wpk;                 // packed weights [K/32][Npad][32]   (direct kernel: HWIO as is)
     const float* scale; const float* shift;   // per output channel
     const float* residual;            // [M][ldc] or null
+    const float* zeros;               // zero page, >= max(C0, C1) floats: source of padded / out-of-range rows
     float* dst;                       // [M][ldc]
     int C0, C1;                       // channels of the two sources (C1 == 0: single source)
     int Hs0, Ws0, Hs1, Ws1;           // physical spatial size of each source

@@ -52,6 +52,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int tile_n = logical % n_tiles, tile_m = logical / n_tiles;
 
     // ---- per-thread A-row bookkeeping (4 rows at BM = 128) ---------------------------------
+    // Each thread stages the same A_LD rows of every K-tile.  Row state = output pixel (sample,
+    // oy, ox); per filter tap a row pointer is derived ONCE (when the tap or the source changes) and
+    // then only advanced by the channel chunk: the K-loop itself carries no im2col arithmetic.
+    // Out-of-image taps (zero padding) and rows past M point at a zero page instead of branching.
     const int a_q = tid & 7;
     int a_iy0[A_LD], a_ix0[A_LD], a_s0[A_LD], a_s1[A_LD];
     const int hw = p.Hout * p.Wout;
@@ -66,42 +70,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             a_s0[j] = s / p.sdiv0;
             a_s1[j] = s / p.sdiv1;
         } else {
-            a_iy0[j] = -(1 << 28);              // every tap out of bounds -> zeros
+            a_iy0[j] = -(1 << 28);              // every tap out of bounds -> zero page
             a_ix0[j] = 0; a_s0[j] = 0; a_s1[j] = 0;
         }
     }
+    const float* a_ptr[A_LD];                    // row pointer of the current (tap, source), + a_q*4
+    const float* w_ptr = p.wpk + (size_t)tile_n * BN * BK + (size_t)tid * 4;   // advanced by Npad*32 per K-tile
+    const size_t w_step = (size_t)p.Npad * BK;
+    int ld_tap = 0, ld_chunk = 0;                // (tap, channel chunk) of the NEXT tile to load
 
     f32x4 a_reg[A_LD], b_reg[B_LD];
 
-    auto load_tile = [&](int kt) {
-        const int tap = kt / p.cin_tiles;
-        int cc = (kt - tap * p.cin_tiles) * BK;
-        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
-        const float* src; int C, Hs, Ws, sh; bool second;
-        if (cc < p.C0) { src = p.src0; C = p.C0; Hs = p.Hs0; Ws = p.Ws0; sh = p.sh0; second = false; }
-        else { src = p.src1; C = p.C1; Hs = p.Hs1; Ws = p.Ws1; sh = p.sh1; cc -= p.C0; second = true; }
+    auto load_tile = [&]() {
+        int cc = ld_chunk * BK;
+        const bool second = cc >= p.C0;
+        if (ld_chunk == 0 || cc == p.C0) {       // block-uniform: new tap or switch to the 2nd source
+            const int ky = ld_tap / p.ksize, kx = ld_tap - ky * p.ksize;
+            const float* src = second ? p.src1 : p.src0;
+            const int C = second ? p.C1 : p.C0, Hs = second ? p.Hs1 : p.Hs0, Ws = second ? p.Ws1 : p.Ws0;
+            const int sh = second ? p.sh1 : p.sh0;
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) {
-            const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) {
+            for (int j = 0; j < A_LD; ++j) {
+                const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
                 const int s = second ? a_s1[j] : a_s0[j];
-                const size_t off = (((size_t)s * Hs + (iy >> sh)) * Ws + (ix >> sh)) * C + cc + a_q * 4;
-                v = *reinterpret_cast<const f32x4*>(src + off);
+                const size_t off = (((size_t)s * Hs + (iy >> sh)) * Ws + (ix >> sh)) * C;
+                a_ptr[j] = (ok ? src + off : p.zeros) + a_q * 4;
             }
-            a_reg[j] = v;
         }
-        const float* wsrc = p.wpk + ((size_t)kt * p.Npad + (size_t)tile_n * BN) * BK;
+        if (second) cc -= p.C0;
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j)
-            b_reg[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(tid + 256 * j) * 4);
+        for (int j = 0; j < A_LD; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + cc);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) b_reg[j] = *reinterpret_cast<const f32x4*>(w_ptr + (size_t)j * 1024);
+        w_ptr += w_step;
+        if (++ld_chunk == p.cin_tiles) { ld_chunk = 0; ++ld_tap; }
     };
-    auto store_tile = [&](int buf) {
+    auto store_a = [&](int buf) {
         float* a = As + buf * BM * LDS_LD;
-        float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j)
             *reinterpret_cast<f32x4*>(a + ((tid >> 3) + 32 * j) * LDS_LD + a_q * 4) = a_reg[j];
+    };
+    auto store_b = [&](int buf) {
+        float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             const int idx = tid + 256 * j;
@@ -112,6 +124,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
+    const int a_frag_off = (wm * TM * 32 + li) * LDS_LD + lh * 4;
+    const int b_frag_off = (wn * TN * 32 + li) * LDS_LD + lh * 4;
+
+    auto read_frags = [&](int buf, int kq, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+        const float* a = As + buf * BM * LDS_LD + a_frag_off + kq * 8;
+        const float* b = Bs + buf * BN * LDS_LD + b_frag_off + kq * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_LD);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_LD);
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -121,34 +144,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- software-pipelined K loop ---------------------------------------------------------------
+    // Per K-tile (4 groups of 16 MFMAs per wave at 128x128): the fragments of group g+1 are read
+    // from LDS while group g runs; the NEXT tile's global loads are issued at the top, its A / B
+    // halves are written to the other LDS buffer after groups 1 / 2; the one barrier per tile sits
+    // BEFORE the last group, so the barrier and the first fragment read of the next tile hide under
+    // the 16 MFMAs of group 3 (all reads of the current buffer are already in registers by then).
+    f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    load_tile();
+    store_a(0); store_b(0);
     __syncthreads();
+    read_frags(0, 0, af0, bf0);
 
     for (int kt = 0; kt < p.KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < p.KT) load_tile(kt + 1);          // global loads in flight under the MFMAs
+        const bool has_next = kt + 1 < p.KT;
+        if (has_next) load_tile();                     // global loads in flight under the MFMAs
 
-        const float* a = As + buf * BM * LDS_LD + (wm * TM * 32 + li) * LDS_LD + lh * 4;
-        const float* b = Bs + buf * BN * LDS_LD + (wn * TN * 32 + li) * LDS_LD + lh * 4;
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_LD + kq * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_LD + kq * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-        }
+        read_frags(buf, 1, af1, bf1);
+        mfma_group(af0, bf0);
 
-        if (kt + 1 < p.KT) store_tile(buf ^ 1);
+        read_frags(buf, 2, af0, bf0);
+        mfma_group(af1, bf1);
+        if (has_next) store_a(buf ^ 1);
+
+        read_frags(buf, 3, af1, bf1);
+        mfma_group(af0, bf0);
+        if (has_next) store_b(buf ^ 1);
+
         __syncthreads();
+        if (has_next) read_frags(buf ^ 1, 0, af0, bf0);
+        mfma_group(af1, bf1);
     }
 
     // ---- fused epilogue: [dropout mask] * scale, + shift, leaky, [+ residual] ------------------

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch hipEvents in the timed region")
+    ap.add_argument("--dump-steps", default=None, help="write the per-launch table (layer, variant, M, N, K, ms, TF/s) here")
     args = ap.parse_args()
 
     import torch
@@ -118,6 +119,7 @@ def main():
         step(i)
     eng.set_profiling(2 if prof else 0)
     acc = {}                      # variant -> [flops, ms, launches]
+    per_launch = {}
     stage = {"backbone": 0.0, "heads": 0.0, "decode": 0.0, "sort_nms": 0.0}
     if world > 1:
         dist.barrier()
@@ -127,9 +129,11 @@ def main():
         step(args.warmup + i)
         if prof:
             # reading the events waits for this step only; the timed region stays back-to-back
-            for s in eng.step_profile():
+            for j, s in enumerate(eng.step_profile()):
                 a = acc.setdefault(s["variant"], [0.0, 0.0, 0])
                 a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1
+                if args.dump_steps:
+                    per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / args.steps
             for k, v in eng.stage_ms().items():
                 stage[k] += v
     torch.cuda.synchronize()
@@ -174,6 +178,13 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": "failed: %r" % (e,)}
         print(json.dumps(line))
+        if args.dump_steps and per_launch:
+            with open(args.dump_steps, "w") as f:
+                f.write("| # | layer | variant | M | N | K | ms | TF/s |\n|---|---|---|---|---|---|---|---|\n")
+                for j in sorted(per_launch):
+                    s = per_launch[j]
+                    f.write("| %d | %d | %d | %d | %d | %d | %.4f | %.1f |\n" % (j, s["layer"], s["variant"], s["M"], s["N"], s["K"],
+                                                                               s["ms"], s["flops"] / (s["ms"] * 1e-3) / 1e12))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

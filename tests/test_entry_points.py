@@ -132,11 +132,17 @@ def test_inference_driver_end_to_end(variant, tmp_path):
             assert len(got) == len(rows)
             want = [cpu_ref.bbox_to_ecp(r, [64, 96, 3], variant, 2, True) for r in rows]
             assert set(got[0]) == set(want[0])
-            key = lambda d: (round(d["y0"], 2), round(d["x0"], 2))
-            for g_, w_ in zip(sorted(got, key=key), sorted(want, key=key)):
-                assert g_["identity"] == w_["identity"]
-                for f in ("y0", "x0", "y1", "x1", "score"):
-                    assert abs(g_[f] - w_[f]) <= 1e-4 * max(1.0, abs(w_[f])) * (96 if f[0] in "xy" else 1)
+            # same boxes (kept order may differ between near-tied scores): match each oracle box to the
+            # nearest written box by its corners
+            gc = np.array([[d["y0"], d["x0"], d["y1"], d["x1"]] for d in got])
+            for r, w_ in zip(rows, want):
+                wc = np.array([w_["y0"], w_["x0"], w_["y1"], w_["x1"]])
+                g_ = got[int(np.argmin(np.abs(gc - wc).sum(1)))]
+                for f in ("y0", "x0", "y1", "x1"):
+                    assert abs(g_[f] - w_[f]) <= 1e-4 * 96 * max(1.0, abs(w_[f]) / 96)
+                assert abs(g_["score"] - w_["score"]) <= 1e-4
+                if abs(float(r[cs]) - float(r[cs + 1])) > 1e-3:       # argmax is rounding-stable
+                    assert g_["identity"] == w_["identity"]
 
 
 @pytest.mark.gpu
