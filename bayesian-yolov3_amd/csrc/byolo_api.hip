@@ -464,8 +464,8 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
             l.Npad = (N + bn - 1) / bn * bn;
             l.w_off = off; off += align_up((size_t)K * l.Npad, 64);
         }
-        l.scale_off = off; off += align_up((size_t)N, 64);
-        l.shift_off = off; off += align_up((size_t)N, 64);
+        l.scale_off = off; off += align_up((size_t)std::max(N, l.Npad), 64);    // readable (zeros) up to Npad
+        l.shift_off = off; off += align_up((size_t)std::max(N, l.Npad), 64);
     }
     std::vector<float> blob(off, 0.f);
     std::vector<float> sc, sf;

@@ -32,6 +32,7 @@ struct ConvParams {
     int flags;                        // EPI_*
     float inv_keep;                   // 1/(1-p) when EPI_DROPOUT
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
+    int ablate;                       // debug: timing ablations (BYOLO_CONV_ABLATE), 0 in production
 };
 
 // tile configuration ids

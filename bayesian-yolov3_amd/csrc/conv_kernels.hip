@@ -10,7 +10,7 @@
 // GEMM view: M = S*Hout*Wout output pixels, N = cout, K = ksize^2 * Cin, NHWC activations
 // (a K-slice of 32 channels of one tap is 128 contiguous bytes per pixel), weights pre-packed at
 // byolo_finalize() as [K/32][Npad][32] so a block's B tile is one contiguous BN*128-byte read.
-// Block = 256 threads = 4 wave64; block tile BM x BN x 32, each wave owns TM x TN tiles of 32x32
+// Block = WM x WN wave64 (256 or 512 threads); block tile BM x BN x 32, each wave owns TM x TN tiles of 32x32
 // accumulated in registers; operands staged global -> VGPR -> LDS (row stride 36 floats: the
 // ds_read_b128 fragment reads and the ds_write_b128 staging writes are bank-conflict free),
 // double-buffered so the loads of K-tile t+1 are in flight under the MFMAs of tile t.
@@ -36,11 +36,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int NT = 64 * WM * WN;            // threads per block
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_LD = BM * 8 / 256;          // float4 loads per thread per A tile
-    constexpr int B_LD = BN * 8 / 256;          // float4 loads per thread per B tile
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1, "tile config");
+    constexpr int A_LD = BM * 8 / NT;           // float4 loads per thread per A tile
+    constexpr int B_LD = BN * 8 / NT;           // float4 loads per thread per B tile
+    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile config");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                            // [2][BM][LDS_LD]
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int hw = p.Hout * p.Wout;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        const int m = tile_m * BM + (tid >> 3) + 32 * j;
+        const int m = tile_m * BM + (tid >> 3) + (NT / 8) * j;
         if (m < p.M) {
             const int s = m / hw, rem = m - s * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
@@ -99,24 +100,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }
         }
         if (second) cc -= p.C0;
+        if (p.ablate & 1) {                       // [ablation] A from the zero page only
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + cc);
+            for (int j = 0; j < A_LD; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(p.zeros + a_q * 4);
+        } else {
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) b_reg[j] = *reinterpret_cast<const f32x4*>(w_ptr + (size_t)j * 1024);
-        w_ptr += w_step;
+            for (int j = 0; j < A_LD; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + cc);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) b_reg[j] = *reinterpret_cast<const f32x4*>(w_ptr + (size_t)j * (NT * 4));
+        if (!(p.ablate & 2)) w_ptr += w_step;     // [ablation] B always the same 16 KB
         if (++ld_chunk == p.cin_tiles) { ld_chunk = 0; ++ld_tap; }
     };
     auto store_a = [&](int buf) {
         float* a = As + buf * BM * LDS_LD;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j)
-            *reinterpret_cast<f32x4*>(a + ((tid >> 3) + 32 * j) * LDS_LD + a_q * 4) = a_reg[j];
+            *reinterpret_cast<f32x4*>(a + ((tid >> 3) + (NT / 8) * j) * LDS_LD + a_q * 4) = a_reg[j];
     };
     auto store_b = [&](int buf) {
         float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
-            const int idx = tid + 256 * j;
+            const int idx = tid + NT * j;
             *reinterpret_cast<f32x4*>(b + (idx >> 3) * LDS_LD + (idx & 7) * 4) = b_reg[j];
         }
     };
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);   // D^T: rows = channels
     };
 
     // ---- software-pipelined K loop ---------------------------------------------------------------
@@ -176,42 +182,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
         read_frags(buf, 2, af0, bf0);
         mfma_group(af1, bf1);
-        if (has_next) store_a(buf ^ 1);
+        if (has_next && !(p.ablate & 4)) store_a(buf ^ 1);   // [ablation] no LDS staging writes
 
         read_frags(buf, 3, af1, bf1);
         mfma_group(af0, bf0);
-        if (has_next) store_b(buf ^ 1);
+        if (has_next && !(p.ablate & 4)) store_b(buf ^ 1);
 
-        __syncthreads();
+        if (!(p.ablate & 8)) __syncthreads();  // [ablation] no barrier
         if (has_next) read_frags(buf ^ 1, 0, af0, bf0);
         mfma_group(af1, bf1);
     }
 
     // ---- fused epilogue: [dropout mask] * scale, + shift, leaky, [+ residual] ------------------
-    // C/D map of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // The MFMAs compute the TRANSPOSED tile (srcA = weights, srcB = pixels), so in the 32x32 C/D map
+    //   col = lane & 31 -> pixel,  row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -> channel
+    // every lane owns, per 32x32 tile, ONE pixel and 4 groups of 4 CONSECUTIVE channels: NHWC stores
+    // (and residual loads) are 16-byte vectors, and there is one row-address computation per tile.
+    if (p.ablate & 16) { if (acc[0][0][0] == 12345.678f) p.dst[0] = 1.f; return; }   // [ablation] no epilogue
     const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
+    const bool vec_ok = (p.ldc & 3) == 0;
+    const float keep_scale = do_drop ? p.inv_keep : 1.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = tile_n * BN + wn * TN * 32 + j * 32 + li;
-        const bool n_ok = n < p.N;
-        const float sc = n_ok ? p.scale[n] * (do_drop ? p.inv_keep : 1.f) : 0.f;
-        const float sf = n_ok ? p.shift[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = tile_n * BN + wn * TN * 32 + j * 32 + 8 * g + 4 * lh;     // 4 channels n0 .. n0+3
+            if (n0 >= p.N) continue;
+            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);          // arrays are padded to Npad
+            const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
+            const bool full = vec_ok && n0 + 3 < p.N;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = tile_m * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n_ok && m < p.M) {
-                    float v = acc[i][j][r] * sc;
-                    if (do_drop) {
-                        const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-                        if (!byolo_keep(idx, p.k0, p.k1, p.thr)) v = 0.f;
-                    }
-                    v += sf;
-                    if (do_leaky) v = fmaxf(v, 0.1f * v);
-                    const size_t o = (size_t)m * p.ldc + n;
-                    if (do_res) v += p.residual[o];
-                    p.dst[o] = v;
+            for (int i = 0; i < TM; ++i) {
+                const int m = tile_m * BM + wm * TM * 32 + i * 32 + li;
+                if (m >= p.M) continue;
+                const size_t o = (size_t)m * p.ldc + n0;
+                const uint64_t idx0 = (uint64_t)m * (uint64_t)p.N + (uint64_t)n0;
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = acc[i][j][4 * g + q] * (sc4[q] * keep_scale);
+                    if (do_drop && !byolo_keep(idx0 + q, p.k0, p.k1, p.thr)) x = 0.f;
+                    x += sf4[q];
+                    if (do_leaky) x = fmaxf(x, 0.1f * x);
+                    v[q] = x;
+                }
+                if (full) {
+                    if (do_res) v += *reinterpret_cast<const f32x4*>(p.residual + o);
+                    *reinterpret_cast<f32x4*>(p.dst + o) = v;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n0 + q < p.N) p.dst[o + q] = do_res ? v[q] + p.residual[o + q] : v[q];
                 }
             }
         }
@@ -238,13 +259,24 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, p);
+    static const int ablate = [] { const char* e = getenv("BYOLO_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    ConvParams q = p; q.ablate = ablate;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, st, q);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st) {
     switch (tile) {
-        case TILE_128x128: return launch_cfg<128, 128, 2, 2>(p, st);
+        case TILE_128x128: {
+            // tuning knob (A/B experiments only; every variant computes the same function)
+            static const int variant = [] { const char* e = getenv("BYOLO_CONV_VARIANT"); return e ? atoi(e) : 0; }();
+            switch (variant) {
+                case 1: return launch_cfg<128, 128, 2, 4>(p, st);     // 8 waves of 64x32
+                case 2: return launch_cfg<128, 128, 4, 2>(p, st);     // 8 waves of 32x64
+                case 3: return launch_cfg<256, 128, 4, 2>(p, st);     // 8 waves of 64x64, 256-row tile
+                default: return launch_cfg<128, 128, 2, 2>(p, st);    // 4 waves of 64x64
+            }
+        }
         case TILE_128x64:  return launch_cfg<128, 64, 2, 2>(p, st);
         default:           return launch_cfg<128, 32, 4, 1>(p, st);
     }
