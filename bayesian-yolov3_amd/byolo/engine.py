@@ -136,9 +136,18 @@ class Engine:
         return self.cfg.max_out * (2 if self.cfg.nms_mode == _lib.NMS_TWO_CLASS else 1)
 
     # ---- run ------------------------------------------------------------------------------------------
-    def _workspace(self, B, T):
+    def _workspace(self, B, T, slot=0):
+        """Workspace arena per slot: concurrent forwards on different HIP streams (slot = stream
+        index) must not share activations."""
         torch = _torch()
         need = self.workspace_bytes(B, T)
+        if slot:
+            if not hasattr(self, "_ws_slots"):
+                self._ws_slots = {}
+            ws = self._ws_slots.get(slot)
+            if ws is None or ws.numel() < need:
+                ws = self._ws_slots[slot] = torch.empty(need, dtype=torch.uint8, device="cuda:%d" % self.device)
+            return ws
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device="cuda:%d" % self.device)
@@ -153,14 +162,14 @@ class Engine:
         if img.device.index != self.device:
             raise ValueError("img is on cuda:%s, engine on cuda:%d" % (img.device.index, self.device))
 
-    def forward(self, img, T=1, seed=0, dropout_on=True, want_boxes=False, want_nms=True, out=None):
+    def forward(self, img, T=1, seed=0, dropout_on=True, want_boxes=False, want_nms=True, out=None, slot=0):
         """One sess.run of the reference (inference_epistemic.py:76).  Returns a dict of device
         tensors: rows [B,cap,D], kept [B,cap] int32, count [B,2] int32 and (want_boxes) boxes [B,N,D].
         Everything is enqueued on torch's current stream; no host synchronisation."""
         torch = _torch()
         self._check_img(img)
         B = int(img.shape[0])
-        ws = self._workspace(B, T)
+        ws = self._workspace(B, T, slot)
         N, D = self.num_boxes()
         dev = img.device
         res = out if out is not None else {}

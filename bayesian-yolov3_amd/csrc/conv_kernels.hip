@@ -17,6 +17,7 @@
 // The K order inside a 32-slice is permuted (lane-half h of MFMA step j consumes k = 8q+4h+j) so
 // that every lane fetches its four A (and B) operands of four MFMA steps with ONE ds_read_b128.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
 
@@ -33,6 +34,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // range of logical tiles so neighbouring tiles (same A rows / same weights) share its L2.
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+// Scheduling pattern for one MFMA group: after every MFMA place ceil(aux / N_MFMA) auxiliary
+// instructions, in the order global loads -> LDS reads -> LDS writes (LLVM SchedGroupMask: MFMA 0x8,
+// VMEM_READ 0x20, DS_READ 0x100, DS_WRITE 0x200).  Address arithmetic is left to the scheduler.
+template <int N_MFMA, int N_VMEM, int N_DSR, int N_DSW>
+__device__ __forceinline__ void sched_interleave() {
+    constexpr int AUX = N_VMEM + N_DSR + N_DSW;
+    constexpr int PER = (AUX + N_MFMA - 1) / N_MFMA;
+#pragma unroll
+    for (int k = 0; k < N_MFMA; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = k * PER + u;
+            if (q < N_VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            else if (q < N_VMEM + N_DSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (q < AUX) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -79,13 +100,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvPara
     const float* w_ptr = p.wpk + (size_t)tile_n * BN * BK + (size_t)tid * 4;   // advanced by Npad*32 per K-tile
     const size_t w_step = (size_t)p.Npad * BK;
     int ld_tap = 0, ld_chunk = 0;                // (tap, channel chunk) of the NEXT tile to load
+    int a_cc = 0;                                // channel offset of that tile inside its source
 
     f32x4 a_reg[A_LD], b_reg[B_LD];
 
-    auto load_tile = [&]() {
-        int cc = ld_chunk * BK;
+    // block-uniform bookkeeping for the next K-tile: scalar counters, and -- only when the filter tap
+    // or the source changes (once per Cin/32 tiles) -- the A_LD row pointers
+    auto next_tile = [&]() {
+        const int cc = ld_chunk * BK;
         const bool second = cc >= p.C0;
-        if (ld_chunk == 0 || cc == p.C0) {       // block-uniform: new tap or switch to the 2nd source
+        if (ld_chunk == 0 || cc == p.C0) {
             const int ky = ld_tap / p.ksize, kx = ld_tap - ky * p.ksize;
             const float* src = second ? p.src1 : p.src0;
             const int C = second ? p.C1 : p.C0, Hs = second ? p.Hs1 : p.Hs0, Ws = second ? p.Ws1 : p.Ws0;
@@ -99,18 +123,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvPara
                 a_ptr[j] = (ok ? src + off : p.zeros) + a_q * 4;
             }
         }
-        if (second) cc -= p.C0;
-        if (p.ablate & 1) {                       // [ablation] A from the zero page only
+        a_cc = second ? cc - p.C0 : cc;
+        if (++ld_chunk == p.cin_tiles) { ld_chunk = 0; ++ld_tap; }
+    };
+    auto issue_loads = [&]() {                   // A_LD + B_LD global_load_dwordx4, nothing else
 #pragma unroll
-            for (int j = 0; j < A_LD; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(p.zeros + a_q * 4);
-        } else {
-#pragma unroll
-            for (int j = 0; j < A_LD; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + cc);
-        }
+        for (int j = 0; j < A_LD; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + a_cc);
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) b_reg[j] = *reinterpret_cast<const f32x4*>(w_ptr + (size_t)j * (NT * 4));
-        if (!(p.ablate & 2)) w_ptr += w_step;     // [ablation] B always the same 16 KB
-        if (++ld_chunk == p.cin_tiles) { ld_chunk = 0; ++ld_tap; }
+        w_ptr += w_step;
     };
     auto store_a = [&](int buf) {
         float* a = As + buf * BM * LDS_LD;
@@ -161,37 +182,55 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvPara
     };
 
     // ---- software-pipelined K loop ---------------------------------------------------------------
-    // Per K-tile (4 groups of 16 MFMAs per wave at 128x128): the fragments of group g+1 are read
-    // from LDS while group g runs; the NEXT tile's global loads are issued at the top, its A / B
-    // halves are written to the other LDS buffer after groups 1 / 2; the one barrier per tile sits
-    // BEFORE the last group, so the barrier and the first fragment read of the next tile hide under
-    // the 16 MFMAs of group 3 (all reads of the current buffer are already in registers by then).
+    // An fp32 MFMA occupies the matrix pipe for 64 cycles; the wave issues in order, so any RUN of
+    // non-MFMA instructions longer than that lets the pipe drain (measured: the bare cluster of 8
+    // global loads + bookkeeping at the top of an iteration cost 8 %).  The loop body is therefore
+    // branch-free (last tile peeled) and every auxiliary instruction is placed BETWEEN two MFMAs with
+    // sched_group_barrier patterns.  Per K-tile, 4 groups of G = 4*TM*TN MFMAs per wave:
+    //   group 0 | global loads of tile t+1, LDS fragment reads of group 1
+    //   group 1 | fragment reads of group 2
+    //   group 2 | fragment reads of group 3, then the LDS writes of tile t+1 (other buffer)
+    //   barrier   (every read of the current buffer is in registers, tile t+1 is visible afterwards)
+    //   group 3 | fragment reads of group 0 of tile t+1  -> barrier + LDS latency hide under group 3
+    constexpr int G = 4 * TM * TN, NFR = TM + TN, NLD = A_LD + B_LD;
     f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
-    load_tile();
+    next_tile();
+    issue_loads();
     store_a(0); store_b(0);
     __syncthreads();
     read_frags(0, 0, af0, bf0);
 
-    for (int kt = 0; kt < p.KT; ++kt) {
-        const int buf = kt & 1;
-        const bool has_next = kt + 1 < p.KT;
-        if (has_next) load_tile();                     // global loads in flight under the MFMAs
-
+    auto tile_body = [&](const int buf, auto has_next_tag) {
+        constexpr bool HN = decltype(has_next_tag)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HN) issue_loads();
         read_frags(buf, 1, af1, bf1);
         mfma_group(af0, bf0);
+        sched_interleave<G, HN ? NLD : 0, NFR, 0>();
+        __builtin_amdgcn_sched_barrier(0);
 
         read_frags(buf, 2, af0, bf0);
         mfma_group(af1, bf1);
-        if (has_next && !(p.ablate & 4)) store_a(buf ^ 1);   // [ablation] no LDS staging writes
+        sched_interleave<G, 0, NFR, 0>();
+        __builtin_amdgcn_sched_barrier(0);
 
         read_frags(buf, 3, af1, bf1);
+        if constexpr (HN) { store_a(buf ^ 1); store_b(buf ^ 1); }
         mfma_group(af0, bf0);
-        if (has_next && !(p.ablate & 4)) store_b(buf ^ 1);
+        sched_interleave<G, 0, NFR, HN ? NLD : 0>();
+        __builtin_amdgcn_sched_barrier(0);
 
-        if (!(p.ablate & 8)) __syncthreads();  // [ablation] no barrier
-        if (has_next) read_frags(buf ^ 1, 0, af0, bf0);
+        __syncthreads();
+        if constexpr (HN) read_frags(buf ^ 1, 0, af0, bf0);
         mfma_group(af1, bf1);
+        sched_interleave<G, 0, HN ? NFR : 0, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kt = 0; kt + 1 < p.KT; ++kt) {
+        next_tile();
+        tile_body(kt & 1, std::true_type{});
     }
+    tile_body((p.KT - 1) & 1, std::false_type{});
 
     // ---- fused epilogue: [dropout mask] * scale, + shift, leaky, [+ residual] ------------------
     // The MFMAs compute the TRANSPOSED tile (srcA = weights, srcB = pixels), so in the 32x32 C/D map
@@ -249,7 +288,9 @@ int conv_pick_tile(int N) {
 
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    // BYOLO_LDS_PAD (bytes): tuning knob -- extra dynamic LDS to lower the blocks/CU residency in experiments
+    static const size_t lds_pad = [] { const char* e = getenv("BYOLO_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float) + lds_pad;
     const int grid = ((p.M + BM - 1) / BM) * (p.Npad / BN);
     auto k = conv_igemm_kernel<BM, BN, WM, WN>;
     static bool attr_done = false;

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch hipEvents in the timed region")
+    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many concurrent HIP streams")
     ap.add_argument("--dump-steps", default=None, help="write the per-launch table (layer, variant, M, N, K, ms, TF/s) here")
     args = ap.parse_args()
 
@@ -108,13 +109,32 @@ def main():
     out = {"rows": torch.empty((B, cap, D), device=x.device), "kept": torch.empty((B, cap), dtype=torch.int32, device=x.device),
            "count": torch.empty((B, 2), dtype=torch.int32, device=x.device)}
 
+    nstreams = max(1, args.streams)
+    assert B % nstreams == 0
+    streams = [torch.cuda.Stream(device=x.device) for _ in range(nstreams)] if nstreams > 1 else []
+    Bs = B // nstreams
+    subs = [dict(x=x[k * Bs:(k + 1) * Bs], out={n: t[k * Bs:(k + 1) * Bs] for n, t in out.items()}) for k in range(nstreams)]
+
     def step(i):
-        r = eng.forward(x, T=T, seed=1000 + i, dropout_on=True, want_boxes=False, want_nms=True, out=out)
+        if nstreams > 1:
+            # the batch as `nstreams` independent sub-batches on separate HIP streams: one sub-batch's
+            # kernel tails / launch gaps are filled by the other's kernels (images are independent)
+            cur = torch.cuda.current_stream(x.device)
+            for k, st in enumerate(streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    eng.forward(subs[k]["x"], T=T, seed=1000 + i, dropout_on=True, want_boxes=False, want_nms=True,
+                                out=subs[k]["out"], slot=k)
+            for st in streams:
+                cur.wait_stream(st)
+            r = out
+        else:
+            r = eng.forward(x, T=T, seed=1000 + i, dropout_on=True, want_boxes=False, want_nms=True, out=out)
         if world > 1:
             return bdist.allgather_boxes(r["rows"], r["kept"], r["count"], world)
         return r["rows"], r["kept"], r["count"]
 
-    prof = not args.no_profile
+    prof = not args.no_profile and nstreams == 1     # the handle's event set belongs to one forward at a time
     for i in range(args.warmup):
         step(i)
     eng.set_profiling(2 if prof else 0)
