@@ -106,10 +106,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvPara
 
     // block-uniform bookkeeping for the next K-tile: scalar counters, and -- only when the filter tap
     // or the source changes (once per Cin/32 tiles) -- the A_LD row pointers
+    // 3x3 over one plain source (every 3x3 conv of this network): the 9 tap pointers of a row differ
+    // by a block-uniform delta, so keep the tap-(0,0) offset + a 9-bit validity mask per row and
+    // switch taps with one add + select per row instead of re-deriving the address.
+    const bool fast_taps = p.ksize == 3 && p.C1 == 0 && p.sh0 == 0;
+    long long a_off00[A_LD];
+    unsigned a_mask[A_LD];
+    if (fast_taps) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = a_iy0[j] + t / 3, ix = a_ix0[j] + t % 3;
+                mk |= ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) ? (1u << t) : 0u;
+            }
+            a_mask[j] = mk;
+            a_off00[j] = (((long long)a_s0[j] * p.Hs0 + a_iy0[j]) * p.Ws0 + a_ix0[j]) * p.C0 + a_q * 4;
+        }
+    }
     auto next_tile = [&]() {
         const int cc = ld_chunk * BK;
         const bool second = cc >= p.C0;
-        if (ld_chunk == 0 || cc == p.C0) {
+        if (fast_taps) {
+            if (ld_chunk == 0) {
+                const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
+                const long long delta = ((long long)ky * p.Ws0 + kx) * p.C0;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j)
+                    a_ptr[j] = ((a_mask[j] >> ld_tap) & 1u) ? p.src0 + (a_off00[j] + delta) : p.zeros + a_q * 4;
+            }
+        } else if (ld_chunk == 0 || cc == p.C0) {
             const int ky = ld_tap / p.ksize, kx = ld_tap - ky * p.ksize;
             const float* src = second ? p.src1 : p.src0;
             const int C = second ? p.C1 : p.C0, Hs = second ? p.Hs1 : p.Hs0, Ws = second ? p.Ws1 : p.Ws0;

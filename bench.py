@@ -59,7 +59,9 @@ def cpu_baseline(cfg, params, n_img=1):
     import torch
     from oracle import cpu_ref
     from byolo import synth
-    cores = os.cpu_count() or 1
+    # oneDNN stops scaling on these layer sizes well before a 256-thread host is full (and
+    # oversubscription hurts): use at most 64 threads and report the number actually used
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     imgs = synth.synthetic_images(n_img, cfg["H"], cfg["W"], seed=1234)
     tp = cpu_ref.to_torch_params(params)
@@ -184,8 +186,14 @@ def main():
             f, ms, n = acc[128]
             tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for a in acc.values())
             ach = f / (ms * 1e-3)
+            # HBM/fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
+            # over this same command (tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "traffic_cfg%d.json" % args.config)
+            if os.path.exists(tpath) and not args.batch:
+                traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
             line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                                "frac": ach / PEAK_FP32_MFMA, "traffic": None,
+                                "frac": ach / PEAK_FP32_MFMA, "traffic": traffic,
                                 "kernel": "conv_igemm_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)",
                                 "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
                                 "all_conv_achieved": tot_f / (tot_ms * 1e-3) / 1e12,
