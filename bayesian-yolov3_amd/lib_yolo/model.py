@@ -301,6 +301,31 @@ class DetLayer:
         return out
 
     @property
+    def det(self):
+        """The per-(cell, prior) statistics of `layers.decode_epistemic` (`lib_yolo/layers.py:397-411`) that
+        consumers such as `vis_uncertainty.py` read, as views/derivations of the last run's box rows
+        (epistemic detection layers only; image 0, like the reference's batch-1 tensors):
+        `epi_covar_loc` [lh,lw,3,4,4] (diagonal only -- the off-diagonal covariances are reduced to the
+        determinant on the device and are not exported), `ale_var_loc` [lh,lw,3,4], `obj_mean`,
+        `obj_mutual_info`, `obj_entropy`, `cls_mutual_info`, `cls_entropy` [lh,lw,3], `cls_mean` [lh,lw,3,C]."""
+        import torch
+        if self.kind != DET_EPISTEMIC:
+            raise AttributeError('det statistics exist for epistemic detection layers only')
+        per_prior = [b[0] for b in self.bbox]                          # 3 x [lh, lw, D]
+        rows = torch.stack(per_prior, dim=2)                           # [lh, lw, 3, D]
+        C = self._model.cls_cnt
+        return {
+            'epi_covar_loc': torch.diag_embed(rows[..., 4:8]),
+            'ale_var_loc': rows[..., 8:12],
+            'obj_mean': rows[..., 14], 'obj_mutual_info': rows[..., 15], 'obj_entropy': rows[..., 16],
+            'cls_mean': rows[..., 17:17 + C], 'cls_mutual_info': rows[..., 17 + C], 'cls_entropy': rows[..., 18 + C],
+        }
+
+    @det.setter
+    def det(self, value):
+        pass
+
+    @property
     def raw_output(self):
         """Raw detection-conv output [S,lh,lw,F] of the last run (engine built with keep_all_outputs)."""
         return self._model.engine.layer_output(self._raw_ref.index)

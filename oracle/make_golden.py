@@ -50,7 +50,8 @@ synth = _synth()
 def _purge_reference_modules():
     for k in list(sys.modules):
         if k == "lib_yolo" or k.startswith("lib_yolo.") or k in ("inference_epistemic", "inference_aleatoric",
-                                                                    "inference_standard_yolov3", "detect"):
+                                                                    "inference_standard_yolov3", "detect",
+                                                                    "vis_uncertainty"):
             del sys.modules[k]
 
 
@@ -262,12 +263,37 @@ def gen_tail():
     np.savez_compressed(os.path.join(OUT, "tail_cases.npz"), **cases)
 
 
+def gen_vis():
+    """vis_uncertainty.py colorize / color_map (reference :15-47) on seeded maps, executed under the shim."""
+    import matplotlib
+    import matplotlib.cm
+    if not hasattr(matplotlib.cm, "get_cmap"):          # removed in matplotlib 3.9; the reference calls it (:27)
+        matplotlib.cm.get_cmap = lambda name: matplotlib.colormaps[name]
+    shim.install(dtype=torch.float32)
+    import_reference()
+    import vis_uncertainty as rvis
+    g = np.random.default_rng(21)
+    out = {}
+    for name, (h, w, stride) in {"s32": (2, 3, 32), "s8": (8, 12, 8)}.items():
+        img = g.random((1, h * stride, w * stride, 3)).astype(np.float32)
+        unc = (g.random((h, w, 1)) ** 3).astype(np.float32)
+        unc[0, 0, 0] = 50.0                                  # outlier above the 99th percentile -> clipped
+        res = rvis.color_map(shim.input_tensor(img), shim.input_tensor(unc), stride, 0, None).numpy()
+        out[name + "_img"], out[name + "_unc"], out[name + "_map"] = img, unc, res
+        out[name + "_colorized"] = rvis.colorize(shim.input_tensor(unc), 0, None).numpy()
+    np.savez_compressed(os.path.join(OUT, "vis_maps.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "vis":      # regenerate only this fixture
+        gen_vis()
+        return
     shim.install(dtype=torch.float32)
     mods = import_reference()
     gen_A(*mods)
+    gen_vis()
     gen_tail()
     stats = calibrated_params()
     gen_B(stats)

@@ -446,7 +446,30 @@ def _reshape(x, shape):
 
 
 def _gather(params, indices, axis=0):
-    return Tensor(torch.index_select(_T(params), axis, _T(indices).long()))
+    idx = _T(indices).long()
+    if idx.dim() > 1:
+        assert axis == 0
+        return Tensor(_T(params)[idx])
+    return Tensor(torch.index_select(_T(params), axis, idx))
+
+
+# ---- symbols used only by vis_uncertainty.py (colour mapping of the uncertainty maps) ----------------
+def _percentile(x, q, interpolation="nearest", **kw):
+    """tf.contrib.distributions.percentile, default 'nearest': sorted[round((n-1) * q/100)]."""
+    t = _T(x).reshape(-1)
+    s, _ = torch.sort(t)
+    i = int(torch.round(torch.tensor((t.numel() - 1) * (q / 100.0), dtype=torch.float64)).item())
+    return Tensor(s[i])
+
+
+def _convert_image_dtype(image, dtype, saturate=False):
+    t = _T(image)
+    if dtype is _UINT8 and t.is_floating_point():
+        # scale = dtype.max + 0.5 (avoids rounding problems in the cast), then saturating cast
+        return Tensor(torch.clamp(torch.floor(t * 255.5), 0, 255).to(torch.uint8))
+    if dtype is _FLOAT32 and t.dtype == torch.uint8:
+        return Tensor(t.to(STATE.dtype) * torch.tensor(1.0 / 255.0, dtype=STATE.dtype))
+    raise NotImplementedError("convert_image_dtype %s -> %s" % (t.dtype, dtype))
 
 
 def _constant(v, dtype=None):
@@ -480,6 +503,7 @@ class _DType:
         return "tf." + self.n
 
 
+_UINT8 = _DType("uint8")
 _FLOAT32 = _DType("float32")
 _INT32 = _DType("int32")
 _INT64 = _DType("int64")
@@ -514,6 +538,14 @@ def build_module():
     tf.ones, tf.ones_like, tf.zeros_like = _ones, _ones_like, _zeros_like
     tf.reshape, tf.gather, tf.constant, tf.cast = _reshape, _gather, _constant, _cast
     tf.while_loop = _while_loop
+    # vis_uncertainty.py
+    tf.uint8 = _UINT8
+    tf.contrib.distributions = types.SimpleNamespace(percentile=_percentile)
+    tf.reduce_min = lambda x, axis=None: Tensor(torch.min(_T(x))) if axis is None else Tensor(torch.amin(_T(x), dim=axis))
+    tf.clip_by_value = lambda x, lo, hi: Tensor(torch.clamp(_T(x), lo, hi))
+    tf.to_int32 = lambda x: Tensor(_T(x).to(torch.int32))
+    tf.round = lambda x: Tensor(torch.round(_T(x)))                  # half to even, like tf.round
+    tf.image.convert_image_dtype = _convert_image_dtype
 
     class _Errors:
         class OutOfRangeError(Exception):

@@ -165,3 +165,33 @@ def test_detect_do_it(tmp_path):
         assert set(res) == set(files)
         for boxes in res.values():
             assert boxes and all(0 <= b["y0"] <= 64 and 0 <= b["x1"] <= 96 for b in boxes)
+
+
+@pytest.mark.parametrize("name,stride", [("s32", 32), ("s8", 8)])
+def test_uncertainty_colour_maps_match_reference(name, stride):
+    """vis_uncertainty.colorize / color_map vs the reference's functions (fixture made by running them)."""
+    import vis_uncertainty as vis
+    g = golden("vis_maps.npz")
+    col = vis.colorize(g[name + "_unc"], 0, None)
+    assert_close(col, g[name + "_colorized"], "colorize", 1e-6, 1e-6)
+    got = vis.color_map(g[name + "_img"], g[name + "_unc"], stride, 0, None)
+    want = g[name + "_map"]
+    assert got.dtype == np.uint8 and got.shape == want.shape
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1 and (got != want).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_vis_uncertainty_do_it(tmp_path):
+    """One forward per image -> 11 uncertainty kinds x 9 (stride, prior) maps, reference file names."""
+    import vis_uncertainty as vis
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    f = str(tmp_path / "frame.png")
+    Image.fromarray(rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)).save(f)
+    cfg = make_config("x", 64, 96, T=4, weights="synthetic", batch_size=1, out_path=str(tmp_path / "maps"))
+    vis.do_it([f], cfg)
+    files = sorted(os.listdir(tmp_path / "maps"))
+    assert len(files) == 11 * 9
+    assert "frame_prior0_epi_x.png" in files and "frame_prior8_obj_mutual_info.png" in files
+    im = np.asarray(Image.open(tmp_path / "maps" / "frame_prior4_ale_w.png"))
+    assert im.shape == (64, 96, 3) and im.dtype == np.uint8
