@@ -253,6 +253,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvPara
         sched_interleave<G, 0, HN ? NFR : 0, 0>();
         __builtin_amdgcn_sched_barrier(0);
     };
+    // (s_setprio around this loop was measured: no effect, 126.3 vs 127.0 TF/s.)
     for (int kt = 0; kt + 1 < p.KT; ++kt) {
         next_tile();
         tile_body(kt & 1, std::true_type{});
