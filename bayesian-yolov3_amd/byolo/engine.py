@@ -223,12 +223,13 @@ class Engine:
         {layer, variant (tile BN or -1 = direct), M, N, K, ms, flops}."""
         n = check(self._h, lib.byolo_num_steps(self._h))
         out = []
-        layer, var, ms = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_float()
+        layer, var, ms, algo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_float(), ctypes.c_double()
         mnk = (ctypes.c_int64 * 3)()
         for i in range(n):
-            check(self._h, lib.byolo_step_profile(self._h, i, ctypes.byref(layer), ctypes.byref(var), mnk, ctypes.byref(ms)))
+            check(self._h, lib.byolo_step_profile(self._h, i, ctypes.byref(layer), ctypes.byref(var), mnk, ctypes.byref(ms),
+                                                  ctypes.byref(algo)))
             out.append(dict(layer=layer.value, variant=var.value, M=int(mnk[0]), N=int(mnk[1]), K=int(mnk[2]),
-                            ms=float(ms.value), flops=2.0 * mnk[0] * mnk[1] * mnk[2]))
+                            ms=float(ms.value), flops=float(algo.value), flops_executed=2.0 * mnk[0] * mnk[1] * mnk[2]))
         return out
 
     def stage_ms(self):

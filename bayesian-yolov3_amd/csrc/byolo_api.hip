@@ -70,7 +70,23 @@ struct Layer {
 struct Src { int layer; int C; int sh; bool tile; };
 struct View { Src s[2]; int n = 0; };
 
-struct Step { int layer; View in; };
+// One conv launch.  Normally one per conv/detection layer; the T-invariant de-duplication
+//  lowers some layers of a stacked (MC-sample) graph differently:
+//   STEP_REP      every input is a T-fold tile of an unstacked tensor and the layer has dropout: the
+//                 conv runs once per image, the epilogue is replayed for the T samples (masks differ);
+//   STEP_PARTIAL  the tiled (T-invariant) half of a channel concat, convolved once per image into an
+//                 auxiliary raw-accumulator tensor ...
+//   STEP_MAIN     ... which the conv over the stacked half picks up as an addend before scale / mask.
+enum StepMode { STEP_NORMAL = 0, STEP_REP = 1, STEP_PARTIAL = 2, STEP_MAIN = 3 };
+struct Step {
+    int layer; View in;
+    int mode = STEP_NORMAL;
+    int c_lo = 0, c_hi = 0;        // input-channel range of the layer's Cin this launch convolves
+    int out_tensor = -1;           // tensor id written (layer index, or n_layers + aux index)
+    int addend_tensor = -1;        // STEP_MAIN: the PARTIAL result
+    size_t w_off = 0; int Npad = 0, tile = 0;   // packed weights of this launch
+};
+struct AuxTensor { int H, W, C; };
 
 struct Plan {
     int B = -1, T = -1;
@@ -92,7 +108,9 @@ struct byolo {
     bool finalized = false;        // weights folded, packed and uploaded
     bool lowered = false;          // graph frozen and lowered to steps (host only)
     std::vector<Step> steps;
-    std::vector<int> last_use;     // per layer tensor: index of the last step reading it
+    std::vector<AuxTensor> aux;    // auxiliary tensors (ids n_layers + k): partial sums of split convs
+    bool dedup = true;             // T-invariant de-duplication (BYOLO_NO_DEDUP=1 disables, for A/B)
+    std::vector<int> last_use;     // per tensor id: index of the last step reading it
     float* d_blob = nullptr;       // packed weights + scale/shift
     size_t blob_floats = 0;
     float* d_ones = nullptr; float* d_zeros = nullptr; int maxC = 0;
@@ -398,11 +416,13 @@ static int32_t lower(byolo_t* h) {
         }
     }
     h->steps.clear();
+    h->aux.clear();
     h->last_use.assign(n, -1);
+    { const char* e = getenv("BYOLO_NO_DEDUP"); h->dedup = !(e && atoi(e)); }
     for (int i = 0; i < n; ++i) {
         Layer& l = h->layers[i];
         if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
-        Step st; st.layer = i;
+        Step st; st.layer = i; st.out_tensor = l.out_tensor; st.c_lo = 0; st.c_hi = l.Cin;
         std::string why;
         if (!resolve_view(h, l.prev, st.in, why)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d: %s", i, why.c_str());
         int ctot = 0;
@@ -417,8 +437,33 @@ static int32_t lower(byolo_t* h) {
         if (l.direct && (st.in.n != 1 || st.in.s[0].sh || (l.filters % 8) || l.op == OP_DETECTION))
             return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d: unsupported small-Cin convolution", i);
         if (st.in.n == 2 && (st.in.s[0].C % 32)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d: concat split not a multiple of 32", i);
+        // ---- T-invariant de-duplication ----------------------------------------------------------
+        if (h->dedup && l.op == OP_CONV && l.stacked && !l.direct) {
+            bool all_tile = true, any_tile = false;
+            for (int k = 0; k < st.in.n; ++k) { all_tile &= st.in.s[k].tile; any_tile |= st.in.s[k].tile; }
+            if (all_tile && l.drop_ordinal >= 0 && l.fused_residual < 0) {
+                st.mode = STEP_REP;                          // conv once per image, T masked epilogues
+                for (int k = 0; k < st.in.n; ++k) st.in.s[k].tile = false;
+            } else if (st.in.n == 2 && any_tile && !all_tile) {
+                const int kt = st.in.s[0].tile ? 0 : 1;      // the tiled (T-invariant) source
+                Step part; part.layer = i; part.mode = STEP_PARTIAL;
+                part.in.n = 1; part.in.s[0] = st.in.s[kt]; part.in.s[0].tile = false;
+                part.c_lo = kt == 0 ? 0 : st.in.s[0].C; part.c_hi = part.c_lo + st.in.s[kt].C;
+                h->aux.push_back({l.H, l.W, l.filters});
+                part.out_tensor = n + (int)h->aux.size() - 1;
+                h->last_use.push_back(-1);
+                const int pidx = (int)h->steps.size();
+                if (part.in.s[0].layer >= 0) h->last_use[part.in.s[0].layer] = pidx;
+                h->steps.push_back(part);
+                Step main = st; main.mode = STEP_MAIN; main.addend_tensor = part.out_tensor;
+                main.in.n = 1; main.in.s[0] = st.in.s[1 - kt];
+                main.c_lo = kt == 0 ? st.in.s[0].C : 0; main.c_hi = main.c_lo + st.in.s[1 - kt].C;
+                st = main;
+            }
+        }
         const int step_idx = (int)h->steps.size();
         for (int k = 0; k < st.in.n; ++k) if (st.in.s[k].layer >= 0) h->last_use[st.in.s[k].layer] = step_idx;
+        if (st.addend_tensor >= 0) h->last_use[st.addend_tensor] = step_idx;
         if (l.fused_residual >= 0) h->last_use[h->layers[l.fused_residual].ref[0]] = step_idx;
         h->steps.push_back(st);
     }
@@ -456,33 +501,37 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
     size_t off = 0; const int maxC = h->maxC;
     for (auto& st : h->steps) {
         Layer& l = h->layers[st.layer];
-        const int K = l.ksize * l.ksize * l.Cin, N = l.filters;
-        if (l.direct) { l.tile = -1; l.Npad = N; l.w_off = off; off += align_up((size_t)K * N, 64); }
+        const int Cs = st.c_hi - st.c_lo, K = l.ksize * l.ksize * Cs, N = l.filters;
+        if (l.direct) { st.tile = -1; st.Npad = N; st.w_off = off; off += align_up((size_t)K * N, 64); }
         else {
-            l.tile = conv_pick_tile(N);
-            const int bn = conv_tile_bn(l.tile);
-            l.Npad = (N + bn - 1) / bn * bn;
-            l.w_off = off; off += align_up((size_t)K * l.Npad, 64);
+            st.tile = conv_pick_tile(N);
+            const int bn = conv_tile_bn(st.tile);
+            st.Npad = (N + bn - 1) / bn * bn;
+            st.w_off = off; off += align_up((size_t)K * st.Npad, 64);
         }
-        l.scale_off = off; off += align_up((size_t)std::max(N, l.Npad), 64);    // readable (zeros) up to Npad
-        l.shift_off = off; off += align_up((size_t)std::max(N, l.Npad), 64);
+        l.tile = st.tile; l.Npad = st.Npad;
+        if (st.mode == STEP_PARTIAL) continue;                  // raw accumulators: no scale / shift
+        l.scale_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);   // readable (zeros) up to Npad
+        l.shift_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
     }
     std::vector<float> blob(off, 0.f);
     std::vector<float> sc, sf;
     for (auto& st : h->steps) {
         const Layer& l = h->layers[st.layer];
-        const int K = l.ksize * l.ksize * l.Cin, N = l.filters;
+        const int Cs = st.c_hi - st.c_lo, taps = l.ksize * l.ksize, N = l.filters;
         const float* w = h->params[l.p_kernel].data.data();     // HWIO == [K][N], k = (ky*ks + kx)*Cin + c
-        float* dst = blob.data() + l.w_off;
-        if (l.direct) memcpy(dst, w, sizeof(float) * (size_t)K * N);
+        float* dst = blob.data() + st.w_off;
+        if (l.direct) memcpy(dst, w, sizeof(float) * (size_t)taps * l.Cin * N);
         else {
-            for (int k = 0; k < K; ++k) {
-                const int kt = k >> 5, kk = k & 31;
-                const float* wr = w + (size_t)k * N;
-                float* d = dst + ((size_t)kt * l.Npad) * 32 + kk;
-                for (int nn = 0; nn < N; ++nn) d[(size_t)nn * 32] = wr[nn];
-            }
+            for (int tap = 0; tap < taps; ++tap)
+                for (int c = 0; c < Cs; ++c) {                  // this launch's channel slice of every tap
+                    const int k = tap * Cs + c, kt = k >> 5, kk = k & 31;
+                    const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
+                    float* d = dst + ((size_t)kt * st.Npad) * 32 + kk;
+                    for (int nn = 0; nn < N; ++nn) d[(size_t)nn * 32] = wr[nn];
+                }
         }
+        if (st.mode == STEP_PARTIAL) continue;
         fold_layer(h, l, sc, sf);
         memcpy(blob.data() + l.scale_off, sc.data(), sizeof(float) * N);
         memcpy(blob.data() + l.shift_off, sf.data(), sizeof(float) * N);
@@ -505,8 +554,13 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
 // ------------------------------------------------------------------------------------------------
 // workspace planning (liveness-based first-fit; 288 GB HBM is not a reason to thrash the caches)
 // ------------------------------------------------------------------------------------------------
-static int64_t tensor_bytes(const byolo_t* h, int layer, int B, int T) {
-    const Layer& l = h->layers[layer];
+static int64_t tensor_bytes(const byolo_t* h, int id, int B, int T) {
+    const int n = (int)h->layers.size();
+    if (id >= n) {                                                // auxiliary: one row per IMAGE pixel
+        const AuxTensor& a = h->aux[id - n];
+        return (int64_t)align_up((size_t)((int64_t)B * a.H * a.W * a.C) * sizeof(float), 256);
+    }
+    const Layer& l = h->layers[id];
     const int64_t S = l.stacked ? (int64_t)B * T : B;
     return (int64_t)align_up((size_t)(S * l.H * l.W * l.C) * sizeof(float), 256);
 }
@@ -514,7 +568,7 @@ static int64_t tensor_bytes(const byolo_t* h, int layer, int B, int T) {
 static void make_plan(byolo_t* h, int B, int T) {
     Plan& p = h->plan;
     if (p.B == B && p.T == T) return;
-    const int n = (int)h->layers.size();
+    const int n = (int)h->layers.size() + (int)h->aux.size();     // tensor ids: layers, then auxiliaries
     p.B = B; p.T = T; p.off.assign(n, -1);
     struct Blk { int64_t off, size; };
     std::vector<Blk> free_list;
@@ -542,7 +596,7 @@ static void make_plan(byolo_t* h, int B, int T) {
     };
     for (int si = 0; si < (int)h->steps.size(); ++si) {
         const Layer& l = h->layers[h->steps[si].layer];
-        const int t = l.out_tensor;
+        const int t = h->steps[si].out_tensor;
         p.off[t] = alloc(tensor_bytes(h, t, B, T));
         if (h->cfg.keep_all_outputs) continue;
         for (int k = 0; k < n; ++k)
@@ -609,14 +663,23 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.Hin = Hs[0] << sh[0]; p.Win = Wsz[0] << sh[0];
     p.Hout = l.H; p.Wout = l.W;
     p.ksize = l.ksize; p.stride = l.stride; p.pad = l.ksize == 3 ? 1 : 0;
-    const int64_t S = l.stacked ? (int64_t)B * T : B;
+    // rows of this launch: MC samples for stacked layers, IMAGES for the de-duplicated launches
+    const bool per_image = st.mode == STEP_REP || st.mode == STEP_PARTIAL;
+    const int64_t S = (l.stacked && !per_image) ? (int64_t)B * T : B;
     p.M = (int)(S * l.H * l.W);
-    p.N = l.filters; p.Npad = l.Npad; p.ldc = l.filters;
-    p.cin_tiles = l.Cin / 32; p.KT = l.ksize * l.ksize * p.cin_tiles;
-    p.wpk = dptr(h, l.w_off); p.scale = dptr(h, l.scale_off); p.shift = dptr(h, l.shift_off);
-    p.dst = reinterpret_cast<float*>(ws + h->plan.off[l.out_tensor]);
+    p.N = l.filters; p.Npad = st.Npad; p.ldc = l.filters;
+    p.cin_tiles = (st.c_hi - st.c_lo) / 32; p.KT = l.ksize * l.ksize * p.cin_tiles;
+    p.wpk = dptr(h, st.w_off);
+    if (st.mode == STEP_PARTIAL) { p.scale = h->d_ones; p.shift = h->d_zeros; }      // raw accumulators
+    else { p.scale = dptr(h, l.scale_off); p.shift = dptr(h, l.shift_off); }
+    p.dst = reinterpret_cast<float*>(ws + h->plan.off[st.out_tensor]);
     p.zeros = h->d_zeros;
     p.inv_keep = 1.f;
+    p.rep = st.mode == STEP_REP ? T : 1;
+    if (st.mode == STEP_MAIN) {
+        p.addend = reinterpret_cast<const float*>(ws + h->plan.off[st.addend_tensor]);
+        p.addend_T = l.stacked ? T : 1;
+    } else { p.addend = nullptr; p.addend_T = 1; }
 }
 
 static int32_t run_decode(byolo_t* h, char* ws, float* boxes, int B, int T, hipStream_t st) {
@@ -668,7 +731,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         }
         ConvParams p; fill_conv(h, s, d_img, ws, B, T, p);
         if (per_step) { HIPCHK(h, hipEventRecord(h->step_ev[si], st)); h->step_M[si] = p.M; }
-        if (l.op == OP_CONV) {
+        if (l.op == OP_CONV && s.mode != STEP_PARTIAL) {
             p.flags = EPI_LEAKY;
             if (l.drop_ordinal >= 0 && dropout_on) {
                 const byolo_drop_keys k = byolo_layer_keys(seed, (uint32_t)l.drop_ordinal, (double)h->cfg.drop_prob);
@@ -680,7 +743,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
                 p.residual = reinterpret_cast<const float*>(ws + h->plan.off[h->layers[l.fused_residual].ref[0]]);
             }
         }
-        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, l.tile, st));
+        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, s.tile, st));
     }
     if (per_step) { HIPCHK(h, hipEventRecord(h->step_ev[h->steps.size()], st)); h->step_valid = true; }
     if (h->profiling) { if (!backbone_marked) HIPCHK(h, hipEventRecord(h->ev[1], st)); HIPCHK(h, hipEventRecord(h->ev[2], st)); }
@@ -771,9 +834,10 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
     for (const Step& s : h->steps) {
         Layer& l = h->layers[s.layer];
         ConvParams p; fill_conv(h, s, d_img, ws, B, 1, p);
-        if (l.op == OP_DETECTION) { HIPCHK(h, launch_conv_igemm(p, l.tile, st)); continue; }
-        p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = 0;             // raw conv output
-        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, l.tile, st));
+        if (l.op == OP_DETECTION) { HIPCHK(h, launch_conv_igemm(p, s.tile, st)); continue; }
+        p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = 0;             // raw conv output (+ addend for STEP_MAIN)
+        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, s.tile, st));
+        if (s.mode == STEP_PARTIAL) continue;                              // half of a split conv: statistics at STEP_MAIN
         const int N = l.filters;
         HIPCHK(h, launch_channel_stats(p.dst, p.M, N, d_mean, d_var, d_tmp, st));
         HIPCHK(h, hipMemcpyAsync(h->params[l.p_mean].data.data(), d_mean, sizeof(float) * N, hipMemcpyDeviceToHost, st));
@@ -806,13 +870,23 @@ extern "C" int32_t byolo_num_steps(const byolo_t* h) {
     return (int32_t)h->steps.size();
 }
 
-extern "C" int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms) {
+extern "C" int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms,
+                                      double* algo_flops) {
     if (!h || i < 0 || i >= (int)h->steps.size()) return fail(h, BYOLO_ERR_ARG, "byolo_step_profile: bad index");
     if (!h->step_valid) return fail(h, BYOLO_ERR_STATE, "byolo_step_profile: no forward with profiling level 2");
-    const Layer& l = h->layers[h->steps[i].layer];
-    if (layer) *layer = h->steps[i].layer;
-    if (variant) *variant = l.direct ? -1 : conv_tile_bn(l.tile);
-    if (mnk) { mnk[0] = h->step_M[i]; mnk[1] = l.filters; mnk[2] = (int64_t)l.ksize * l.ksize * l.Cin; }
+    const Step& s = h->steps[i];
+    const Layer& l = h->layers[s.layer];
+    if (layer) *layer = s.layer;
+    if (variant) *variant = l.direct ? -1 : conv_tile_bn(s.tile);
+    // EXECUTED GEMM extents of this launch
+    if (mnk) { mnk[0] = h->step_M[i]; mnk[1] = l.filters; mnk[2] = (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo); }
+    // ALGORITHMIC FLOPs it stands for (graph as written): the whole layer on all MC
+    // samples for a de-duplicated launch, nothing for the auxiliary partial launch
+    if (algo_flops) {
+        const int64_t S = l.stacked ? (int64_t)h->plan.B * h->plan.T : h->plan.B;
+        *algo_flops = s.mode == STEP_PARTIAL ? 0.0
+                    : 2.0 * (double)(S * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);
+    }
     if (ms) {
         HIPCHK(h, hipSetDevice(h->device));
         HIPCHK(h, hipEventSynchronize(h->step_ev[i + 1]));

@@ -20,6 +20,9 @@ struct ConvParams {
     const float* scale; const float* shift;   // per output channel
     const float* residual;            // [M][ldc] or null
     const float* zeros;               // zero page, >= max(C0, C1) floats: source of padded / out-of-range rows
+    const float* addend;              // [B*hw][N] raw partial sums joined before scale (T-invariant half), or null
+    int addend_T;                     // samples per image of THIS launch's rows (1 if rows are images)
+    int rep;                          // >= 1: epilogue replays for `rep` MC samples per computed row
     float* dst;                       // [M][ldc]
     int C0, C1;                       // channels of the two sources (C1 == 0: single source)
     int Hs0, Ws0, Hs1, Ws1;           // physical spatial size of each source

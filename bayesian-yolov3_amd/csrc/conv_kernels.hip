@@ -269,6 +269,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvPara
     const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
     const bool vec_ok = (p.ldc & 3) == 0;
     const float keep_scale = do_drop ? p.inv_keep : 1.f;
+    // T-invariant de-duplication (lowering in byolo_api.hip):
+    //   rep > 1     the conv ran once per IMAGE (its input does not depend on the MC sample); only the
+    //               dropout mask differs between the T samples, so the epilogue is replayed T times and
+    //               writes the T stacked outputs (row m = img*hw + pix  ->  (img*rep + t)*hw + pix);
+    //   addend      the T-invariant half of a concat input was convolved once per image into `addend`
+    //               (raw accumulators, [B*hw][N]); it joins the accumulator here, before scale / mask.
+    const int rep = p.rep;
+    int row_img[TM], row_pix[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = tile_m * BM + wm * TM * 32 + i * 32 + li;
+        row_img[i] = m / hw;
+        row_pix[i] = m - row_img[i] * hw;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -282,24 +296,39 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvPara
             for (int i = 0; i < TM; ++i) {
                 const int m = tile_m * BM + wm * TM * 32 + i * 32 + li;
                 if (m >= p.M) continue;
-                const size_t o = (size_t)m * p.ldc + n0;
-                const uint64_t idx0 = (uint64_t)m * (uint64_t)p.N + (uint64_t)n0;
-                f32x4 v;
+                f32x4 a4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float x = acc[i][j][4 * g + q] * (sc4[q] * keep_scale);
-                    if (do_drop && !byolo_keep(idx0 + q, p.k0, p.k1, p.thr)) x = 0.f;
-                    x += sf4[q];
-                    if (do_leaky) x = fmaxf(x, 0.1f * x);
-                    v[q] = x;
+                for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
+                if (p.addend) {
+                    const int mu = (row_img[i] / p.addend_T) * hw + row_pix[i];
+                    const float* ad = p.addend + (size_t)mu * p.N + n0;
+                    if (full) a4 += *reinterpret_cast<const f32x4*>(ad);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (n0 + q < p.N) a4[q] += ad[q];
+                    }
                 }
-                if (full) {
-                    if (do_res) v += *reinterpret_cast<const f32x4*>(p.residual + o);
-                    *reinterpret_cast<f32x4*>(p.dst + o) = v;
-                } else {
+                for (int t = 0; t < rep; ++t) {
+                    const int mo = rep > 1 ? (row_img[i] * rep + t) * hw + row_pix[i] : m;
+                    const size_t o = (size_t)mo * p.ldc + n0;
+                    const uint64_t idx0 = (uint64_t)mo * (uint64_t)p.N + (uint64_t)n0;
+                    f32x4 v;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n0 + q < p.N) p.dst[o + q] = do_res ? v[q] + p.residual[o + q] : v[q];
+                    for (int q = 0; q < 4; ++q) {
+                        float x = a4[q] * (sc4[q] * keep_scale);
+                        if (do_drop && !byolo_keep(idx0 + q, p.k0, p.k1, p.thr)) x = 0.f;
+                        x += sf4[q];
+                        if (do_leaky) x = fmaxf(x, 0.1f * x);
+                        v[q] = x;
+                    }
+                    if (full) {
+                        if (do_res) v += *reinterpret_cast<const f32x4*>(p.residual + o);
+                        *reinterpret_cast<f32x4*>(p.dst + o) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n0 + q < p.N) p.dst[o + q] = do_res ? v[q] + p.residual[o + q] : v[q];
+                    }
                 }
             }
         }

@@ -150,9 +150,13 @@ BYOLO_API int32_t byolo_set_profiling(byolo_t* h, int32_t on);   /* 0 off, 1 per
 BYOLO_API int32_t byolo_stage_ms(byolo_t* h, float ms[4]);
 /* per conv launch of the LAST forward (profiling level 2): graph layer, kernel variant
  * (BN of the implicit-GEMM tile: 128 / 64 / 32, or -1 for the direct small-Cin kernel), the GEMM
- * extents {M, N, K} and the launch's device time.  byolo_num_steps = launches per forward. */
+ * EXECUTED extents {M, N, K}, the launch's device time and the ALGORITHMIC FLOPs it stands for (2*M*N*K of
+ * the layer as written; differs from the executed work only for the T-invariant de-duplicated launches:
+ * conv once per image + T masked epilogues, and the per-image partial sum of a concat's tiled half, which
+ * carries 0).  byolo_num_steps = launches per forward. */
 BYOLO_API int32_t byolo_num_steps(const byolo_t* h);
-BYOLO_API int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms);
+BYOLO_API int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms,
+                                     double* algo_flops);
 /* analytic cost of one forward: conv FLOPs (2*MAC, graph as written) for B images x T samples */
 BYOLO_API int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops);
 
