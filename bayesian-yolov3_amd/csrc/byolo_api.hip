@@ -122,6 +122,7 @@ struct byolo {
     bool ev_valid = false;
     std::vector<hipEvent_t> step_ev;   // steps + 1 events (level 2)
     std::vector<int64_t> step_M;       // M of each launch in the last forward
+    std::vector<int> step_tile;        // tile variant it was launched with
     bool step_valid = false;
 };
 
@@ -721,6 +722,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
     if (per_step) {
         while (h->step_ev.size() < h->steps.size() + 1) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->step_ev.push_back(e); }
         h->step_M.assign(h->steps.size(), 0);
+        h->step_tile.assign(h->steps.size(), 0);
     }
     bool backbone_marked = false;
     for (size_t si = 0; si < h->steps.size(); ++si) {
@@ -743,7 +745,14 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
                 p.residual = reinterpret_cast<const float*>(ws + h->plan.off[h->layers[l.fused_residual].ref[0]]);
             }
         }
-        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, s.tile, st));
+        // Grid fill: 256 CUs x 2 resident blocks.  A 128x128 tiling of a small-M layer (deep backbone
+        // layers at small batch) leaves CUs idle; the 128x64 tile doubles the block count (the packed
+        // weight layout [K/32][Npad][32] does not depend on BN when N % 128 == 0).
+        int tile = s.tile;
+        if (!l.direct && tile == TILE_128x128 && (p.N % 128) == 0 &&
+            (int64_t)((p.M + 127) / 128) * (p.N / 128) < 512) tile = TILE_128x64;
+        if (per_step) h->step_tile[si] = tile;
+        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, tile, st));
     }
     if (per_step) { HIPCHK(h, hipEventRecord(h->step_ev[h->steps.size()], st)); h->step_valid = true; }
     if (h->profiling) { if (!backbone_marked) HIPCHK(h, hipEventRecord(h->ev[1], st)); HIPCHK(h, hipEventRecord(h->ev[2], st)); }
@@ -877,7 +886,7 @@ extern "C" int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int
     const Step& s = h->steps[i];
     const Layer& l = h->layers[s.layer];
     if (layer) *layer = s.layer;
-    if (variant) *variant = l.direct ? -1 : conv_tile_bn(s.tile);
+    if (variant) *variant = l.direct ? -1 : conv_tile_bn(h->step_tile[i]);
     // EXECUTED GEMM extents of this launch
     if (mnk) { mnk[0] = h->step_M[i]; mnk[1] = l.filters; mnk[2] = (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo); }
     // ALGORITHMIC FLOPs it stands for (graph as written): the whole layer on all MC
