@@ -258,9 +258,6 @@ static constexpr int SORT_CH = 4096;                        // u64 keys per LDS 
 static inline int64_t next_pow2(int64_t n) { int64_t p = 1; while (p < n) p <<= 1; return p; }
 static inline int64_t sort_np(int64_t N) { const int64_t p = next_pow2(N); return p < SORT_CH ? SORT_CH : p; }
 
-size_t nms_workspace_bytes(int B, int64_t N) {
-    return (size_t)B * (size_t)sort_np(N) * sizeof(unsigned long long) + (size_t)B * 16;
-}
 
 __device__ __forceinline__ unsigned int score_key(float f) {
     // ascending key == descending score; NaN and scores <= -FLT_MAX are not candidates
@@ -277,10 +274,11 @@ __device__ __forceinline__ void ce(unsigned long long& a, unsigned long long& b,
 
 __global__ __launch_bounds__(SORT_THREADS) void sort_keys_kernel(const float* boxes, int64_t N, int D, int obj_idx,
                                                                  int64_t NP, unsigned long long* keys_all,
-                                                                 int* n_valid_all) {
+                                                                 int* n_valid_all, const int* need) {
     __shared__ unsigned long long sk[SORT_CH];
     __shared__ int s_valid;
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (need && !need[b]) return;                            // the fast path already finished this image
     unsigned long long* keys = keys_all + (size_t)b * NP;
     const float* bx = boxes + (size_t)b * N * D;
     if (tid == 0) s_valid = 0;
@@ -380,12 +378,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* boxes, in
                                                           int cls_start, int two_class, int max_out, float thr,
                                                           int64_t NP, const unsigned long long* keys_all,
                                                           const int* n_valid_all, float* rows, int32_t* kept,
-                                                          int32_t* count) {
+                                                          int32_t* count, const int* need) {
     __shared__ float k_y0[NMS_MAXK], k_x0[NMS_MAXK], k_y1[NMS_MAXK], k_x1[NMS_MAXK], k_ar[NMS_MAXK];
     __shared__ int k_idx[2 * NMS_MAXK];
     __shared__ float w_y0[64], w_x0[64], w_y1[64], w_x1[64], w_ar[64];
     __shared__ int s_nk;
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (need && !need[b]) return;                            // the fast path already finished this image
     const float* bx = boxes + (size_t)b * N * D;
     const unsigned long long* keys = keys_all + (size_t)b * NP;
     const int n_valid = n_valid_all[b];
@@ -477,16 +476,277 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* boxes, in
     if (tid == 0) { count[2 * b] = out_base; count[2 * b + 1] = first_cnt; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path of K8/K9: greedy NMS only ever looks at a PREFIX of the score order (until max_out boxes
+// are kept), and on that prefix it is a bit-matrix problem that the whole chip can work on:
+//   topk_select   per image, one workgroup: 3-level radix select (11+11+10 bits of the score key) of
+//                 the best >= NMS_TOPK candidates, compaction, bitonic sort in LDS  -> sorted prefix
+//   nms_matrix    suppression bit matrix of the prefix (row r, bit c: c later than r and IoU > thr),
+//                 64x64 tiles on ALL CUs (upper triangle only)
+//   nms_scan      per image: serial greedy scan over the prefix, 64 candidates per step from LDS,
+//                 the 4096-bit "removed" set lives in one wave's registers (lane w = word w)
+//   nms_finish    gather rows (tf.gather) + counts
+// Same result as the sequential definition.  If the prefix is exhausted before max_out boxes are kept
+// while more candidates exist (pathological clustering), or scores tie en masse, the image is flagged
+// and the exact general kernels above (full sort + nms_kernel) redo it -- decided on the device, no
+// host round trip.
+// ------------------------------------------------------------------------------------------------
+static constexpr int NMS_TOPK = 4096;                        // prefix length / matrix dimension
+static constexpr int NMS_CAP = 8192;                         // LDS sort capacity (prefix + score ties)
+static constexpr int NMS_WORDS = NMS_TOPK / 64;
+
+struct NmsWs {                                               // carve-up of the workspace
+    unsigned long long* keys; int* n_valid;                  // general path
+    unsigned long long* cand; int* n_cand; int* more; int* need; int* cnt;   // cnt [B][2]
+    unsigned long long* mask; int* kidx;
+};
+static size_t nms_ws_layout(int B, int64_t N, char* base, NmsWs* w) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += (bytes + 255) / 256 * 256; return p; };
+    char* a = take((size_t)B * sort_np(N) * 8); char* b = take((size_t)B * 4);
+    char* c = take((size_t)B * NMS_CAP * 8); char* d = take((size_t)B * 4); char* e = take((size_t)B * 4);
+    char* f = take((size_t)B * 4); char* g = take((size_t)B * 8);
+    char* hh = take((size_t)B * NMS_TOPK * NMS_WORDS * 8); char* i = take((size_t)B * 2 * NMS_MAXK * 4);
+    if (w) { w->keys = (unsigned long long*)a; w->n_valid = (int*)b; w->cand = (unsigned long long*)c; w->n_cand = (int*)d;
+             w->more = (int*)e; w->need = (int*)f; w->cnt = (int*)g; w->mask = (unsigned long long*)hh; w->kidx = (int*)i; }
+    return o;
+}
+size_t nms_workspace_bytes(int B, int64_t N) { return nms_ws_layout(B, N, nullptr, nullptr); }
+
+__global__ __launch_bounds__(1024) void topk_select_kernel(const float* boxes, int64_t N, int D, int obj_idx, int cls_start,
+                                                           int two_class, int pass, unsigned long long* cand_all,
+                                                           int* n_cand_all, int* more_all, int* need) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sbuf[];      // NMS_CAP keys
+    __shared__ int hist[2048];
+    __shared__ int part[32];
+    __shared__ int s_digit, s_below, s_le, s_cnt;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* bx = boxes + (size_t)b * N * D;
+    if (pass == 0 && tid == 0) need[b] = 0;
+    auto key_of = [&](int64_t i) -> unsigned int {
+        const float* r = bx + (size_t)i * D;
+        if (two_class) {
+            const float c0 = r[cls_start], c1 = r[cls_start + 1];
+            if (!((pass == 0) ? (c0 > c1) : (c1 > c0))) return 0xFFFFFFFFu;       // strict; ties dropped
+        }
+        return score_key(r[obj_idx]);
+    };
+    unsigned int prefix = 0, pmask = 0;
+    int below = 0, n_valid = 0, C = 0;
+    bool ties_overflow = false;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int level = 0; level < 3; ++level) {
+        const int shift = shifts[level], nd = 1 << widths[level];
+        for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < N; i += 1024) {
+            const unsigned int k = key_of(i);
+            if (k != 0xFFFFFFFFu && (k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & (nd - 1)], 1);
+        }
+        __syncthreads();
+        if (tid < 32) { int s = 0; for (int d = tid * 64; d < tid * 64 + 64; ++d) s += hist[d]; part[tid] = s; }
+        __syncthreads();
+        if (tid == 0) {
+            int total = 0;
+            for (int q = 0; q < 32; ++q) total += part[q];
+            if (level == 0) n_valid = total;                 // nothing filtered yet
+            // smallest digit d with below + #(digit <= d) >= target
+            const int nv = level == 0 ? total : 0;
+            (void)nv;
+            s_cnt = total;
+        }
+        __syncthreads();
+        if (level == 0) n_valid = s_cnt;
+        const int target = n_valid < NMS_TOPK ? n_valid : NMS_TOPK;
+        if (tid == 0) {
+            int cum = below, q = 0;
+            while (q < 31 && cum + part[q] < target) { cum += part[q]; ++q; }
+            int d = q * 64;
+            while (d < q * 64 + 63 && cum + hist[d] < target) { cum += hist[d]; ++d; }
+            s_digit = d; s_below = cum; s_le = cum + hist[d];
+        }
+        __syncthreads();
+        prefix |= (unsigned int)s_digit << shift;
+        pmask |= (unsigned int)(nd - 1) << shift;
+        below = s_below;
+        C = s_le;
+        __syncthreads();
+        if (C <= NMS_CAP) break;                             // every key <= this (partial) threshold fits
+        if (level == 2) ties_overflow = true;                // > NMS_CAP boxes share one exact score
+    }
+    if (n_valid == 0) C = 0;
+    if (ties_overflow) { C = 0; if (tid == 0) need[b] = 1; }
+    // compaction of the keys <= threshold, then sort
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    if (C > 0) {
+        for (int64_t i = tid; i < N; i += 1024) {
+            const unsigned int k = key_of(i);
+            if (k != 0xFFFFFFFFu && (k & pmask) <= prefix) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                sbuf[pos] = ((unsigned long long)k << 32) | (unsigned int)i;
+            }
+        }
+    }
+    __syncthreads();
+    int P2 = 64;
+    while (P2 < C) P2 <<= 1;
+    for (int i = C + tid; i < P2; i += 1024) sbuf[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < P2 / 2; t += 1024) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                ce(sbuf[i], sbuf[i + j], (i & k) == 0);
+            }
+            __syncthreads();
+        }
+    unsigned long long* cand = cand_all + (size_t)b * NMS_CAP;
+    for (int i = tid; i < C; i += 1024) cand[i] = sbuf[i];
+    if (tid == 0) { n_cand_all[b] = C; more_all[b] = n_valid > C ? 1 : 0; }
+}
+
+__global__ __launch_bounds__(64) void nms_matrix_kernel(const float* boxes, int64_t N, int D, float thr,
+                                                        const unsigned long long* cand_all, const int* n_cand_all,
+                                                        unsigned long long* mask_all) {
+    __shared__ float c_y0[64], c_x0[64], c_y1[64], c_x1[64], c_ar[64];
+    const int w = blockIdx.x, rb = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    if (w < rb) return;                                      // lower triangle is never read
+    int Kc = n_cand_all[b];
+    if (Kc > NMS_TOPK) Kc = NMS_TOPK;
+    if (rb * 64 >= Kc) return;
+    const float* bx = boxes + (size_t)b * N * D;
+    const unsigned long long* cand = cand_all + (size_t)b * NMS_CAP;
+    const int r = rb * 64 + lane, c = w * 64 + lane;
+    NBox me = {0, 0, 0, 0, 0};
+    if (r < Kc) { const float* q = bx + (size_t)(cand[r] & 0xFFFFFFFFull) * D; me = make_box(q[0], q[1], q[2], q[3]); }
+    if (c < Kc) {
+        const float* q = bx + (size_t)(cand[c] & 0xFFFFFFFFull) * D;
+        const NBox o = make_box(q[0], q[1], q[2], q[3]);
+        c_y0[lane] = o.y0; c_x0[lane] = o.x0; c_y1[lane] = o.y1; c_x1[lane] = o.x1; c_ar[lane] = o.area;
+    }
+    __syncthreads();
+    unsigned long long bits = 0ull;
+    if (r < Kc) {
+        for (int e = 0; e < 64; ++e) {
+            const int col = w * 64 + e;
+            if (col > r && col < Kc) {
+                const NBox o = {c_y0[e], c_x0[e], c_y1[e], c_x1[e], c_ar[e]};
+                if (iou_gt(me, o, thr)) bits |= 1ull << e;
+            }
+        }
+        mask_all[((size_t)b * NMS_TOPK + r) * NMS_WORDS + w] = bits;
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_scan_kernel(int max_out, int pass, const unsigned long long* cand_all,
+                                                       const int* n_cand_all, const int* more_all,
+                                                       const unsigned long long* mask_all, int* kidx_all, int* cnt_all,
+                                                       int* need) {
+    __shared__ unsigned long long rows[64][NMS_WORDS];       // 32 KiB: the 64 matrix rows of this step
+    __shared__ int s_nk, s_done;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_cand = n_cand_all[b];
+    const int Kc = n_cand > NMS_TOPK ? NMS_TOPK : n_cand;
+    const int nwords = (Kc + 63) / 64;
+    const unsigned long long* cand = cand_all + (size_t)b * NMS_CAP;
+    const unsigned long long* mask = mask_all + (size_t)b * NMS_TOPK * NMS_WORDS;
+    const int base = pass ? cnt_all[2 * b] : 0;
+    int* kidx = kidx_all + (size_t)b * 2 * NMS_MAXK + base;
+    if (tid == 0) { s_nk = 0; s_done = 0; }
+    unsigned long long rem = 0ull;                           // wave 0, lane w: word w of the removed set
+    __syncthreads();
+    for (int c = 0; c < nwords; ++c) {
+        for (int t = tid; t < 64 * NMS_WORDS; t += 256) {
+            const int r = t / NMS_WORDS, w = t - r * NMS_WORDS;
+            const int gi = c * 64 + r;
+            rows[r][w] = (w >= c && w < nwords && gi < Kc) ? mask[(size_t)gi * NMS_WORDS + w] : 0ull;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int nk = s_nk;
+            unsigned long long cur =
+                ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(rem >> 32), c) << 32) |
+                (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)rem, c);
+            bool done = false;
+            for (int i = 0; i < 64; ++i) {
+                const int gi = c * 64 + i;
+                if (gi >= Kc) break;
+                if (!((cur >> i) & 1ull)) {
+                    if (lane == 0) kidx[nk] = (int)(cand[gi] & 0xFFFFFFFFull);
+                    ++nk;
+                    rem |= rows[i][lane];
+                    cur |= rows[i][c];
+                    if (nk == max_out) { done = true; break; }
+                }
+            }
+            if (lane == 0) { s_nk = nk; s_done = done ? 1 : 0; }
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    if (tid == 0) {
+        const int nk = s_nk;
+        cnt_all[2 * b + pass] = nk;
+        // prefix exhausted without filling max_out although more candidates exist -> general path
+        if (nk < max_out && (more_all[b] || n_cand > Kc)) need[b] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_finish_kernel(const float* boxes, int64_t N, int D, int max_out, int npass,
+                                                         const int* kidx_all, const int* cnt_all, const int* need,
+                                                         float* rows, int32_t* kept, int32_t* count) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (need[b]) return;                                     // the general kernels write this image
+    const float* bx = boxes + (size_t)b * N * D;
+    const int* kidx = kidx_all + (size_t)b * 2 * NMS_MAXK;
+    const int first = cnt_all[2 * b], total = first + (npass > 1 ? cnt_all[2 * b + 1] : 0);
+    const int cap = max_out * npass;
+    float* ro = rows + (size_t)b * cap * D;
+    int32_t* ko = kept + (size_t)b * cap;
+    for (int e = tid; e < cap * D; e += 256) {
+        const int k = e / D, c = e - k * D;
+        ro[e] = (k < total) ? bx[(size_t)kidx[k] * D + c] : 0.f;
+    }
+    for (int k = tid; k < cap; k += 256) ko[k] = (k < total) ? kidx[k] : -1;
+    if (tid == 0) { count[2 * b] = total; count[2 * b + 1] = first; }
+}
+
 hipError_t launch_sort_nms(const NmsParams& p, hipStream_t st) {
     if (p.max_out > NMS_MAXK || p.max_out < 1) return hipErrorInvalidValue;
     const int64_t NP = sort_np(p.N);
     if (p.ws_bytes < nms_workspace_bytes(p.B, p.N)) return hipErrorInvalidValue;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(p.ws);
-    int* n_valid = reinterpret_cast<int*>(keys + (size_t)p.B * NP);
-    hipLaunchKernelGGL(sort_keys_kernel, dim3(p.B), dim3(SORT_THREADS), 0, st, p.boxes, p.N, p.D, p.obj_idx, NP, keys,
-                       n_valid);
+    NmsWs w;
+    nms_ws_layout(p.B, p.N, reinterpret_cast<char*>(p.ws), &w);
+    static const bool general_only = [] { const char* e = getenv("BYOLO_NMS_GENERAL"); return e && atoi(e); }();
+    const int* need = nullptr;
+    if (!general_only) {
+        static bool attr_done = false;
+        const size_t lds = (size_t)NMS_CAP * sizeof(unsigned long long);
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        const int npass = p.two_class ? 2 : 1;
+        for (int pass = 0; pass < npass; ++pass) {
+            hipLaunchKernelGGL(topk_select_kernel, dim3(p.B), dim3(1024), lds, st, p.boxes, p.N, p.D, p.obj_idx, p.cls_start,
+                               p.two_class, pass, w.cand, w.n_cand, w.more, w.need);
+            hipLaunchKernelGGL(nms_matrix_kernel, dim3(NMS_WORDS, NMS_WORDS, p.B), dim3(64), 0, st, p.boxes, p.N, p.D,
+                               p.iou_thr, w.cand, w.n_cand, w.mask);
+            hipLaunchKernelGGL(nms_scan_kernel, dim3(p.B), dim3(256), 0, st, p.max_out, pass, w.cand, w.n_cand, w.more,
+                               w.mask, w.kidx, w.cnt, w.need);
+        }
+        hipLaunchKernelGGL(nms_finish_kernel, dim3(p.B), dim3(256), 0, st, p.boxes, p.N, p.D, p.max_out, npass, w.kidx,
+                           w.cnt, w.need, p.rows, p.kept, p.count);
+        need = w.need;
+    }
+    // general path (exact for every input); a no-op per image unless flagged by the fast path
+    hipLaunchKernelGGL(sort_keys_kernel, dim3(p.B), dim3(SORT_THREADS), 0, st, p.boxes, p.N, p.D, p.obj_idx, NP, w.keys,
+                       w.n_valid, need);
     hipLaunchKernelGGL(nms_kernel, dim3(p.B), dim3(NMS_THREADS), 0, st, p.boxes, p.N, p.D, p.obj_idx, p.cls_start,
-                       p.two_class, p.max_out, p.iou_thr, NP, keys, n_valid, p.rows, p.kept, p.count);
+                       p.two_class, p.max_out, p.iou_thr, NP, w.keys, w.n_valid, p.rows, p.kept, p.count, need);
     return hipGetLastError();
 }
 

@@ -179,6 +179,39 @@ def test_nms_random_large(two_class):
     _check_nms_against_oracle(rows, res, "bayesian_yolov3_aleatoric", two_class=two_class)
 
 
+@pytest.mark.parametrize("case", ["spread", "spread_two_class", "mass_ties", "prefix_exhausted", "few_valid"])
+def test_nms_fast_path_and_fallbacks(case):
+    """The bit-matrix fast path (top-4096 prefix) and every way it hands over to the general kernels:
+    spread boxes (fast path alone), > 8192 exactly tied scores (radix select overflows), a prefix that is
+    exhausted before max_out boxes are kept (heavy clustering), fewer valid scores than the prefix."""
+    torch = _torch()
+    from byolo import Engine
+    g = np.random.default_rng(11)
+    N, D = 22743, 23
+    rows = g.random((2, N, D)).astype(np.float32)
+    two_class = case == "spread_two_class"
+    if case in ("spread", "spread_two_class", "mass_ties", "few_valid"):
+        c = g.random((2, N, 2)).astype(np.float32)
+        s = (g.random((2, N, 2)) * 0.02 + 0.002).astype(np.float32)
+        rows[..., 0:2] = c - s; rows[..., 2:4] = c + s
+    else:                                   # 40 tight clusters: ~40 boxes survive, all 22 743 must be visited
+        centers = g.random((40, 2)).astype(np.float32)
+        c = centers[g.integers(0, 40, (2, N))] + (g.standard_normal((2, N, 2)) * 0.002).astype(np.float32)
+        rows[..., 0:2] = c - 0.05; rows[..., 2:4] = c + 0.05
+    if case == "mass_ties":
+        rows[0, :, 14] = 0.25               # one score for every box: ties resolved by index
+        rows[1, :12000, 14] = 0.5           # 12 000-way tie at the top
+    if case == "few_valid":
+        rows[0, 100:, 14] = np.nan          # only 100 candidates
+        rows[1, :, 14] = -np.inf            # none at all
+    eng = Engine((64, 64, 3), 2, nms_mode=1 if two_class else 0)
+    res = eng.sort_nms(torch.from_numpy(rows).cuda(), obj_idx=14, cls_start_idx=17)
+    torch.cuda.synchronize()
+    _check_nms_against_oracle(rows, res, "bayesian_yolov3_aleatoric", two_class=two_class)
+    if case == "few_valid":
+        assert res["count"].cpu().numpy().tolist() == [[100, 100], [0, 0]] or int(res["count"][1, 0]) == 0
+
+
 @pytest.mark.parametrize("kind,variant", [(0, "yolov3"), (1, "yolov3_aleatoric"), (2, "bayesian_yolov3_aleatoric")])
 def test_decode_stage(kind, variant):
     """Staged decode on oracle-provided raw logits incl. saturated ones (NaN entropies, App. D.2)."""
