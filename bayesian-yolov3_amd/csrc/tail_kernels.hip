@@ -664,23 +664,32 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(int max_out, int pass, co
         }
         __syncthreads();
         if (wave == 0) {
-            int nk = s_nk;
+            // The only serial dependency is the removed-word of THIS step (`cur`); everything on its
+            // chain stays in registers: lane i holds word c of row i (suppression inside the step) and
+            // candidate i's box index.  Folding the kept rows into the other 63 words of the removed set
+            // and writing the kept indices happen after the loop, fully parallel.
+            const int nk0 = s_nk;
+            const int gi_l = c * 64 + lane;
+            const unsigned long long own = rows[lane][c];
+            const int my_idx = gi_l < Kc ? (int)(cand[gi_l] & 0xFFFFFFFFull) : -1;
+            const unsigned int own_lo = (unsigned int)own, own_hi = (unsigned int)(own >> 32);
             unsigned long long cur =
                 ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(rem >> 32), c) << 32) |
                 (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)rem, c);
-            bool done = false;
-            for (int i = 0; i < 64; ++i) {
-                const int gi = c * 64 + i;
-                if (gi >= Kc) break;
+            unsigned long long keptmask = 0ull;
+            int nk = nk0;
+            const int lim = Kc - c * 64 < 64 ? Kc - c * 64 : 64;
+            for (int i = 0; i < lim && nk < max_out; ++i) {
                 if (!((cur >> i) & 1ull)) {
-                    if (lane == 0) kidx[nk] = (int)(cand[gi] & 0xFFFFFFFFull);
+                    keptmask |= 1ull << i;
                     ++nk;
-                    rem |= rows[i][lane];
-                    cur |= rows[i][c];
-                    if (nk == max_out) { done = true; break; }
+                    cur |= ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)own_hi, i) << 32) |
+                           (unsigned int)__builtin_amdgcn_readlane((int)own_lo, i);
                 }
             }
-            if (lane == 0) { s_nk = nk; s_done = done ? 1 : 0; }
+            if ((keptmask >> lane) & 1ull) kidx[nk0 + __popcll(keptmask & ((1ull << lane) - 1ull))] = my_idx;
+            for (unsigned long long m = keptmask; m; m &= m - 1) rem |= rows[__builtin_ctzll(m)][lane];
+            if (lane == 0) { s_nk = nk; s_done = nk >= max_out ? 1 : 0; }
         }
         __syncthreads();
         if (s_done) break;
@@ -693,7 +702,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(int max_out, int pass, co
     }
 }
 
-__global__ __launch_bounds__(256) void nms_finish_kernel(const float* boxes, int64_t N, int D, int max_out, int npass,
+__global__ __launch_bounds__(1024) void nms_finish_kernel(const float* boxes, int64_t N, int D, int max_out, int npass,
                                                          const int* kidx_all, const int* cnt_all, const int* need,
                                                          float* rows, int32_t* kept, int32_t* count) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -704,11 +713,11 @@ __global__ __launch_bounds__(256) void nms_finish_kernel(const float* boxes, int
     const int cap = max_out * npass;
     float* ro = rows + (size_t)b * cap * D;
     int32_t* ko = kept + (size_t)b * cap;
-    for (int e = tid; e < cap * D; e += 256) {
+    for (int e = tid; e < cap * D; e += 1024) {
         const int k = e / D, c = e - k * D;
         ro[e] = (k < total) ? bx[(size_t)kidx[k] * D + c] : 0.f;
     }
-    for (int k = tid; k < cap; k += 256) ko[k] = (k < total) ? kidx[k] : -1;
+    for (int k = tid; k < cap; k += 1024) ko[k] = (k < total) ? kidx[k] : -1;
     if (tid == 0) { count[2 * b] = total; count[2 * b + 1] = first; }
 }
 
@@ -738,7 +747,7 @@ hipError_t launch_sort_nms(const NmsParams& p, hipStream_t st) {
             hipLaunchKernelGGL(nms_scan_kernel, dim3(p.B), dim3(256), 0, st, p.max_out, pass, w.cand, w.n_cand, w.more,
                                w.mask, w.kidx, w.cnt, w.need);
         }
-        hipLaunchKernelGGL(nms_finish_kernel, dim3(p.B), dim3(256), 0, st, p.boxes, p.N, p.D, p.max_out, npass, w.kidx,
+        hipLaunchKernelGGL(nms_finish_kernel, dim3(p.B), dim3(1024), 0, st, p.boxes, p.N, p.D, p.max_out, npass, w.kidx,
                            w.cnt, w.need, p.rows, p.kept, p.count);
         need = w.need;
     }
