@@ -56,21 +56,20 @@ __device__ __forceinline__ void sched_interleave() {
     }
 }
 
+// One BM x BN output tile (logical tile index -> (tile_m, tile_n)).
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical) {
     constexpr int NT = 64 * WM * WN;            // threads per block
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_LD = BM * 8 / NT;           // float4 loads per thread per A tile
     constexpr int B_LD = BN * 8 / NT;           // float4 loads per thread per B tile
     static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile config");
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                            // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;          // [2][BN][LDS_LD]
 
     const int tid = threadIdx.x;
     const int n_tiles = p.Npad / BN;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = logical % n_tiles, tile_m = logical / n_tiles;
 
     // ---- per-thread A-row bookkeeping (4 rows at BM = 128) ---------------------------------
@@ -335,6 +334,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvPara
     }
 }
 
+// Workgroups walk the tile list with stride gridDim.x: with gridDim.x == #tiles every workgroup owns one
+// tile; with a smaller (persistent) grid a workgroup runs several tiles back to back and skips the
+// per-workgroup launch cost.  Either way the tiles that are in flight on one XCD at a time are neighbours.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ntiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) conv_tile<BM, BN, WM, WN>(p, smem, xcd_remap(v, ntiles));
+}
+
 int conv_tile_bn(int tile) { return tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32); }
 
 int conv_pick_tile(int N) {
@@ -348,7 +357,10 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     // BYOLO_LDS_PAD (bytes): tuning knob -- extra dynamic LDS to lower the blocks/CU residency in experiments
     static const size_t lds_pad = [] { const char* e = getenv("BYOLO_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
     const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float) + lds_pad;
-    const int grid = ((p.M + BM - 1) / BM) * (p.Npad / BN);
+    int grid = ((p.M + BM - 1) / BM) * (p.Npad / BN);
+    // BYOLO_PERSIST = workgroups per CU of a persistent grid (0 = one workgroup per tile)
+    static const int persist = [] { const char* e = getenv("BYOLO_PERSIST"); return e ? atoi(e) : 0; }();
+    if (persist > 0 && grid > 256 * persist) grid = 256 * persist;
     auto k = conv_igemm_kernel<BM, BN, WM, WN>;
     static bool attr_done = false;
     if (!attr_done) {
