@@ -3,6 +3,8 @@ the oracle (CPU restatement + committed golden fixtures) on the same seeded inpu
 
 Tolerances (BASELINE.json north_star): class ids and kept-box indices bit-exact; box coords /
 scores / sigma within 1e-4 (abs, or relative for |v| > 1)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -281,6 +283,31 @@ def test_workspace_reuse_matches_keep_all():
     _, a, _, _ = _run(v, 2, keep_all=True)
     _, b, _, _ = _run(v, 2, keep_all=False)
     assert torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["kept"], b["kept"])
+
+
+def test_full_size_vs_cpu_restatement():
+    """BASELINE config 4 geometry (608x608, T=30), one image, against the CPU restatement run on the
+    same device-calibrated weights: every pre-NMS row within 1e-4, tail bit-exact on the GPU's rows."""
+    torch = _torch()
+    from byolo import synth
+    from oracle import cpu_ref
+    v = "bayesian_yolov3_aleatoric"
+    m = build_model(v, 608, 608, T=30)[1]
+    eng = m.engine
+    eng.set_params(synth.base_params(eng.param_shapes(), v, 2, seed=7))
+    eng.finalize()
+    eng.calibrate_bn(torch.from_numpy(synth.synthetic_images(2, 608, 608, seed=999)).cuda())
+    imgs = synth.synthetic_images(1, 608, 608, seed=1234)
+    out = eng.forward(torch.from_numpy(imgs).cuda(), T=30, seed=42, want_boxes=True)
+    torch.cuda.synchronize()
+    params = eng.get_params()                                   # includes the calibrated BN statistics
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        ref, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params), imgs, v, T=30, seed=42)
+    boxes = out["boxes"].cpu().numpy()
+    err = assert_close(boxes, ref.numpy(), "608x608 T=30 pre-NMS rows")
+    print("608x608 T=30: max |err| = %.3e over %d values" % (err, boxes.size))
+    _check_nms_against_oracle(boxes, out, v)
 
 
 def test_full_size_properties():
