@@ -631,7 +631,13 @@ static int32_t check_run(byolo_t* h, int32_t B, int32_t T, const char* what, boo
     for (const auto& l : h->layers) {
         const int64_t S = l.stacked ? (int64_t)B * T : B;
         if (S * l.H * l.W >= (int64_t)1 << 31) return fail(h, BYOLO_ERR_ARG, "%s: B*T*h*w exceeds 2^31 pixels", what);
+        // the convolution addresses its sources with 32-bit byte offsets (buffer loads)
+        if ((uint64_t)S * l.H * l.W * l.C * 4 > CONV_MAX_SRC_BYTES)
+            return fail(h, BYOLO_ERR_ARG, "%s: a [%lld,%d,%d,%d] activation exceeds the 3 GiB a convolution source may span; "
+                        "split the call into smaller image batches", what, (long long)S, l.H, l.W, l.C);
     }
+    if ((uint64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c * 4 > CONV_MAX_SRC_BYTES)
+        return fail(h, BYOLO_ERR_ARG, "%s: the image batch exceeds 3 GiB; split the call", what);
     return BYOLO_OK;
 }
 
@@ -651,10 +657,14 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     memset(&p, 0, sizeof p);
     const float* srcs[2] = {nullptr, nullptr};
     int Cs[2] = {0, 0}, Hs[2] = {1, 1}, Wsz[2] = {1, 1}, sh[2] = {0, 0}, sdiv[2] = {1, 1};
+    int64_t nsrc[2] = {0, 0};                 // samples held by each source tensor
     for (int k = 0; k < st.in.n; ++k) {
         const Src& s = st.in.s[k];
-        if (s.layer < 0) { srcs[k] = d_img; Hs[k] = h->cfg.img_h; Wsz[k] = h->cfg.img_w; }
-        else { srcs[k] = reinterpret_cast<const float*>(ws + h->plan.off[s.layer]); Hs[k] = h->layers[s.layer].H; Wsz[k] = h->layers[s.layer].W; }
+        if (s.layer < 0) { srcs[k] = d_img; Hs[k] = h->cfg.img_h; Wsz[k] = h->cfg.img_w; nsrc[k] = B; }
+        else {
+            srcs[k] = reinterpret_cast<const float*>(ws + h->plan.off[s.layer]); Hs[k] = h->layers[s.layer].H; Wsz[k] = h->layers[s.layer].W;
+            nsrc[k] = h->layers[s.layer].stacked ? (int64_t)B * T : B;
+        }
         Cs[k] = s.C; sh[k] = s.sh; sdiv[k] = s.tile ? T : 1;
     }
     p.src0 = srcs[0]; p.src1 = srcs[1] ? srcs[1] : srcs[0];
@@ -674,13 +684,19 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     if (st.mode == STEP_PARTIAL) { p.scale = h->d_ones; p.shift = h->d_zeros; }      // raw accumulators
     else { p.scale = dptr(h, l.scale_off); p.shift = dptr(h, l.shift_off); }
     p.dst = reinterpret_cast<float*>(ws + h->plan.off[st.out_tensor]);
-    p.zeros = h->d_zeros;
+    // buffer-descriptor extents (check_run bounds every tensor by CONV_MAX_SRC_BYTES) and the launch-constant divisors
+    p.src0_bytes = (uint32_t)((uint64_t)nsrc[0] * Hs[0] * Wsz[0] * Cs[0] * 4);
+    p.src1_bytes = Cs[1] ? (uint32_t)((uint64_t)nsrc[1] * Hs[1] * Wsz[1] * Cs[1] * 4) : p.src0_bytes;
+    p.w_bytes = (uint32_t)((uint64_t)p.KT * p.Npad * 32 * 4);
+    p.d_hw = make_fastdiv((uint32_t)(l.H * l.W)); p.d_wout = make_fastdiv((uint32_t)l.W);
+    p.d_sdiv0 = make_fastdiv((uint32_t)sdiv[0]); p.d_sdiv1 = make_fastdiv((uint32_t)sdiv[1]);
     p.inv_keep = 1.f;
     p.rep = st.mode == STEP_REP ? T : 1;
     if (st.mode == STEP_MAIN) {
         p.addend = reinterpret_cast<const float*>(ws + h->plan.off[st.addend_tensor]);
         p.addend_T = l.stacked ? T : 1;
     } else { p.addend = nullptr; p.addend_T = 1; }
+    p.d_addT = make_fastdiv((uint32_t)p.addend_T);
 }
 
 static int32_t run_decode(byolo_t* h, char* ws, float* boxes, int B, int T, hipStream_t st) {

@@ -14,13 +14,32 @@ enum : int { EPI_LEAKY = 1, EPI_DROPOUT = 2, EPI_RESIDUAL = 4 };
 // nearest x2 upsample (sh = 1) and/or a T-fold batch tile (sdiv = T): the reference's
 // tf.image.resize_nearest_neighbor / tf.concat(axis=3) / tf.concat([x]*T, axis=0)
 // (lib_yolo/layers.py:578-597) are never materialised.
+// n / d for n < 2^31 as (umulhi(n, mul) + n) >> shr: the kernels divide by launch constants only
+// (h*w, w, T, #column tiles), and a 32-bit integer division costs ~30 vector-ALU instructions that
+// are NOT hidden under the MFMAs (tools/mfma_peak.hip).
+struct FastDiv { uint32_t mul, shr; };
+inline FastDiv make_fastdiv(uint32_t d) {
+    uint32_t l = 0;
+    while (l < 32 && ((uint64_t)1 << l) < d) ++l;
+    FastDiv f;
+    f.mul = (uint32_t)(((((uint64_t)1 << l) - d) << 32) / d + 1);
+    f.shr = l;
+    return f;
+}
+
+// byte offsets into a source are 32-bit (buffer addressing); rows that fall into the zero padding get
+// this offset, which is out of range for every admissible source (<= CONV_MAX_SRC_BYTES) -> they read 0
+static constexpr uint32_t CONV_OOB_OFFSET = 0xC0000000u;
+static constexpr uint64_t CONV_MAX_SRC_BYTES = 0xBFF00000ull;
+
 struct ConvParams {
     const float* src0; const float* src1;
+    uint32_t src0_bytes, src1_bytes;  // extent of each source (buffer descriptor range)
     const float* wpk;                 // packed weights [K/32][Npad][32]   (direct kernel: HWIO as is)
+    uint32_t w_bytes;
     const float* scale; const float* shift;   // per output channel
     const float* residual;            // [M][ldc] or null
-    const float* zeros;               // zero page, >= max(C0, C1) floats: source of padded / out-of-range rows
-    const float* addend;              // [B*hw][N] raw partial sums joined before scale (T-invariant half), or null
+    const float* addend;             // [B*hw][N] raw partial sums joined before scale (T-invariant half), or null
     int addend_T;                     // samples per image of THIS launch's rows (1 if rows are images)
     int rep;                          // >= 1: epilogue replays for `rep` MC samples per computed row
     float* dst;                       // [M][ldc]
@@ -35,7 +54,8 @@ struct ConvParams {
     int flags;                        // EPI_*
     float inv_keep;                   // 1/(1-p) when EPI_DROPOUT
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
-    int ablate;                       // debug: timing ablations (BYOLO_CONV_ABLATE), 0 in production
+    FastDiv d_hw, d_wout, d_sdiv0, d_sdiv1, d_addT;   // Hout*Wout, Wout, sdiv0, sdiv1, addend_T
+    FastDiv d_ntiles;                 // Npad / BN: filled by the launcher for the tile it picked
 };
 
 // tile configuration ids

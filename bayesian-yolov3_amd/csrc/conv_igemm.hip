@@ -1,0 +1,457 @@
+// conv_igemm.hip -- K1..K5 of SURVEY.md section 2.1 as ONE fused implicit-GEMM kernel family for
+// gfx950 (CDNA4), exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, per call, the reference's op chain of lib_yolo/layers.py:545-575
+//   tf.layers.conv2d(no bias) -> tf.layers.dropout -> tf.layers.batch_normalization -> leaky_relu
+// plus, folded into the operand loader / epilogue, layers.py:505-507 (residual add), :578-580
+// (nearest x2 upsample), :583-592 (channel concat), :595-597 (T-fold batch tile), :533-537
+// (darknet stride-2 padding) and :600-613 (detection conv + bias).
+//
+// GEMM view: M = S*Hout*Wout output pixels, N = cout, K = ksize^2 * Cin, NHWC activations
+// (a K-slice of 32 channels of one tap is 128 contiguous bytes per pixel), weights pre-packed at
+// byolo_finalize() as [K/32][Npad][32] so a block's B tile is one contiguous BN*128-byte read.
+// Block = WM x WN wave64; block tile BM x BN x 32, each wave owns TM x TN tiles of 32x32 accumulated in
+// registers; operands staged global -> VGPR -> LDS (row stride 36 floats: the ds_read_b128 fragment
+// reads and the ds_write_b128 staging writes are bank-conflict free), double-buffered.
+// The K order inside a 32-slice is permuted (lane-half h of MFMA step j consumes k = 8q+4h+j) so
+// that every lane fetches its four A (and B) operands of four MFMA steps with ONE ds_read_b128.
+//
+// The design rule of the K loop (measured, tools/mfma_peak.hip): a vector-ALU instruction is NOT hidden
+// under a v_mfma_f32_32x32x2_f32 -- every one costs the SIMD ~3-4 cycles of matrix-pipe time, with one
+// or two waves per SIMD alike (1 VALU per MFMA: 155.5 -> 145.7 TFLOP/s).  Global loads, LDS reads/writes,
+// scalar ALU and waits do hide.  So the steady-state loop carries NO vector-ALU instruction at all:
+//   * operands are fetched with buffer loads: per-row 32-bit byte offset in a VGPR that changes only
+//     when the filter tap changes, the running channel offset in an SGPR (scalar ALU); rows in the zero
+//     padding hold an out-of-range offset and the buffer bounds check returns 0 for them;
+//   * every LDS address is a loop-invariant VGPR + an immediate (the loop is unrolled x2 so that the
+//     double-buffer index is a compile-time constant);
+//   * the K-tile sequencing (tap, channel chunk, weight offset) lives in SGPRs.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "byolo_kernels.h"
+#include "byolo_rng.h"
+
+namespace byk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BK = 32;
+static constexpr int LDS_LD = 36;            // floats per staged row (32 + 4 pad)
+static constexpr int RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family)
+// the loads of K-tile t+2 are issued in the last MFMA group of tile t (right after the staging registers
+// were written to LDS) instead of the first group of tile t+1: three groups of MFMAs between issue and
+// the LDS write that waits for them instead of two (measured +0.3 %)
+static constexpr bool EARLY_LOADS = true;
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shr; }
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // Blocks are dispatched round-robin over the 8 XCDs (bid % 8); give each XCD a contiguous
+    // range of logical tiles so neighbouring tiles (same A rows / same weights) share its L2.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+// Scheduling pattern for one MFMA group: after every MFMA place ceil(aux / N_MFMA) auxiliary
+// instructions, in the order global loads -> LDS reads -> LDS writes (LLVM SchedGroupMask: MFMA 0x8,
+// VMEM_READ 0x20, DS_READ 0x100, DS_WRITE 0x200).
+template <int N_MFMA, int N_VMEM, int N_DSR, int N_DSW>
+__device__ __forceinline__ void sched_interleave() {
+    constexpr int AUX = N_VMEM + N_DSR + N_DSW;
+    constexpr int PER = (AUX + N_MFMA - 1) / N_MFMA;
+#pragma unroll
+    for (int k = 0; k < N_MFMA; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = k * PER + u;
+            if (q < N_VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            else if (q < N_VMEM + N_DSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (q < AUX) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    }
+}
+
+// One BM x BN output tile (logical tile index -> (tile_m, tile_n)).
+// FAST: one plain source (no concat, no upsample), ksize <= 3 -- every backbone conv and every 3x3 /
+//       1x1 head conv after the concat de-duplication.  The ksize^2 tap addresses of a row differ by a
+//       block-uniform delta, so a row keeps the tap-(0,0) byte offset + a validity bit per tap, and a tap
+//       switch is one add + select per row.  !FAST re-derives the row offsets per (tap, source).
+template <int BM, int BN, int WM, int WN, bool FAST>
+__device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical) {
+    constexpr int NT = 64 * WM * WN;            // threads per block
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_LD = BM * 8 / NT;           // 16-byte loads per thread per A tile
+    constexpr int B_LD = BN * 8 / NT;           // 16-byte loads per thread per B tile
+    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile config");
+    // LDS map (bytes): A[2][BM][LDS_LD] then B[2][BN][LDS_LD]
+    constexpr int ROWB = LDS_LD * 4, A_BUF = BM * ROWB, B_BUF = BN * ROWB, B_BASE = 2 * A_BUF;
+    constexpr int JSTEP = (NT / 8) * ROWB;      // staging rows of one thread are NT/8 apart
+    char* lds = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x;
+    const uint32_t n_tiles = (uint32_t)p.Npad / BN;
+    const uint32_t tile_m = fdiv((uint32_t)logical, p.d_ntiles), tile_n = (uint32_t)logical - tile_m * n_tiles;
+
+    // ---- per-thread A-row bookkeeping (4 rows at BM = 128, 256 threads) -----------------------------
+    // Each thread stages the same A_LD rows of every K-tile.  Row state = output pixel (sample, oy, ox).
+    const int a_q = tid & 7, a_r = tid >> 3;
+    const uint32_t hw = (uint32_t)(p.Hout * p.Wout);
+    uint32_t a_voff[A_LD];                       // byte offset of the row for the current (tap, source)
+    uint32_t a_off00[A_LD], a_mask[A_LD];        // FAST: tap (0,0) offset, validity bit per tap
+    int a_iy0[A_LD], a_ix0[A_LD];                // !FAST: input coordinate of tap (0,0)
+    uint32_t a_s0[A_LD], a_s1[A_LD];             //        sample index in each source
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const uint32_t m = tile_m * BM + a_r + (NT / 8) * j;
+        const bool row_ok = m < (uint32_t)p.M;
+        const uint32_t mm = row_ok ? m : 0u;
+        const uint32_t s = fdiv(mm, p.d_hw), rem = mm - s * hw;
+        const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * (uint32_t)p.Wout;
+        const int iy0 = (int)oy * p.stride - p.pad, ix0 = (int)ox * p.stride - p.pad;
+        if constexpr (FAST) {
+            unsigned ym = 0, xm = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ym |= (t < p.ksize && (unsigned)(iy0 + t) < (unsigned)p.Hin) ? (1u << t) : 0u;
+                xm |= (t < p.ksize && (unsigned)(ix0 + t) < (unsigned)p.Win) ? (1u << t) : 0u;
+            }
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) mk |= ((ym >> t) & 1u) ? xm << (t * p.ksize) : 0u;
+            a_mask[j] = row_ok ? mk : 0u;
+            // 32-bit wrap-around arithmetic: the sum for a VALID tap is the true offset (< 2^32)
+            const uint32_t s0 = fdiv(s, p.d_sdiv0);
+            a_off00[j] = ((((s0 * (uint32_t)p.Hs0 + (uint32_t)iy0) * (uint32_t)p.Ws0 + (uint32_t)ix0) * (uint32_t)p.C0) + a_q * 4) * 4u;
+        } else {
+            a_iy0[j] = row_ok ? iy0 : -(1 << 28);    // every tap out of bounds -> reads 0
+            a_ix0[j] = ix0;
+            a_s0[j] = fdiv(s, p.d_sdiv0);
+            a_s1[j] = fdiv(s, p.d_sdiv1);
+        }
+    }
+
+    // ---- K-tile sequencing: block-uniform, scalar registers ------------------------------------------
+    int ld_chunk = 0, ld_tap = 0, ld_ky = 0, ld_kx = 0;      // (channel chunk, tap) of the NEXT tile to load
+    uint32_t a_soff = 0;                                    // byte offset of that tile's channels inside a row
+    const float* a_base = p.src0;
+    uint32_t a_bytes = p.src0_bytes;
+    uint32_t w_soff = 0;                                    // byte offset of the next weight tile
+    const uint32_t w_step = (uint32_t)p.Npad * BK * 4;
+    const uint32_t b_voff = (tile_n * BN * BK + (uint32_t)tid * 4) * 4;
+
+    auto next_tile = [&]() {
+        if constexpr (FAST) {
+            if (ld_chunk == 0) {
+                const uint32_t delta = (uint32_t)((ld_ky * p.Ws0 + ld_kx) * p.C0) * 4u;
+                const uint32_t bit = 1u << ld_tap;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) a_voff[j] = (a_mask[j] & bit) ? a_off00[j] + delta : CONV_OOB_OFFSET;
+            }
+            a_soff = (uint32_t)ld_chunk * (BK * 4);
+        } else {
+            const int cc = ld_chunk * BK;
+            const bool second = cc >= p.C0;
+            if (ld_chunk == 0 || cc == p.C0) {
+                const uint32_t C = second ? p.C1 : p.C0, Hs = second ? p.Hs1 : p.Hs0, Ws = second ? p.Ws1 : p.Ws0;
+                const int sh = second ? p.sh1 : p.sh0;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) {
+                    const int iy = a_iy0[j] + ld_ky, ix = a_ix0[j] + ld_kx;
+                    const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                    const uint32_t s = second ? a_s1[j] : a_s0[j];
+                    const uint32_t off = ((((s * Hs + (uint32_t)(iy >> sh)) * Ws + (uint32_t)(ix >> sh)) * C) + a_q * 4) * 4u;
+                    a_voff[j] = ok ? off : CONV_OOB_OFFSET;
+                }
+                a_base = second ? p.src1 : p.src0;
+                a_bytes = second ? p.src1_bytes : p.src0_bytes;
+            }
+            a_soff = (uint32_t)(second ? cc - p.C0 : cc) * 4u;
+        }
+        if (++ld_chunk == p.cin_tiles) {
+            ld_chunk = 0; ++ld_tap;
+            if (++ld_kx == p.ksize) { ld_kx = 0; ++ld_ky; }
+        }
+    };
+
+    f32x4 a_reg[A_LD], b_reg[B_LD];              // staging registers, one K-tile
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, p.w_bytes, RSRC_FLAGS);
+    auto issue_loads = [&]() {                   // A_LD + B_LD buffer_load_dwordx4 of the tile set up by next_tile()
+        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_base), 0, a_bytes, RSRC_FLAGS);
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j)
+            a_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[j], a_soff, 0));
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            b_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff, w_soff + j * (NT * 16), 0));
+        w_soff += w_step;
+    };
+    const int st_off = (a_r * LDS_LD + a_q * 4) * 4;         // A and B staging: row tid/8 (+ NT/8 per j), 16-byte column tid%8
+    auto store_tile = [&](auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (BUF * A_BUF + j * JSTEP)) = a_reg[j];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (B_BASE + BUF * B_BUF + j * JSTEP)) = b_reg[j];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int fa_off = ((wm * TM * 32 + li) * LDS_LD + lh * 4) * 4;
+    const int fb_off = ((wn * TN * 32 + li) * LDS_LD + lh * 4) * 4;
+
+    auto read_frags = [&](auto buf_tag, auto kq_tag, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+        constexpr int BUF = decltype(buf_tag)::value, KQ = decltype(kq_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(lds + fa_off + (BUF * A_BUF + KQ * 32 + i * 32 * ROWB));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(lds + fb_off + (B_BASE + BUF * B_BUF + KQ * 32 + j * 32 * ROWB));
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);   // D^T: rows = channels
+    };
+
+    // ---- software-pipelined K loop ---------------------------------------------------------------
+    // An fp32 MFMA occupies the matrix pipe for 64 cycles; the wave issues in order, so any RUN of
+    // non-MFMA instructions longer than that lets the pipe drain.  The loop body is branch-free (tail
+    // tiles peeled) and every auxiliary instruction is placed BETWEEN two MFMAs with
+    // sched_group_barrier patterns.  Per K-tile t, 4 groups of G = 4*TM*TN MFMAs per wave:
+    //   group 0 | LDS fragment reads of group 1
+    //   group 1 | fragment reads of group 2
+    //   group 2 | fragment reads of group 3, then the LDS writes of tile t+1 (other buffer)
+    //   barrier   (every read of the current buffer is in registers, tile t+1 is visible afterwards)
+    //   group 3 | buffer loads of tile t+2 into the staging registers just freed,
+    //           | fragment reads of group 0 of tile t+1  -> barrier + LDS latency hide under group 3
+    constexpr int G = 4 * TM * TN, NFR = TM + TN, NLD = A_LD + B_LD;
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    using c3 = std::integral_constant<int, 3>;
+    f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    const int KT = p.KT;
+    next_tile();
+    issue_loads();
+    store_tile(c0{});
+    if constexpr (EARLY_LOADS) { if (KT > 1) { next_tile(); issue_loads(); } }
+    __syncthreads();
+    read_frags(c0{}, c0{}, af0, bf0);
+
+    // tile t lives in LDS buffer BUF = t & 1.  HN: tile t+1 exists (stage it);  LD: tile t+2 exists (fetch it)
+    auto tile_body = [&](auto buf_tag, auto has_next_tag, auto load_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        using cur = std::integral_constant<int, BUF>;
+        using nxt = std::integral_constant<int, BUF ^ 1>;
+        constexpr bool HN = decltype(has_next_tag)::value;
+        constexpr bool LD0 = HN && !EARLY_LOADS, LD3 = decltype(load_tag)::value && EARLY_LOADS;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LD0) issue_loads();
+        read_frags(cur{}, c1{}, af1, bf1);
+        mfma_group(af0, bf0);
+        sched_interleave<G, LD0 ? NLD : 0, NFR, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+
+        read_frags(cur{}, c2{}, af0, bf0);
+        mfma_group(af1, bf1);
+        sched_interleave<G, 0, NFR, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+
+        read_frags(cur{}, c3{}, af1, bf1);
+        if constexpr (HN) store_tile(nxt{});
+        mfma_group(af0, bf0);
+        sched_interleave<G, 0, NFR, HN ? NLD : 0>();
+        __builtin_amdgcn_sched_barrier(0);
+
+        __syncthreads();
+        if constexpr (LD3) issue_loads();
+        if constexpr (HN) read_frags(nxt{}, c0{}, af0, bf0);
+        mfma_group(af1, bf1);
+        sched_interleave<G, LD3 ? NLD : 0, HN ? NFR : 0, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+    // (s_setprio around this loop was measured: no effect.)
+    int kt = 0;
+    if constexpr (EARLY_LOADS) {
+        for (; kt + 3 < KT; kt += 2) {                  // tiles kt, kt+1: both stage t+1 and fetch t+2
+            next_tile(); tile_body(c0{}, yes{}, yes{});
+            next_tile(); tile_body(c1{}, yes{}, yes{});
+        }
+        auto tail = [&](auto buf_tag, const int t) {      // the last 1..3 tiles (block-uniform branches)
+            if (t >= KT) return;
+            if (t + 2 < KT) { next_tile(); tile_body(buf_tag, yes{}, yes{}); }
+            else if (t + 1 < KT) tile_body(buf_tag, yes{}, no{});
+            else tile_body(buf_tag, no{}, no{});
+        };
+        tail(c0{}, kt); tail(c1{}, kt + 1); tail(c0{}, kt + 2);
+    } else {
+        for (; kt + 2 < KT; kt += 2) {
+            next_tile(); tile_body(c0{}, yes{}, no{});
+            next_tile(); tile_body(c1{}, yes{}, no{});
+        }
+        if (kt + 1 < KT) { next_tile(); tile_body(c0{}, yes{}, no{}); tile_body(c1{}, no{}, no{}); }
+        else tile_body(c0{}, no{}, no{});
+    }
+
+    // ---- fused epilogue: [+ addend] [dropout mask] * scale, + shift, leaky, [+ residual] ---------------
+    // The MFMAs compute the TRANSPOSED tile (srcA = weights, srcB = pixels), so in the 32x32 C/D map
+    //   col = lane & 31 -> pixel,  row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -> channel
+    // every lane owns, per 32x32 tile, ONE pixel and 4 groups of 4 CONSECUTIVE channels: NHWC stores
+    // (and residual loads) are 16-byte vectors.  The row part of every address (dst, residual, addend,
+    // dropout element index) is derived once per row; the (j, g) channel-group part is an immediate.
+    const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
+    const bool vec_ok = (p.ldc & 3) == 0;
+    const float keep_scale = do_drop ? p.inv_keep : 1.f;
+    // T-invariant de-duplication (lowering in byolo_api.hip):
+    //   rep > 1     the conv ran once per IMAGE (its input does not depend on the MC sample); only the
+    //               dropout mask differs between the T samples, so the epilogue is replayed T times and
+    //               writes the T stacked outputs (row m = img*hw + pix  ->  (img*rep + t)*hw + pix);
+    //   addend      the T-invariant half of a concat input was convolved once per image into `addend`
+    //               (raw accumulators, [B*hw][N]); it joins the accumulator here, before scale / mask.
+    const int rep = p.rep;
+    const int nb = (int)(tile_n * BN) + wn * TN * 32 + 4 * lh;       // first channel of this lane's (j=0, g=0) group
+    uint32_t row_m[TM], row_img[TM], row_pix[TM];
+    const float* add_row[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        row_m[i] = tile_m * BM + wm * TM * 32 + i * 32 + li;
+        const uint32_t mm = row_m[i] < (uint32_t)p.M ? row_m[i] : 0u;
+        row_img[i] = fdiv(mm, p.d_hw);
+        row_pix[i] = mm - row_img[i] * hw;
+        add_row[i] = p.addend ? p.addend + (size_t)(fdiv(row_img[i], p.d_addT) * hw + row_pix[i]) * p.N + nb : nullptr;
+    }
+    for (int t = 0; t < rep; ++t) {
+        float* dst_row[TM];
+        const float* res_row[TM];
+        uint64_t idx_row[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t mo = rep > 1 ? (row_img[i] * rep + t) * hw + row_pix[i] : row_m[i];
+            dst_row[i] = p.dst + (size_t)mo * p.ldc + nb;
+            res_row[i] = do_res ? p.residual + (size_t)mo * p.ldc + nb : nullptr;
+            idx_row[i] = (uint64_t)mo * (uint64_t)p.N + (uint64_t)nb;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dn = j * 32 + 8 * g;                        // channel offset of the group from nb
+                const int n0 = nb + dn;                               // 4 channels n0 .. n0+3
+                if (n0 >= p.N) continue;
+                f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);     // arrays are padded to Npad
+                const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
+                sc4 *= keep_scale;
+                const bool full = vec_ok && n0 + 3 < p.N;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (row_m[i] >= (uint32_t)p.M) continue;
+                    f32x4 a4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
+                    if (p.addend) {
+                        const float* ad = add_row[i] + dn;
+                        if (full) a4 += *reinterpret_cast<const f32x4*>(ad);
+                        else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (n0 + q < p.N) a4[q] += ad[q];
+                        }
+                    }
+                    const uint64_t idx0 = idx_row[i] + (uint64_t)dn;
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float x = a4[q] * sc4[q];
+                        if (do_drop && !byolo_keep(idx0 + q, p.k0, p.k1, p.thr)) x = 0.f;
+                        x += sf4[q];
+                        if (do_leaky) x = fmaxf(x, 0.1f * x);
+                        v[q] = x;
+                    }
+                    float* d = dst_row[i] + dn;
+                    if (full) {
+                        if (do_res) v += *reinterpret_cast<const f32x4*>(res_row[i] + dn);
+                        *reinterpret_cast<f32x4*>(d) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n0 + q < p.N) d[q] = do_res ? v[q] + res_row[i][dn + q] : v[q];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Workgroups walk the tile list with stride gridDim.x: with gridDim.x == #tiles every workgroup owns one
+// tile; with a smaller (persistent) grid a workgroup runs several tiles back to back.  Either way the
+// tiles that are in flight on one XCD at a time are neighbours.
+// (Measured and dropped: 8-wave 128x128 and 256x128 tiles, one workgroup per CU, a persistent grid, two
+//  streams, s_setprio, and de-phasing the two co-resident workgroups of a CU at launch -- none moved the
+//  number)
+template <int BM, int BN, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ntiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) conv_tile<BM, BN, WM, WN, FAST>(p, smem, xcd_remap(v, ntiles));
+}
+
+int conv_tile_bn(int tile) { return tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32); }
+
+int conv_pick_tile(int N) {
+    if (N > 64) return TILE_128x128;
+    if (N > 32) return TILE_128x64;
+    return TILE_128x32;
+}
+
+template <int BM, int BN, int WM, int WN, bool FAST>
+static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    auto k = conv_igemm_kernel<BM, BN, WM, WN, FAST>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
+    int grid = ((p.M + BM - 1) / BM) * (p.Npad / BN);
+    ConvParams q = p;
+    q.d_ntiles = make_fastdiv((uint32_t)(p.Npad / BN));
+    // BYOLO_PERSIST = workgroups per CU of a persistent grid (0 = one workgroup per tile; tuning knob)
+    static const int persist = [] { const char* e = getenv("BYOLO_PERSIST"); return e ? atoi(e) : 0; }();
+    if (persist > 0 && grid > 256 * persist) grid = 256 * persist;
+    const bool fast = p.C1 == 0 && p.sh0 == 0 && p.ksize <= 3;
+    return fast ? launch_one<BM, BN, WM, WN, true>(q, grid, st) : launch_one<BM, BN, WM, WN, false>(q, grid, st);
+}
+
+hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st) {
+    switch (tile) {
+        case TILE_128x128: return launch_cfg<128, 128, 2, 2>(p, st);      // 4 waves of 64x64
+        case TILE_128x64:  return launch_cfg<128, 64, 2, 2>(p, st);       // 4 waves of 64x32
+        default:           return launch_cfg<128, 32, 4, 1>(p, st);       // 4 waves of 32x32
+    }
+}
+
+}  // namespace byk

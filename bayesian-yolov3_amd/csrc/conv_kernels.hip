@@ -1,396 +1,12 @@
-// conv_kernels.hip -- K1..K5 of SURVEY.md section 2.1 as ONE fused implicit-GEMM kernel family for
-// gfx950 (CDNA4), exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32).
-//
-// Replaces, per call, the reference's op chain of lib_yolo/layers.py:545-575
-//   tf.layers.conv2d(no bias) -> tf.layers.dropout -> tf.layers.batch_normalization -> leaky_relu
-// plus, folded into the operand loader / epilogue, layers.py:505-507 (residual add), :578-580
-// (nearest x2 upsample), :583-592 (channel concat), :595-597 (T-fold batch tile), :533-537
-// (darknet stride-2 padding) and :600-613 (detection conv + bias).
-//
-// GEMM view: M = S*Hout*Wout output pixels, N = cout, K = ksize^2 * Cin, NHWC activations
-// (a K-slice of 32 channels of one tap is 128 contiguous bytes per pixel), weights pre-packed at
-// byolo_finalize() as [K/32][Npad][32] so a block's B tile is one contiguous BN*128-byte read.
-// Block = WM x WN wave64 (256 or 512 threads); block tile BM x BN x 32, each wave owns TM x TN tiles of 32x32
-// accumulated in registers; operands staged global -> VGPR -> LDS (row stride 36 floats: the
-// ds_read_b128 fragment reads and the ds_write_b128 staging writes are bank-conflict free),
-// double-buffered so the loads of K-tile t+1 are in flight under the MFMAs of tile t.
-// The K order inside a 32-slice is permuted (lane-half h of MFMA step j consumes k = 8q+4h+j) so
-// that every lane fetches its four A (and B) operands of four MFMA steps with ONE ds_read_b128.
+// conv_kernels.hip -- the convolution work that is NOT the implicit GEMM of conv_igemm.hip: the direct
+// 3-channel stem convolution and the BN-calibration helpers.
 #include <hip/hip_runtime.h>
-#include <type_traits>
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
 
 namespace byk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-static constexpr int BK = 32;
-static constexpr int LDS_LD = 36;        // floats per staged row (32 + 4 pad)
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // Blocks are dispatched round-robin over the 8 XCDs (bid % 8); give each XCD a contiguous
-    // range of logical tiles so neighbouring tiles (same A rows / same weights) share its L2.
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-}
-
-// Scheduling pattern for one MFMA group: after every MFMA place ceil(aux / N_MFMA) auxiliary
-// instructions, in the order global loads -> LDS reads -> LDS writes (LLVM SchedGroupMask: MFMA 0x8,
-// VMEM_READ 0x20, DS_READ 0x100, DS_WRITE 0x200).  Address arithmetic is left to the scheduler.
-template <int N_MFMA, int N_VMEM, int N_DSR, int N_DSW>
-__device__ __forceinline__ void sched_interleave() {
-    constexpr int AUX = N_VMEM + N_DSR + N_DSW;
-    constexpr int PER = (AUX + N_MFMA - 1) / N_MFMA;
-#pragma unroll
-    for (int k = 0; k < N_MFMA; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int q = k * PER + u;
-            if (q < N_VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            else if (q < N_VMEM + N_DSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            else if (q < AUX) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-    }
-}
-
-// One BM x BN output tile (logical tile index -> (tile_m, tile_n)).
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical) {
-    constexpr int NT = 64 * WM * WN;            // threads per block
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_LD = BM * 8 / NT;           // float4 loads per thread per A tile
-    constexpr int B_LD = BN * 8 / NT;           // float4 loads per thread per B tile
-    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile config");
-
-    float* As = smem;                            // [2][BM][LDS_LD]
-    float* Bs = smem + 2 * BM * LDS_LD;          // [2][BN][LDS_LD]
-
-    const int tid = threadIdx.x;
-    const int n_tiles = p.Npad / BN;
-    const int tile_n = logical % n_tiles, tile_m = logical / n_tiles;
-
-    // ---- per-thread A-row bookkeeping (4 rows at BM = 128) ---------------------------------
-    // Each thread stages the same A_LD rows of every K-tile.  Row state = output pixel (sample,
-    // oy, ox); per filter tap a row pointer is derived ONCE (when the tap or the source changes) and
-    // then only advanced by the channel chunk: the K-loop itself carries no im2col arithmetic.
-    // Out-of-image taps (zero padding) and rows past M point at a zero page instead of branching.
-    const int a_q = tid & 7;
-    int a_iy0[A_LD], a_ix0[A_LD], a_s0[A_LD], a_s1[A_LD];
-    const int hw = p.Hout * p.Wout;
-#pragma unroll
-    for (int j = 0; j < A_LD; ++j) {
-        const int m = tile_m * BM + (tid >> 3) + (NT / 8) * j;
-        if (m < p.M) {
-            const int s = m / hw, rem = m - s * hw;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            a_iy0[j] = oy * p.stride - p.pad;
-            a_ix0[j] = ox * p.stride - p.pad;
-            a_s0[j] = s / p.sdiv0;
-            a_s1[j] = s / p.sdiv1;
-        } else {
-            a_iy0[j] = -(1 << 28);              // every tap out of bounds -> zero page
-            a_ix0[j] = 0; a_s0[j] = 0; a_s1[j] = 0;
-        }
-    }
-    const float* a_ptr[A_LD];                    // row pointer of the current (tap, source), + a_q*4
-    const float* w_ptr = p.wpk + (size_t)tile_n * BN * BK + (size_t)tid * 4;   // advanced by Npad*32 per K-tile
-    const size_t w_step = (size_t)p.Npad * BK;
-    int ld_tap = 0, ld_chunk = 0;                // (tap, channel chunk) of the NEXT tile to load
-    int a_cc = 0;                                // channel offset of that tile inside its source
-
-    f32x4 a_reg[A_LD], b_reg[B_LD];
-
-    // block-uniform bookkeeping for the next K-tile: scalar counters, and -- only when the filter tap
-    // or the source changes (once per Cin/32 tiles) -- the A_LD row pointers
-    // 3x3 over one plain source (every 3x3 conv of this network): the 9 tap pointers of a row differ
-    // by a block-uniform delta, so keep the tap-(0,0) offset + a 9-bit validity mask per row and
-    // switch taps with one add + select per row instead of re-deriving the address.
-    const bool fast_taps = p.ksize == 3 && p.C1 == 0 && p.sh0 == 0;
-    long long a_off00[A_LD];
-    unsigned a_mask[A_LD];
-    if (fast_taps) {
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j) {
-            unsigned mk = 0;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int iy = a_iy0[j] + t / 3, ix = a_ix0[j] + t % 3;
-                mk |= ((unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win) ? (1u << t) : 0u;
-            }
-            a_mask[j] = mk;
-            a_off00[j] = (((long long)a_s0[j] * p.Hs0 + a_iy0[j]) * p.Ws0 + a_ix0[j]) * p.C0 + a_q * 4;
-        }
-    }
-    auto next_tile = [&]() {
-        const int cc = ld_chunk * BK;
-        const bool second = cc >= p.C0;
-        if (fast_taps) {
-            if (ld_chunk == 0) {
-                const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
-                const long long delta = ((long long)ky * p.Ws0 + kx) * p.C0;
-#pragma unroll
-                for (int j = 0; j < A_LD; ++j)
-                    a_ptr[j] = ((a_mask[j] >> ld_tap) & 1u) ? p.src0 + (a_off00[j] + delta) : p.zeros + a_q * 4;
-            }
-        } else if (ld_chunk == 0 || cc == p.C0) {
-            const int ky = ld_tap / p.ksize, kx = ld_tap - ky * p.ksize;
-            const float* src = second ? p.src1 : p.src0;
-            const int C = second ? p.C1 : p.C0, Hs = second ? p.Hs1 : p.Hs0, Ws = second ? p.Ws1 : p.Ws0;
-            const int sh = second ? p.sh1 : p.sh0;
-#pragma unroll
-            for (int j = 0; j < A_LD; ++j) {
-                const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-                const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                const int s = second ? a_s1[j] : a_s0[j];
-                const size_t off = (((size_t)s * Hs + (iy >> sh)) * Ws + (ix >> sh)) * C;
-                a_ptr[j] = (ok ? src + off : p.zeros) + a_q * 4;
-            }
-        }
-        a_cc = second ? cc - p.C0 : cc;
-        if (++ld_chunk == p.cin_tiles) { ld_chunk = 0; ++ld_tap; }
-    };
-    auto issue_loads = [&]() {                   // A_LD + B_LD global_load_dwordx4, nothing else
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j) a_reg[j] = *reinterpret_cast<const f32x4*>(a_ptr[j] + a_cc);
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) b_reg[j] = *reinterpret_cast<const f32x4*>(w_ptr + (size_t)j * (NT * 4));
-        w_ptr += w_step;
-    };
-    auto store_a = [&](int buf) {
-        float* a = As + buf * BM * LDS_LD;
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j)
-            *reinterpret_cast<f32x4*>(a + ((tid >> 3) + (NT / 8) * j) * LDS_LD + a_q * 4) = a_reg[j];
-    };
-    auto store_b = [&](int buf) {
-        float* b = Bs + buf * BN * LDS_LD;
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            const int idx = tid + NT * j;
-            *reinterpret_cast<f32x4*>(b + (idx >> 3) * LDS_LD + (idx & 7) * 4) = b_reg[j];
-        }
-    };
-
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lh = lane >> 5;
-    const int a_frag_off = (wm * TM * 32 + li) * LDS_LD + lh * 4;
-    const int b_frag_off = (wn * TN * 32 + li) * LDS_LD + lh * 4;
-
-    auto read_frags = [&](int buf, int kq, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
-        const float* a = As + buf * BM * LDS_LD + a_frag_off + kq * 8;
-        const float* b = Bs + buf * BN * LDS_LD + b_frag_off + kq * 8;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_LD);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_LD);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);   // D^T: rows = channels
-    };
-
-    // ---- software-pipelined K loop ---------------------------------------------------------------
-    // An fp32 MFMA occupies the matrix pipe for 64 cycles; the wave issues in order, so any RUN of
-    // non-MFMA instructions longer than that lets the pipe drain (measured: the bare cluster of 8
-    // global loads + bookkeeping at the top of an iteration cost 8 %).  The loop body is therefore
-    // branch-free (last tile peeled) and every auxiliary instruction is placed BETWEEN two MFMAs with
-    // sched_group_barrier patterns.  Per K-tile, 4 groups of G = 4*TM*TN MFMAs per wave:
-    //   group 0 | global loads of tile t+1, LDS fragment reads of group 1
-    //   group 1 | fragment reads of group 2
-    //   group 2 | fragment reads of group 3, then the LDS writes of tile t+1 (other buffer)
-    //   barrier   (every read of the current buffer is in registers, tile t+1 is visible afterwards)
-    //   group 3 | fragment reads of group 0 of tile t+1  -> barrier + LDS latency hide under group 3
-    constexpr int G = 4 * TM * TN, NFR = TM + TN, NLD = A_LD + B_LD;
-    f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
-    next_tile();
-    issue_loads();
-    store_a(0); store_b(0);
-    __syncthreads();
-    read_frags(0, 0, af0, bf0);
-
-    auto tile_body = [&](const int buf, auto has_next_tag) {
-        constexpr bool HN = decltype(has_next_tag)::value;
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (HN) issue_loads();
-        read_frags(buf, 1, af1, bf1);
-        mfma_group(af0, bf0);
-        sched_interleave<G, HN ? NLD : 0, NFR, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-
-        read_frags(buf, 2, af0, bf0);
-        mfma_group(af1, bf1);
-        sched_interleave<G, 0, NFR, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-
-        read_frags(buf, 3, af1, bf1);
-        if constexpr (HN) { store_a(buf ^ 1); store_b(buf ^ 1); }
-        mfma_group(af0, bf0);
-        sched_interleave<G, 0, NFR, HN ? NLD : 0>();
-        __builtin_amdgcn_sched_barrier(0);
-
-        __syncthreads();
-        if constexpr (HN) read_frags(buf ^ 1, 0, af0, bf0);
-        mfma_group(af1, bf1);
-        sched_interleave<G, 0, HN ? NFR : 0, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // (s_setprio around this loop was measured: no effect, 126.3 vs 127.0 TF/s.)
-    for (int kt = 0; kt + 1 < p.KT; ++kt) {
-        next_tile();
-        tile_body(kt & 1, std::true_type{});
-    }
-    tile_body((p.KT - 1) & 1, std::false_type{});
-
-    // ---- fused epilogue: [dropout mask] * scale, + shift, leaky, [+ residual] ------------------
-    // The MFMAs compute the TRANSPOSED tile (srcA = weights, srcB = pixels), so in the 32x32 C/D map
-    //   col = lane & 31 -> pixel,  row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -> channel
-    // every lane owns, per 32x32 tile, ONE pixel and 4 groups of 4 CONSECUTIVE channels: NHWC stores
-    // (and residual loads) are 16-byte vectors, and there is one row-address computation per tile.
-    if (p.ablate & 16) { if (acc[0][0][0] == 12345.678f) p.dst[0] = 1.f; return; }   // [ablation] no epilogue
-    const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
-    const bool vec_ok = (p.ldc & 3) == 0;
-    const float keep_scale = do_drop ? p.inv_keep : 1.f;
-    // T-invariant de-duplication (lowering in byolo_api.hip):
-    //   rep > 1     the conv ran once per IMAGE (its input does not depend on the MC sample); only the
-    //               dropout mask differs between the T samples, so the epilogue is replayed T times and
-    //               writes the T stacked outputs (row m = img*hw + pix  ->  (img*rep + t)*hw + pix);
-    //   addend      the T-invariant half of a concat input was convolved once per image into `addend`
-    //               (raw accumulators, [B*hw][N]); it joins the accumulator here, before scale / mask.
-    const int rep = p.rep;
-    int row_img[TM], row_pix[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = tile_m * BM + wm * TM * 32 + i * 32 + li;
-        row_img[i] = m / hw;
-        row_pix[i] = m - row_img[i] * hw;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n0 = tile_n * BN + wn * TN * 32 + j * 32 + 8 * g + 4 * lh;     // 4 channels n0 .. n0+3
-            if (n0 >= p.N) continue;
-            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);          // arrays are padded to Npad
-            const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
-            const bool full = vec_ok && n0 + 3 < p.N;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = tile_m * BM + wm * TM * 32 + i * 32 + li;
-                if (m >= p.M) continue;
-                f32x4 a4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
-                if (p.addend) {
-                    const int mu = (row_img[i] / p.addend_T) * hw + row_pix[i];
-                    const float* ad = p.addend + (size_t)mu * p.N + n0;
-                    if (full) a4 += *reinterpret_cast<const f32x4*>(ad);
-                    else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) if (n0 + q < p.N) a4[q] += ad[q];
-                    }
-                }
-                for (int t = 0; t < rep; ++t) {
-                    const int mo = rep > 1 ? (row_img[i] * rep + t) * hw + row_pix[i] : m;
-                    const size_t o = (size_t)mo * p.ldc + n0;
-                    const uint64_t idx0 = (uint64_t)mo * (uint64_t)p.N + (uint64_t)n0;
-                    f32x4 v;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float x = a4[q] * (sc4[q] * keep_scale);
-                        if (do_drop && !byolo_keep(idx0 + q, p.k0, p.k1, p.thr)) x = 0.f;
-                        x += sf4[q];
-                        if (do_leaky) x = fmaxf(x, 0.1f * x);
-                        v[q] = x;
-                    }
-                    if (full) {
-                        if (do_res) v += *reinterpret_cast<const f32x4*>(p.residual + o);
-                        *reinterpret_cast<f32x4*>(p.dst + o) = v;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (n0 + q < p.N) p.dst[o + q] = do_res ? v[q] + p.residual[o + q] : v[q];
-                    }
-                }
-            }
-        }
-    }
-}
-
-// Workgroups walk the tile list with stride gridDim.x: with gridDim.x == #tiles every workgroup owns one
-// tile; with a smaller (persistent) grid a workgroup runs several tiles back to back and skips the
-// per-workgroup launch cost.  Either way the tiles that are in flight on one XCD at a time are neighbours.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int ntiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
-    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) conv_tile<BM, BN, WM, WN>(p, smem, xcd_remap(v, ntiles));
-}
-
-int conv_tile_bn(int tile) { return tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32); }
-
-int conv_pick_tile(int N) {
-    if (N > 64) return TILE_128x128;
-    if (N > 32) return TILE_128x64;
-    return TILE_128x32;
-}
-
-template <int BM, int BN, int WM, int WN>
-static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
-    // BYOLO_LDS_PAD (bytes): tuning knob -- extra dynamic LDS to lower the blocks/CU residency in experiments
-    static const size_t lds_pad = [] { const char* e = getenv("BYOLO_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float) + lds_pad;
-    int grid = ((p.M + BM - 1) / BM) * (p.Npad / BN);
-    // BYOLO_PERSIST = workgroups per CU of a persistent grid (0 = one workgroup per tile)
-    static const int persist = [] { const char* e = getenv("BYOLO_PERSIST"); return e ? atoi(e) : 0; }();
-    if (persist > 0 && grid > 256 * persist) grid = 256 * persist;
-    auto k = conv_igemm_kernel<BM, BN, WM, WN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    static const int ablate = [] { const char* e = getenv("BYOLO_CONV_ABLATE"); return e ? atoi(e) : 0; }();
-    ConvParams q = p; q.ablate = ablate;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, st, q);
-    return hipGetLastError();
-}
-
-hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st) {
-    switch (tile) {
-        case TILE_128x128: {
-            // tuning knob (A/B experiments only; every variant computes the same function)
-            static const int variant = [] { const char* e = getenv("BYOLO_CONV_VARIANT"); return e ? atoi(e) : 0; }();
-            switch (variant) {
-                case 1: return launch_cfg<128, 128, 2, 4>(p, st);     // 8 waves of 64x32
-                case 2: return launch_cfg<128, 128, 4, 2>(p, st);     // 8 waves of 32x64
-                case 3: return launch_cfg<256, 128, 4, 2>(p, st);     // 8 waves of 64x64, 256-row tile
-                default: return launch_cfg<128, 128, 2, 2>(p, st);    // 4 waves of 64x64
-            }
-        }
-        case TILE_128x64:  return launch_cfg<128, 64, 2, 2>(p, st);
-        default:           return launch_cfg<128, 32, 4, 1>(p, st);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Direct convolution for tiny Cin (the 3-channel stem, lib_yolo/darknet.py:10): HBM-bound

@@ -549,16 +549,12 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* boxes, i
         if (tid == 0) {
             int total = 0;
             for (int q = 0; q < 32; ++q) total += part[q];
-            if (level == 0) n_valid = total;                 // nothing filtered yet
-            // smallest digit d with below + #(digit <= d) >= target
-            const int nv = level == 0 ? total : 0;
-            (void)nv;
-            s_cnt = total;
+            s_cnt = total;                                   // level 0: nothing filtered yet = #valid scores
         }
         __syncthreads();
         if (level == 0) n_valid = s_cnt;
         const int target = n_valid < NMS_TOPK ? n_valid : NMS_TOPK;
-        if (tid == 0) {
+        if (tid == 0) {                                      // smallest digit d with below + #(digit <= d) >= target
             int cum = below, q = 0;
             while (q < 31 && cum + part[q] < target) { cum += part[q]; ++q; }
             int d = q * 64;

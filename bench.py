@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch hipEvents in the timed region")
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many concurrent HIP streams")
+    ap.add_argument("--no-dropout", action="store_true",
+                    help="[experiment, not the metric] skip the dropout masks: isolates the epilogue's RNG cost")
     ap.add_argument("--dump-steps", default=None, help="write the per-launch table (layer, variant, M, N, K, ms, TF/s) here")
     args = ap.parse_args()
 
@@ -125,13 +127,13 @@ def main():
             for k, st in enumerate(streams):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
-                    eng.forward(subs[k]["x"], T=T, seed=1000 + i, dropout_on=True, want_boxes=False, want_nms=True,
+                    eng.forward(subs[k]["x"], T=T, seed=1000 + i, dropout_on=not args.no_dropout, want_boxes=False, want_nms=True,
                                 out=subs[k]["out"], slot=k)
             for st in streams:
                 cur.wait_stream(st)
             r = out
         else:
-            r = eng.forward(x, T=T, seed=1000 + i, dropout_on=True, want_boxes=False, want_nms=True, out=out)
+            r = eng.forward(x, T=T, seed=1000 + i, dropout_on=not args.no_dropout, want_boxes=False, want_nms=True, out=out)
         if world > 1:
             return bdist.allgather_boxes(r["rows"], r["kept"], r["count"], world)
         return r["rows"], r["kept"], r["count"]
@@ -174,7 +176,7 @@ def main():
             "metric": "img/s at T=%d MC-dropout, %dx%d" % (T, cfg["H"], cfg["W"]),
             "value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" [EXPERIMENT: dropout off, invalid]" if args.no_dropout else ""),
             "config": {"workload": "BASELINE configs[%d]: %s %dx%d T=%d, %d images/GPU (global batch %d), "
                                    "class-%s NMS max_out=1000, random-init weights with device-calibrated BN"
                                    % (args.config - 1, cfg["variant"], cfg["H"], cfg["W"], T, B, B * world,
