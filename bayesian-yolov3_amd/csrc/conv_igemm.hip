@@ -405,8 +405,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
 // (Measured and dropped: 8-wave 128x128 and 256x128 tiles, one workgroup per CU, a persistent grid, two
 //  streams, s_setprio, and de-phasing the two co-resident workgroups of a CU at launch -- none moved the
 //  number)
+// 2nd launch bound = waves per SIMD: two workgroups per CU (what the LDS allows for the 128x128 tile) must
+// also fit the register file, i.e. VGPRs + AGPRs <= 256 per wave.
 template <int BM, int BN, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ntiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) conv_tile<BM, BN, WM, WN, FAST>(p, smem, xcd_remap(v, ntiles));
