@@ -632,7 +632,7 @@ static int32_t check_run(byolo_t* h, int32_t B, int32_t T, const char* what, boo
         const int64_t S = l.stacked ? (int64_t)B * T : B;
         if (S * l.H * l.W >= (int64_t)1 << 31) return fail(h, BYOLO_ERR_ARG, "%s: B*T*h*w exceeds 2^31 pixels", what);
         // the convolution addresses its sources with 32-bit byte offsets (buffer loads)
-        if ((uint64_t)S * l.H * l.W * l.C * 4 > CONV_MAX_SRC_BYTES)
+        if (l.materialized && (uint64_t)S * l.H * l.W * l.C * 4 > CONV_MAX_SRC_BYTES)
             return fail(h, BYOLO_ERR_ARG, "%s: a [%lld,%d,%d,%d] activation exceeds the 3 GiB a convolution source may span; "
                         "split the call into smaller image batches", what, (long long)S, l.H, l.W, l.C);
     }

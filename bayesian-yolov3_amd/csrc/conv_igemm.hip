@@ -318,7 +318,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     // (and residual loads) are 16-byte vectors.  The row part of every address (dst, residual, addend,
     // dropout element index) is derived once per row; the (j, g) channel-group part is an immediate.
     const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
-    const bool vec_ok = (p.ldc & 3) == 0;
     const float keep_scale = do_drop ? p.inv_keep : 1.f;
     // T-invariant de-duplication (lowering in byolo_api.hip):
     //   rep > 1     the conv ran once per IMAGE (its input does not depend on the MC sample); only the
@@ -338,65 +337,86 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         row_pix[i] = mm - row_img[i] * hw;
         add_row[i] = p.addend ? p.addend + (size_t)(fdiv(row_img[i], p.d_addT) * hw + row_pix[i]) * p.N + nb : nullptr;
     }
-    for (int t = 0; t < rep; ++t) {
-        float* dst_row[TM];
-        const float* res_row[TM];
-        uint64_t idx_row[TM];
+    // VEC: N % 4 == 0 and ldc % 4 == 0 (every convolution but the 3*(5+C)-channel detection heads): a lane's
+    //      4-channel group is entirely inside or entirely outside N, its element index is a multiple of 4,
+    //      so the group is one 16-byte store and its dropout bits are two pair hashes.
+    auto epilogue = [&](auto vec_tag) {
+        constexpr bool VEC = decltype(vec_tag)::value;
+        for (int t = 0; t < rep; ++t) {
+            float* dst_row[TM];
+            const float* res_row[TM];
+            uint64_t idx_row[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const uint32_t mo = rep > 1 ? (row_img[i] * rep + t) * hw + row_pix[i] : row_m[i];
-            dst_row[i] = p.dst + (size_t)mo * p.ldc + nb;
-            res_row[i] = do_res ? p.residual + (size_t)mo * p.ldc + nb : nullptr;
-            idx_row[i] = (uint64_t)mo * (uint64_t)p.N + (uint64_t)nb;
-        }
+            for (int i = 0; i < TM; ++i) {
+                const uint32_t mo = rep > 1 ? (row_img[i] * rep + t) * hw + row_pix[i] : row_m[i];
+                dst_row[i] = p.dst + (size_t)mo * p.ldc + nb;
+                res_row[i] = do_res ? p.residual + (size_t)mo * p.ldc + nb : nullptr;
+                idx_row[i] = (uint64_t)mo * (uint64_t)p.N + (uint64_t)nb;
+            }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dn = j * 32 + 8 * g;                        // channel offset of the group from nb
-                const int n0 = nb + dn;                               // 4 channels n0 .. n0+3
-                if (n0 >= p.N) continue;
-                f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);     // arrays are padded to Npad
-                const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
-                sc4 *= keep_scale;
-                const bool full = vec_ok && n0 + 3 < p.N;
+                for (int g = 0; g < 4; ++g) {
+                    const int dn = j * 32 + 8 * g;                        // channel offset of the group from nb
+                    const int n0 = nb + dn;                               // 4 channels n0 .. n0+3
+                    if (n0 >= p.N) continue;
+                    f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);     // arrays are padded to Npad
+                    const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
+                    sc4 *= keep_scale;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    if (row_m[i] >= (uint32_t)p.M) continue;
-                    f32x4 a4;
+                    for (int i = 0; i < TM; ++i) {
+                        if (row_m[i] >= (uint32_t)p.M) continue;
+                        f32x4 a4;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
-                    if (p.addend) {
-                        const float* ad = add_row[i] + dn;
-                        if (full) a4 += *reinterpret_cast<const f32x4*>(ad);
-                        else {
+                        for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
+                        if (p.addend) {
+                            const float* ad = add_row[i] + dn;
+                            if constexpr (VEC) a4 += *reinterpret_cast<const f32x4*>(ad);
+                            else {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) if (n0 + q < p.N) a4[q] += ad[q];
+                                for (int q = 0; q < 4; ++q) if (n0 + q < p.N) a4[q] += ad[q];
+                            }
                         }
-                    }
-                    const uint64_t idx0 = idx_row[i] + (uint64_t)dn;
-                    f32x4 v;
+                        const uint64_t idx0 = idx_row[i] + (uint64_t)dn;
+                        bool keep[4] = {true, true, true, true};
+                        if (do_drop) {
+                            if constexpr (VEC) {
+                                const uint64_t gp = idx0 >> 1;            // even: gp + 1 never carries
+                                const uint32_t k1h = p.k1 + (uint32_t)(gp >> 32) * 0x9E3779B9u;
+                                const uint32_t h0 = byolo_pair_hash((uint32_t)gp, p.k0, k1h);
+                                const uint32_t h1 = byolo_pair_hash((uint32_t)gp + 1u, p.k0, k1h);
+                                keep[0] = (h0 & 0xFFFFu) < p.thr; keep[1] = (h0 >> 16) < p.thr;
+                                keep[2] = (h1 & 0xFFFFu) < p.thr; keep[3] = (h1 >> 16) < p.thr;
+                            } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float x = a4[q] * sc4[q];
-                        if (do_drop && !byolo_keep(idx0 + q, p.k0, p.k1, p.thr)) x = 0.f;
-                        x += sf4[q];
-                        if (do_leaky) x = fmaxf(x, 0.1f * x);
-                        v[q] = x;
-                    }
-                    float* d = dst_row[i] + dn;
-                    if (full) {
-                        if (do_res) v += *reinterpret_cast<const f32x4*>(res_row[i] + dn);
-                        *reinterpret_cast<f32x4*>(d) = v;
-                    } else {
+                                for (int q = 0; q < 4; ++q) keep[q] = byolo_keep(idx0 + q, p.k0, p.k1, p.thr);
+                            }
+                        }
+                        f32x4 v;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (n0 + q < p.N) d[q] = do_res ? v[q] + res_row[i][dn + q] : v[q];
+                        for (int q = 0; q < 4; ++q) {
+                            float x = a4[q] * sc4[q];
+                            x = keep[q] ? x : 0.f;
+                            x += sf4[q];
+                            if (do_leaky) x = fmaxf(x, 0.1f * x);
+                            v[q] = x;
+                        }
+                        float* d = dst_row[i] + dn;
+                        if constexpr (VEC) {
+                            if (do_res) v += *reinterpret_cast<const f32x4*>(res_row[i] + dn);
+                            *reinterpret_cast<f32x4*>(d) = v;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (n0 + q < p.N) d[q] = do_res ? v[q] + res_row[i][dn + q] : v[q];
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    if (((p.N | p.ldc) & 3) == 0) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 // Workgroups walk the tile list with stride gridDim.x: with gridDim.x == #tiles every workgroup owns one

@@ -7,11 +7,12 @@ function of ``(seed, dropout_layer_ordinal, element_index)`` and implements the 
 bit-exactly here (numpy, uint32 wrap-around arithmetic) and on the device
 (``bayesian-yolov3_amd/csrc/byolo_rng.h``).
 
-  element_index = linear NHWC index into the dropout input tensor [S, h, w, cout]
+  element_index i = linear NHWC index into the dropout input tensor [S, h, w, cout]
                   (S = images*T, sample s = img*T + t), as uint64
   dropout_layer_ordinal = 0..14, order of the dropout calls in one forward
                   (`lib_yolo/yolov3.py:544-548`, `:575-579`, `:606-610`)
-  keep  <=>  hash < floor((1 - drop_prob) * 2^32)
+  h(g)     one lowbias32 round over the pair index g = i >> 1, keyed at both ends (pair_hash)
+  keep(i)  <=>  16-bit half (i & 1) of h(i >> 1)  <  round((1 - drop_prob) * 2^16)
 """
 import numpy as np
 
@@ -21,7 +22,7 @@ _GOLD = np.uint32(0x9E3779B9)
 
 
 def mix32(x):
-    """lowbias32-style avalanche hash on uint32 arrays (wrap-around arithmetic)."""
+    """lowbias32 avalanche hash on uint32 arrays (wrap-around arithmetic); key derivation."""
     x = np.asarray(x, dtype=np.uint32).copy()
     with np.errstate(over="ignore"):
         x ^= x >> np.uint32(16)
@@ -45,9 +46,35 @@ def layer_keys(seed, layer):
 
 
 def keep_threshold(drop_prob):
-    # drop_prob travels through the C-ABI as float32 (byolo_cfg.drop_prob); the threshold is
+    # drop_prob travels through the C-ABI as float32 (byolo_cfg.drop_prob); the 16-bit threshold is
     # computed from that float32 value in double precision (csrc/byolo_rng.h: byolo_layer_keys)
-    return np.uint32(int((1.0 - float(np.float32(drop_prob))) * 4294967296.0))
+    return np.uint32(int((1.0 - float(np.float32(drop_prob))) * 65536.0 + 0.5))
+
+
+def pair_hash(g, k0, k1):
+    """32 mask bits of every pair index in the uint64 array g."""
+    g = np.asarray(g, dtype=np.uint64)
+    lo = (g & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (g >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x = lo + np.uint32(k0)
+        x ^= x >> np.uint32(16)
+        x *= _M1
+        x ^= np.uint32(k1) + hi * _GOLD
+        x ^= x >> np.uint32(15)
+        x *= _M2
+        x ^= x >> np.uint32(15)
+    return x
+
+
+def keep_mask(seed, layer, shape, drop_prob=0.1, offset=0):
+    """Boolean keep-mask for a dropout input of NHWC `shape` (element order = C order)."""
+    n = int(np.prod(shape))
+    idx = np.arange(offset, offset + n, dtype=np.uint64)
+    k0, k1 = layer_keys(seed, layer)
+    h = pair_hash(idx >> np.uint64(1), k0, k1)
+    u = np.where((idx & np.uint64(1)).astype(bool), h >> np.uint32(16), h & np.uint32(0xFFFF))
+    return (u < keep_threshold(drop_prob)).reshape(shape)
 
 
 def keep_mask_torch(seed, layer, shape, drop_prob=0.1, offset=0, chunk=1 << 24):
@@ -59,31 +86,17 @@ def keep_mask_torch(seed, layer, shape, drop_prob=0.1, offset=0, chunk=1 << 24):
     thr = int(keep_threshold(drop_prob))
     M = 0xFFFFFFFF
     out = torch.empty(n, dtype=torch.bool)
-
-    def mix(x):
-        x = x ^ (x >> 16)
-        x = (x * 0x21F0AAAD) & M
-        x = x ^ (x >> 15)
-        x = (x * 0x735A2D97) & M
-        return x ^ (x >> 15)
-
     for lo_i in range(0, n, chunk):
         hi_i = min(n, lo_i + chunk)
         idx = torch.arange(offset + lo_i, offset + hi_i, dtype=torch.int64)
-        lo = idx & M
-        hi = idx >> 32
-        h = mix(mix((lo + k0) & M) ^ ((hi + k1) & M))
-        out[lo_i:hi_i] = h < thr
+        g = idx >> 1
+        x = ((g & M) + k0) & M
+        x = x ^ (x >> 16)
+        x = (x * 0x21F0AAAD) & M
+        x = x ^ ((k1 + ((g >> 32) * 0x9E3779B9)) & M)
+        x = x ^ (x >> 15)
+        x = (x * 0x735A2D97) & M
+        x = x ^ (x >> 15)
+        u = torch.where((idx & 1).bool(), x >> 16, x & 0xFFFF)
+        out[lo_i:hi_i] = u < thr
     return out.reshape(shape)
-
-
-def keep_mask(seed, layer, shape, drop_prob=0.1, offset=0):
-    """Boolean keep-mask for a dropout input of NHWC `shape` (element order = C order)."""
-    n = int(np.prod(shape))
-    idx = np.arange(offset, offset + n, dtype=np.uint64)
-    k0, k1 = layer_keys(seed, layer)
-    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    hi = (idx >> np.uint64(32)).astype(np.uint32)
-    with np.errstate(over="ignore"):
-        h = mix32(mix32(lo + k0) ^ (hi + k1))
-    return (h < keep_threshold(drop_prob)).reshape(shape)
