@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbyolo.so")
+# BYOLO_LIB: load another build of the same library (the timing-ablation builds of csrc/build.py --ablate)
+LIB_PATH = os.environ.get("BYOLO_LIB") or os.path.join(_HERE, "libbyolo.so")
 
 OK, ERR_ARG, ERR_STATE, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4
 DET_STANDARD, DET_ALEATORIC, DET_EPISTEMIC = 0, 1, 2

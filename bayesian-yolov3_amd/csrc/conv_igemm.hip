@@ -44,6 +44,13 @@ static constexpr int RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data forma
 // were written to LDS) instead of the first group of tile t+1: three groups of MFMAs between issue and
 // the LDS write that waits for them instead of two (measured +0.3 %)
 static constexpr bool EARLY_LOADS = true;
+// Timing ablations of the K loop (build.py --ablate N -> libbyolo_ablN.so, loaded with BYOLO_LIB=...; the
+// results are WRONG by construction): 1 no global loads, 2 no LDS staging writes (the loads are still
+// waited for), 4 no barrier, 8 no fragment reads.
+#ifndef BYOLO_CONV_ABLATE
+#define BYOLO_CONV_ABLATE 0
+#endif
+static constexpr int ABL = BYOLO_CONV_ABLATE;
 
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shr; }
 
@@ -191,6 +198,13 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     const int st_off = (a_r * LDS_LD + a_q * 4) * 4;         // A and B staging: row tid/8 (+ NT/8 per j), 16-byte column tid%8
     auto store_tile = [&](auto buf_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
+        if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) asm volatile("" : : "v"(a_reg[j]));
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) asm volatile("" : : "v"(b_reg[j]));
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (BUF * A_BUF + j * JSTEP)) = a_reg[j];
 #pragma unroll
@@ -260,30 +274,31 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         using cur = std::integral_constant<int, BUF>;
         using nxt = std::integral_constant<int, BUF ^ 1>;
         constexpr bool HN = decltype(has_next_tag)::value;
-        constexpr bool LD0 = HN && !EARLY_LOADS, LD3 = decltype(load_tag)::value && EARLY_LOADS;
+        constexpr bool LD0 = HN && !EARLY_LOADS && !(ABL & 1), LD3 = decltype(load_tag)::value && EARLY_LOADS && !(ABL & 1);
+        constexpr bool FR = !(ABL & 8), ST = HN && !(ABL & 2);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LD0) issue_loads();
-        read_frags(cur{}, c1{}, af1, bf1);
+        if constexpr (FR) read_frags(cur{}, c1{}, af1, bf1);
         mfma_group(af0, bf0);
-        sched_interleave<G, LD0 ? NLD : 0, NFR, 0>();
+        sched_interleave<G, LD0 ? NLD : 0, FR ? NFR : 0, 0>();
         __builtin_amdgcn_sched_barrier(0);
 
-        read_frags(cur{}, c2{}, af0, bf0);
+        if constexpr (FR) read_frags(cur{}, c2{}, af0, bf0);
         mfma_group(af1, bf1);
-        sched_interleave<G, 0, NFR, 0>();
+        sched_interleave<G, 0, FR ? NFR : 0, 0>();
         __builtin_amdgcn_sched_barrier(0);
 
-        read_frags(cur{}, c3{}, af1, bf1);
+        if constexpr (FR) read_frags(cur{}, c3{}, af1, bf1);
         if constexpr (HN) store_tile(nxt{});
         mfma_group(af0, bf0);
-        sched_interleave<G, 0, NFR, HN ? NLD : 0>();
+        sched_interleave<G, 0, FR ? NFR : 0, ST ? NLD : 0>();
         __builtin_amdgcn_sched_barrier(0);
 
-        __syncthreads();
+        if constexpr (!(ABL & 4)) __syncthreads();
         if constexpr (LD3) issue_loads();
-        if constexpr (HN) read_frags(nxt{}, c0{}, af0, bf0);
+        if constexpr (HN && FR) read_frags(nxt{}, c0{}, af0, bf0);
         mfma_group(af1, bf1);
-        sched_interleave<G, LD3 ? NLD : 0, HN ? NFR : 0, 0>();
+        sched_interleave<G, LD3 ? NLD : 0, (HN && FR) ? NFR : 0, 0>();
         __builtin_amdgcn_sched_barrier(0);
     };
     using yes = std::true_type;

@@ -196,7 +196,7 @@ def main():
                 traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
             line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
                                 "frac": ach / PEAK_FP32_MFMA, "traffic": traffic,
-                                "kernel": "conv_igemm_kernel<128,128,2,2> (fp32 v_mfma_f32_32x32x2_f32)",
+                                "kernel": "conv_igemm_kernel<128,128,2,2,*> (fp32 v_mfma_f32_32x32x2_f32)",
                                 "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
                                 "all_conv_achieved": tot_f / (tot_ms * 1e-3) / 1e12,
                                 "end_to_end_frac": (imgs / dt) * flops_img / (world * PEAK_FP32_MFMA)}
