@@ -92,7 +92,11 @@ struct Plan {
     int B = -1, T = -1;
     std::vector<int64_t> off;      // per layer tensor offset in bytes (-1: none)
     size_t arena = 0, boxes_off = 0, nms_off = 0, stats_off = 0, total = 0;
+    size_t slab_off = 0, cnt_off = 0, cnt_bytes = 0;   // split-K slabs (shared by all steps), per-step ticket counters
+    std::vector<ConvSplit> split;  // per step
+    std::vector<int> tile;         // per step: tile configuration of the launch
 };
+static constexpr int CNT_PER_STEP = 1024;      // >= resident workgroups of any tile configuration
 
 }  // namespace
 
@@ -566,6 +570,15 @@ static int64_t tensor_bytes(const byolo_t* h, int id, int B, int T) {
     return (int64_t)align_up((size_t)(S * l.H * l.W * l.C) * sizeof(float), 256);
 }
 
+// rows (M) and K-tiles of one launch -- the same arithmetic as fill_conv
+static void step_geometry(const byolo_t* h, const Step& st, int B, int T, int* M, int* KT) {
+    const Layer& l = h->layers[st.layer];
+    const bool per_image = st.mode == STEP_REP || st.mode == STEP_PARTIAL;
+    const int64_t S = (l.stacked && !per_image) ? (int64_t)B * T : B;
+    *M = (int)(S * l.H * l.W);
+    *KT = l.ksize * l.ksize * ((st.c_hi - st.c_lo) / 32);
+}
+
 static void make_plan(byolo_t* h, int B, int T) {
     Plan& p = h->plan;
     if (p.B == B && p.T == T) return;
@@ -611,6 +624,27 @@ static void make_plan(byolo_t* h, int B, int T) {
     size_t o = p.boxes_off + align_up((size_t)B * h->n_boxes * h->row_len * sizeof(float), 256);
     p.nms_off = o; o += align_up(nms_workspace_bytes(B, h->n_boxes), 256);
     p.stats_off = o; o += align_up((size_t)1024 * 2 * h->maxC * sizeof(double) + 2 * h->maxC * sizeof(float), 256);
+    // launch geometry per step: tile configuration and the split-K of the last partial round (shape-only)
+    p.split.assign(h->steps.size(), ConvSplit{0, 0, 0, 1});
+    p.tile.assign(h->steps.size(), 0);
+    size_t slab = 0;
+    for (size_t si = 0; si < h->steps.size(); ++si) {
+        const Step& s = h->steps[si];
+        const Layer& l = h->layers[s.layer];
+        if (l.direct) continue;
+        int M, KT; step_geometry(h, s, B, T, &M, &KT);
+        // Grid fill: a 128x128 tiling of a small-M layer (deep backbone layers at small batch) leaves CUs
+        // idle; the 128x64 tile doubles the block count (the packed weight layout [K/32][Npad][32] does not
+        // depend on BN when N % 128 == 0).
+        int tile = s.tile;
+        if (tile == TILE_128x128 && (l.filters % 128) == 0 && (int64_t)((M + 127) / 128) * (l.filters / 128) < 512) tile = TILE_128x64;
+        p.tile[si] = tile;
+        p.split[si] = conv_plan_split(M, s.Npad, KT, tile);
+        slab = std::max(slab, conv_split_slab_bytes(p.split[si], tile));
+    }
+    p.slab_off = o; o += align_up(slab, 256);
+    p.cnt_bytes = h->steps.size() * CNT_PER_STEP * sizeof(unsigned);
+    p.cnt_off = o; o += align_up(p.cnt_bytes, 256);
     p.total = o;
 }
 
@@ -741,6 +775,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         h->step_tile.assign(h->steps.size(), 0);
     }
     bool backbone_marked = false;
+    HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     for (size_t si = 0; si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
@@ -761,12 +796,13 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
                 p.residual = reinterpret_cast<const float*>(ws + h->plan.off[h->layers[l.fused_residual].ref[0]]);
             }
         }
-        // Grid fill: 256 CUs x 2 resident blocks.  A 128x128 tiling of a small-M layer (deep backbone
-        // layers at small batch) leaves CUs idle; the 128x64 tile doubles the block count (the packed
-        // weight layout [K/32][Npad][32] does not depend on BN when N % 128 == 0).
-        int tile = s.tile;
-        if (!l.direct && tile == TILE_128x128 && (p.N % 128) == 0 &&
-            (int64_t)((p.M + 127) / 128) * (p.N / 128) < 512) tile = TILE_128x64;
+        // tile configuration and split-K of the last partial round: decided per (B, T) in make_plan
+        const int tile = h->plan.tile[si];
+        const ConvSplit& sp = h->plan.split[si];
+        p.full_tiles = sp.full_tiles; p.split_tiles = sp.split_tiles; p.split_blocks = sp.split_blocks; p.ksplit = sp.ksplit;
+        p.slabs = reinterpret_cast<float*>(ws + h->plan.slab_off);
+        p.slab_bytes = (uint32_t)conv_split_slab_bytes(sp, tile);
+        p.counters = reinterpret_cast<unsigned*>(ws + h->plan.cnt_off) + si * CNT_PER_STEP;
         if (per_step) h->step_tile[si] = tile;
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, tile, st));
     }

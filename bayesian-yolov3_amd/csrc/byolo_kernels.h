@@ -55,8 +55,19 @@ struct ConvParams {
     float inv_keep;                   // 1/(1-p) when EPI_DROPOUT
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
     FastDiv d_hw, d_wout, d_sdiv0, d_sdiv1, d_addT;   // Hout*Wout, Wout, sdiv0, sdiv1, addend_T
-    FastDiv d_ntiles;                 // Npad / BN: filled by the launcher for the tile it picked
+    // split-K of the last partial round of tiles (conv_plan_split): blocks [0, full_tiles) compute whole
+    // tiles, the remaining split_tiles tiles are computed by ksplit K-slice blocks each
+    int full_tiles, split_tiles, split_blocks, ksplit;
+    float* slabs;                     // [split_tiles][ksplit][128*BN] raw accumulators
+    uint32_t slab_bytes;
+    unsigned* counters;               // [split_tiles] arrival tickets, zero at launch
+    // filled by the launcher for the tile it picked
+    FastDiv d_ntiles, d_cin, d_ks, d_ksplit;   // Npad / BN, cin_tiles, ksize, ksplit
 };
+
+struct ConvSplit { int full_tiles, split_tiles, split_blocks, ksplit; };
+ConvSplit conv_plan_split(int M, int Npad, int KT, int tile);      // decision (shape-only, deterministic)
+size_t conv_split_slab_bytes(const ConvSplit& sp, int tile);
 
 // tile configuration ids
 enum : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };

@@ -86,8 +86,13 @@ __device__ __forceinline__ void sched_interleave() {
 //       1x1 head conv after the concat de-duplication.  The ksize^2 tap addresses of a row differ by a
 //       block-uniform delta, so a row keeps the tap-(0,0) byte offset + a validity bit per tap, and a tap
 //       switch is one add + select per row.  !FAST re-derives the row offsets per (tap, source).
+// Split-K slices (ConvParams::ksplit > 1, the tiles of the last, partial wave of a launch): the block
+// computes K-tiles [kt_begin, kt_end) of tile `logical`, writes its raw accumulators to slab
+// (slice_tile, slice) and draws a ticket; the block that draws the last ticket of the tile sums the slabs
+// in slice order (deterministic) and runs the epilogue.
 template <int BM, int BN, int WM, int WN, bool FAST>
-__device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical) {
+__device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical, const int kt_begin,
+                                          const int kt_end, const int slice_tile, const int slice) {
     constexpr int NT = 64 * WM * WN;            // threads per block
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_LD = BM * 8 / NT;           // 16-byte loads per thread per A tile
@@ -141,17 +146,20 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     }
 
     // ---- K-tile sequencing: block-uniform, scalar registers ------------------------------------------
-    int ld_chunk = 0, ld_tap = 0, ld_ky = 0, ld_kx = 0;      // (channel chunk, tap) of the NEXT tile to load
+    int ld_tap = (int)fdiv((uint32_t)kt_begin, p.d_cin);     // (channel chunk, tap) of the NEXT tile to load
+    int ld_chunk = kt_begin - ld_tap * p.cin_tiles;
+    int ld_ky = (int)fdiv((uint32_t)ld_tap, p.d_ks), ld_kx = ld_tap - ld_ky * p.ksize;
+    bool ld_first = true;                                   // the first tile sets the row offsets whatever its chunk
     uint32_t a_soff = 0;                                    // byte offset of that tile's channels inside a row
     const float* a_base = p.src0;
     uint32_t a_bytes = p.src0_bytes;
-    uint32_t w_soff = 0;                                    // byte offset of the next weight tile
     const uint32_t w_step = (uint32_t)p.Npad * BK * 4;
+    uint32_t w_soff = (uint32_t)kt_begin * w_step;          // byte offset of the next weight tile
     const uint32_t b_voff = (tile_n * BN * BK + (uint32_t)tid * 4) * 4;
 
     auto next_tile = [&]() {
         if constexpr (FAST) {
-            if (ld_chunk == 0) {
+            if (ld_chunk == 0 || ld_first) {
                 const uint32_t delta = (uint32_t)((ld_ky * p.Ws0 + ld_kx) * p.C0) * 4u;
                 const uint32_t bit = 1u << ld_tap;
 #pragma unroll
@@ -161,7 +169,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         } else {
             const int cc = ld_chunk * BK;
             const bool second = cc >= p.C0;
-            if (ld_chunk == 0 || cc == p.C0) {
+            if (ld_chunk == 0 || cc == p.C0 || ld_first) {
                 const uint32_t C = second ? p.C1 : p.C0, Hs = second ? p.Hs1 : p.Hs0, Ws = second ? p.Ws1 : p.Ws0;
                 const int sh = second ? p.sh1 : p.sh0;
 #pragma unroll
@@ -177,6 +185,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
             }
             a_soff = (uint32_t)(second ? cc - p.C0 : cc) * 4u;
         }
+        ld_first = false;
         if (++ld_chunk == p.cin_tiles) {
             ld_chunk = 0; ++ld_tap;
             if (++ld_kx == p.ksize) { ld_kx = 0; ++ld_ky; }
@@ -260,7 +269,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     using c2 = std::integral_constant<int, 2>;
     using c3 = std::integral_constant<int, 3>;
     f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
-    const int KT = p.KT;
+    const int KT = kt_end - kt_begin;            // K-tiles of this block
     next_tile();
     issue_loads();
     store_tile(c0{});
@@ -324,6 +333,64 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         }
         if (kt + 1 < KT) { next_tile(); tile_body(c0{}, yes{}, no{}); tile_body(c1{}, no{}, no{}); }
         else tile_body(c0{}, no{}, no{});
+    }
+
+    // ---- split-K hand-off (block-uniform): slab write, ticket, ordered reduce by the last arriver ---------
+    // Per-XCD L2s are not coherent with each other and a CU's L1 is not refreshed by other CUs' stores, so
+    // the slabs travel with sc1 (write-through / system-coherent) stores and loads: once a wave's vmcnt has
+    // drained its slab is visible to the whole device, and the reducer's sc1 loads cannot hit a stale line.
+    // No release/acquire fence (an agent-scope release = buffer_wbl2 writes back the whole L2; hundreds of
+    // slice blocks doing that at the end of a launch cost more than the split saved).  Correct for any
+    // placement of a tile's slices on XCDs / CUs.
+    if (slice_tile >= 0) {
+        constexpr uint32_t SLAB_B = BM * BN * 4;     // bytes; lane-linear image: float4 q of thread t at (q * NT + t) * 16
+        constexpr int SC1 = 16;
+        const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.slabs, 0, p.slab_bytes, RSRC_FLAGS);
+        const uint32_t tile_off = (uint32_t)slice_tile * (uint32_t)p.ksplit * SLAB_B;
+        const uint32_t my_off = tile_off + (uint32_t)slice * SLAB_B;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), s_rsrc, tid * 16,
+                                                           my_off + ((i * TN + j) * 4 + g) * (NT * 16), SC1);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // also: every wave is done with the LDS tiles
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(p.counters + slice_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = ticket == (unsigned)p.ksplit - 1u;
+        }
+        __syncthreads();
+        const int last = *flag;
+        __syncthreads();                         // the flag word is LDS the next tile of this block overwrites
+        if (!last) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int sl = 0; sl < p.ksplit; ++sl) {      // slice order: the sum does not depend on arrival order
+            const uint32_t off = tile_off + (uint32_t)sl * SLAB_B;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            s_rsrc, tid * 16, off + ((i * TN + j) * 4 + g) * (NT * 16), SC1));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[i][j][4 * g + q] += v[q];
+                    }
+        }
     }
 
     // ---- fused epilogue: [+ addend] [dropout mask] * scale, + shift, leaky, [+ residual] ---------------
@@ -445,8 +512,24 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
 template <int BM, int BN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int ntiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
-    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) conv_tile<BM, BN, WM, WN, FAST>(p, smem, xcd_remap(v, ntiles));
+    // blocks [0, full_tiles): whole tiles, each XCD a contiguous range of them;
+    // blocks beyond: K slices of the remaining tiles -- slices of one tile on one XCD (block id % 8),
+    // neighbours in dispatch order: id = full_tiles + ((tile_local / 8) * ksplit + slice) * 8 + tile_local % 8
+    const int total = p.full_tiles + p.split_blocks;
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        int logical = xcd_remap(v, p.full_tiles), kb = 0, ke = p.KT, tile_local = -1, slice = 0;
+        if (v >= p.full_tiles) {
+            const uint32_t id = (uint32_t)(v - p.full_tiles), i = id >> 3, x = id & 7u;
+            const uint32_t grp = fdiv(i, p.d_ksplit);
+            slice = (int)(i - grp * (uint32_t)p.ksplit);
+            tile_local = (int)(grp * 8u + x);
+            if (tile_local >= p.split_tiles) continue;
+            logical = p.full_tiles + tile_local;
+            kb = (int)fdiv((uint32_t)slice * (uint32_t)p.KT, p.d_ksplit);
+            ke = (int)fdiv((uint32_t)(slice + 1) * (uint32_t)p.KT, p.d_ksplit);
+        }
+        conv_tile<BM, BN, WM, WN, FAST>(p, smem, logical, kb, ke, tile_local, slice);
+    }
 }
 
 int conv_tile_bn(int tile) { return tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32); }
@@ -471,11 +554,61 @@ static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
     return hipGetLastError();
 }
 
+// workgroups of a tile configuration resident on the chip: LDS-limited (160 KB per CU; 73.7 / 55.3 / 46.1 KB per
+// workgroup), the register bound of __launch_bounds__ allows at least as many
+static int tile_slots(int tile) { return 256 * (tile == TILE_128x32 ? 3 : 2); }
+
+// Tile quantisation: a launch of `tiles` equal tiles on `slots` resident workgroups takes ceil(tiles/slots)
+// rounds although the last one may be nearly empty (5416 tiles on 512 slots: 10.58 -> 11 rounds, 3.8 % of
+// the chip-time idle).  The tiles of that last partial round are therefore cut into `ksplit` K slices so that
+// they fill the chip once more with shorter blocks.  Cost model in tile-times of a whole tile; t_k, t_o from
+// DESIGN.md section 3 (per-K-tile and per-tile overhead), a slice pays the overhead + the hand-off fences.
+ConvSplit conv_plan_split(int M, int Npad, int KT, int tile) {
+    const int BN = conv_tile_bn(tile), slots = tile_slots(tile);
+    const int tiles = ((M + 127) / 128) * (Npad / BN);
+    ConvSplit r; r.full_tiles = tiles; r.split_tiles = 0; r.ksplit = 1; r.split_blocks = 0;
+    // BYOLO_KSPLIT: 0 = never split, n > 1 = always n slices (tests, A/B); read when a handle plans a (B, T)
+    const char* env = getenv("BYOLO_KSPLIT");
+    const int knob = env ? atoi(env) : -1;
+    const int rem = tiles % slots;
+    if (knob == 0 || rem == 0) return r;
+    // microseconds: K-tile and tile overhead of a whole tile, overhead of a slice (prologue, sc1 slab
+    // round trip, ticket; measured on the 19x19 .. 76x76 head shapes and the small backbone launches)
+    const double t_k = 1.8 * BN / 128.0, t_o = 3.3, t_slice = 16.0;
+    const double whole = KT * t_k + t_o;
+    // a round that leaves at most one workgroup per CU runs faster than a full one (a lone workgroup owns
+    // the matrix pipe), IF the dispatcher spreads it -- it does not always: 0.8 / 0.7 are averages
+    // (measured: bimodal 0.58 / 1.0 for the 128x128 tile, always spread for the 128x64 tile)
+    const double base = rem > 256 ? 1.0 : (tile == TILE_128x128 ? 0.8 : 0.62);
+    double best = base; int best_s = 1;
+    if (whole < 60.0 && knob <= 1) return r;     // fixed launch costs dominate: nothing to win
+    for (int s = 2; s <= 8; ++s) {
+        if (KT / s < 8) break;
+        const int blocks = rem * s, rounds = (blocks + slots - 1) / slots, last = blocks - (rounds - 1) * slots;
+        const double frac = ((double)((KT + s - 1) / s) * t_k + t_slice) / whole;
+        const double cost = ((rounds - 1) + (last > 256 ? 1.0 : 0.7)) * frac;
+        if (cost < best - 0.08) { best = cost; best_s = s; }
+    }
+    if (knob > 1) best_s = (KT / knob >= 2) ? knob : 1;
+    if (best_s == 1) return r;
+    r.full_tiles = tiles - rem; r.split_tiles = rem; r.ksplit = best_s;
+    r.split_blocks = ((rem + 7) / 8) * 8 * best_s;
+    return r;
+}
+size_t conv_split_slab_bytes(const ConvSplit& sp, int tile) {
+    return sp.ksplit > 1 ? (size_t)sp.split_tiles * sp.ksplit * 128 * conv_tile_bn(tile) * sizeof(float) : 0;
+}
+
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
-    int grid = ((p.M + BM - 1) / BM) * (p.Npad / BN);
     ConvParams q = p;
     q.d_ntiles = make_fastdiv((uint32_t)(p.Npad / BN));
+    q.d_cin = make_fastdiv((uint32_t)p.cin_tiles);
+    q.d_ks = make_fastdiv((uint32_t)p.ksize);
+    const int tiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
+    if (p.ksplit <= 1 || !p.slabs || !p.counters) { q.full_tiles = tiles; q.split_tiles = 0; q.split_blocks = 0; q.ksplit = 1; }
+    q.d_ksplit = make_fastdiv((uint32_t)q.ksplit);
+    int grid = q.full_tiles + q.split_blocks;
     // BYOLO_PERSIST = workgroups per CU of a persistent grid (0 = one workgroup per tile; tuning knob)
     static const int persist = [] { const char* e = getenv("BYOLO_PERSIST"); return e ? atoi(e) : 0; }();
     if (persist > 0 && grid > 256 * persist) grid = 256 * persist;

@@ -285,6 +285,27 @@ def test_workspace_reuse_matches_keep_all():
     assert torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["kept"], b["kept"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ksplit", [2, 3, 5])
+def test_split_k_slices(ksplit, monkeypatch):
+    """The tiles of a launch's last partial round may be computed by K-slice workgroups (slab hand-off, ordered
+    reduce by the last arriver).  Forced on EVERY launch here (BYOLO_KSPLIT; at these sizes the planner
+    would not split): same rows as the golden fixture, twice the same bits, and within fp32 re-association
+    of the unsplit run."""
+    torch = _torch()
+    v = "bayesian_yolov3_aleatoric"
+    monkeypatch.setenv("BYOLO_KSPLIT", "0")
+    _, ref, _, _ = _run(v, 2, keep_all=False)
+    monkeypatch.setenv("BYOLO_KSPLIT", str(ksplit))
+    _, a, _, _ = _run(v, 2, keep_all=False)
+    _, b, _, _ = _run(v, 2, keep_all=False)
+    assert torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["kept"], b["kept"])      # deterministic
+    g = golden("fwd_bayesian_b2_loop.npz")
+    assert_close(a["boxes"].cpu().numpy(), g["bbox"], "split-K rows vs golden")
+    assert_close(a["boxes"].cpu().numpy(), ref["boxes"].cpu().numpy(), "split-K vs unsplit")
+    assert not torch.equal(a["boxes"], ref["boxes"])        # the slices really ran (summation order differs)
+
+
 def test_full_size_vs_cpu_restatement():
     """BASELINE config 4 geometry (608x608, T=30), one image, against the CPU restatement run on the
     same device-calibrated weights: every pre-NMS row within 1e-4, tail bit-exact on the GPU's rows."""
