@@ -4,11 +4,12 @@ the oracle (CPU restatement + committed golden fixtures) on the same seeded inpu
 Tolerances (BASELINE.json north_star): class ids and kept-box indices bit-exact; box coords /
 scores / sigma within 1e-4 (abs, or relative for |v| > 1)."""
 import os
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import (RTOL, ATOL, golden, golden_params, golden_images, build_model, assert_close)
+from conftest import (REPO, RTOL, ATOL, golden, golden_params, golden_images, build_model, assert_close)
 
 pytestmark = pytest.mark.gpu
 
@@ -304,6 +305,18 @@ def test_split_k_slices(ksplit, monkeypatch):
     assert_close(a["boxes"].cpu().numpy(), g["bbox"], "split-K rows vs golden")
     assert_close(a["boxes"].cpu().numpy(), ref["boxes"].cpu().numpy(), "split-K vs unsplit")
     assert not torch.equal(a["boxes"], ref["boxes"])        # the slices really ran (summation order differs)
+
+
+def test_sources_beyond_2GiB(monkeypatch):
+    """The convolution addresses its sources with 32-bit buffer offsets.  At 608x608, T=30 and 12 images the
+    76x76x256 activation spans 2.13 GB (offsets with the top bit set): every image of the batch must equal
+    its own batch-1 run (dropout off, so that rows do not depend on the batch position)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_big_batch", os.path.join(REPO, "tools", "check_big_batch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["check_big_batch.py", "12"])
+    mod.main()
 
 
 def test_full_size_vs_cpu_restatement():
