@@ -401,6 +401,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     // dropout element index) is derived once per row; the (j, g) channel-group part is an immediate.
     const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
     const float keep_scale = do_drop ? p.inv_keep : 1.f;
+    const float slope = do_leaky ? 0.1f : 1.f;
     // T-invariant de-duplication (lowering in byolo_api.hip):
     //   rep > 1     the conv ran once per IMAGE (its input does not depend on the MC sample); only the
     //               dropout mask differs between the T samples, so the epilogue is replayed T times and
@@ -436,25 +437,39 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                 idx_row[i] = (uint64_t)mo * (uint64_t)p.N + (uint64_t)nb;
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+            for (int i = 0; i < TM; ++i) {
+                if (row_m[i] >= (uint32_t)p.M) continue;
+                // VEC: the row's addend (joins before scale) or residual (joins after the activation) values are
+                // fetched up front, all TN*4 groups in flight at once -- a load + wait per group serialises the
+                // epilogue on memory latency (the staging / fragment registers of the K loop are dead here)
+                f32x4 extra[TN * 4];
+                const float* extra_row = p.addend ? add_row[i] : res_row[i];
+                if constexpr (VEC) {
+                    if (extra_row) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int dn = j * 32 + 8 * g;                        // channel offset of the group from nb
-                    const int n0 = nb + dn;                               // 4 channels n0 .. n0+3
-                    if (n0 >= p.N) continue;
-                    f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);     // arrays are padded to Npad
-                    const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
-                    sc4 *= keep_scale;
+                        for (int k = 0; k < TN * 4; ++k) {
+                            const int dn = (k >> 2) * 32 + 8 * (k & 3);
+                            extra[k] = nb + dn < p.N ? *reinterpret_cast<const f32x4*>(extra_row + dn) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                }
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        if (row_m[i] >= (uint32_t)p.M) continue;
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int dn = j * 32 + 8 * g;                        // channel offset of the group from nb
+                        const int n0 = nb + dn;                               // 4 channels n0 .. n0+3
+                        if (n0 >= p.N) continue;
+                        f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);     // arrays are padded to Npad
+                        const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
+                        sc4 *= keep_scale;
                         f32x4 a4;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
                         if (p.addend) {
-                            const float* ad = add_row[i] + dn;
-                            if constexpr (VEC) a4 += *reinterpret_cast<const f32x4*>(ad);
+                            if constexpr (VEC) a4 += extra[j * 4 + g];
                             else {
+                                const float* ad = add_row[i] + dn;
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) if (n0 + q < p.N) a4[q] += ad[q];
                             }
@@ -480,12 +495,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                             float x = a4[q] * sc4[q];
                             x = keep[q] ? x : 0.f;
                             x += sf4[q];
-                            if (do_leaky) x = fmaxf(x, 0.1f * x);
-                            v[q] = x;
+                            v[q] = fmaxf(x, slope * x);                   // slope = 0.1 (leaky) or 1 (linear)
                         }
                         float* d = dst_row[i] + dn;
                         if constexpr (VEC) {
-                            if (do_res) v += *reinterpret_cast<const f32x4*>(res_row[i] + dn);
+                            if (do_res) v += extra[j * 4 + g];
                             *reinterpret_cast<f32x4*>(d) = v;
                         } else {
 #pragma unroll
