@@ -8,10 +8,59 @@ namespace byk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shr; }
+
 // ---------------------------------------------------------------------------------------------
-// Direct convolution for tiny Cin (the 3-channel stem, lib_yolo/darknet.py:10): HBM-bound
-// (writes 128 B per pixel, reads 12 B), so plain VALU FMAs: thread = (pixel, group of 8 output
-// channels); weights (HWIO, k*k*Cin x cout) broadcast from LDS.
+// The stem (lib_yolo/darknet.py:10): 3x3, 3 -> NOUT channels, no dropout / residual.  Writes 128 B per pixel
+// and reads 12: too little K for the matrix cores (27), so vector FMAs -- thread = one output pixel x ALL
+// NOUT channels: its 27 inputs are loaded once, the 27*NOUT weights and the folded BN scale / shift are
+// wave-uniform (scalar loads, SGPR operands of v_fmac), and each thread stores one full 128-byte line.
+// Same summation order (ky, kx, c) as conv_direct_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int NOUT>
+__global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= (uint32_t)p.M) return;
+    const uint32_t hw = (uint32_t)(p.Hout * p.Wout);
+    const uint32_t s = fdiv(m, p.d_hw), rem = m - s * hw;
+    const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * (uint32_t)p.Wout;
+    const float* img = p.src0 + (size_t)fdiv(s, p.d_sdiv0) * p.Hs0 * p.Ws0 * 3;
+    float x[27];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = (int)oy * p.stride - p.pad + ky, ix = (int)ox * p.stride - p.pad + kx;
+            const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const float* px = img + ((size_t)(ok ? iy : 0) * p.Ws0 + (ok ? ix : 0)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[(ky * 3 + kx) * 3 + c] = ok ? px[c] : 0.f;
+        }
+    const float* __restrict__ w = p.wpk;          // HWIO [27][NOUT]: uniform addresses -> scalar loads
+    float acc[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(x[k], w[k * NOUT + n], acc[n]);
+    const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
+    float* d = p.dst + (size_t)m * p.ldc;
+#pragma unroll
+    for (int n = 0; n < NOUT; n += 4) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float y = acc[n + q] * p.scale[n + q] + p.shift[n + q];
+            v[q] = fmaxf(y, slope * y);
+        }
+        *reinterpret_cast<f32x4*>(d + n) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct convolution for tiny Cin, any shape (fallback of the stem kernel above): thread = (pixel, group
+// of 8 output channels); weights (HWIO, k*k*Cin x cout) broadcast from LDS.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float wl[];    // [K][N]
@@ -69,6 +118,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
 }
 
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st) {
+    if (p.ksize == 3 && p.C0 == 3 && p.C1 == 0 && p.sh0 == 0 && p.N == 32 && (p.flags & ~EPI_LEAKY) == 0 &&
+        (p.ldc & 3) == 0 && p.rep == 1 && !p.addend) {
+        hipLaunchKernelGGL(conv_stem3x3_kernel<32>, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st, p);
+        return hipGetLastError();
+    }
     const int K = p.ksize * p.ksize * p.C0;
     const size_t lds = (size_t)K * p.N * sizeof(float);
     const int64_t total = (int64_t)p.M * (p.N >> 3);
