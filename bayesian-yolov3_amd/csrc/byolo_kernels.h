@@ -8,12 +8,6 @@ namespace byk {
 
 enum : int { EPI_LEAKY = 1, EPI_DROPOUT = 2, EPI_RESIDUAL = 4 };
 
-// One fused convolution  dst = [residual +] leaky( mask * (conv(src) * scale [/keep]) + shift )
-// as an implicit GEMM  M = S*Hout*Wout (pixels), N = cout, K = ksize^2 * (C0 + C1).
-// The input is the channel concat of up to two NHWC sources, each optionally read through a
-// nearest x2 upsample (sh = 1) and/or a T-fold batch tile (sdiv = T): the reference's
-// tf.image.resize_nearest_neighbor / tf.concat(axis=3) / tf.concat([x]*T, axis=0)
-// (lib_yolo/layers.py:578-597) are never materialised.
 // n / d for n < 2^31 as (umulhi(n, mul) + n) >> shr: the kernels divide by launch constants only
 // (h*w, w, T, #column tiles), and a 32-bit integer division costs ~30 vector-ALU instructions that
 // are NOT hidden under the MFMAs (tools/mfma_peak.hip).
@@ -32,6 +26,12 @@ inline FastDiv make_fastdiv(uint32_t d) {
 static constexpr uint32_t CONV_OOB_OFFSET = 0xC0000000u;
 static constexpr uint64_t CONV_MAX_SRC_BYTES = 0xBFF00000ull;
 
+// One fused convolution  dst = [residual +] leaky( mask * (conv(src) * scale [/keep]) + shift )
+// as an implicit GEMM  M = S*Hout*Wout (pixels), N = cout, K = ksize^2 * (C0 + C1).
+// The input is the channel concat of up to two NHWC sources, each optionally read through a
+// nearest x2 upsample (sh = 1) and/or a T-fold batch tile (sdiv = T): the reference's
+// tf.image.resize_nearest_neighbor / tf.concat(axis=3) / tf.concat([x]*T, axis=0)
+// (lib_yolo/layers.py:578-597) are never materialised.
 struct ConvParams {
     const float* src0; const float* src1;
     uint32_t src0_bytes, src1_bytes;  // extent of each source (buffer descriptor range)
