@@ -162,13 +162,40 @@ class Engine:
         if img.device.index != self.device:
             raise ValueError("img is on cuda:%s, engine on cuda:%d" % (img.device.index, self.device))
 
-    def forward(self, img, T=1, seed=0, dropout_on=True, want_boxes=False, want_nms=True, out=None, slot=0):
+    def max_images(self, T=1):
+        """Largest batch one byolo_forward call accepts at this T (32-bit source offsets: every activation < 3 GiB)."""
+        n = ctypes.c_int32()
+        check(self._h, lib.byolo_max_images(self._h, int(T), ctypes.byref(n)))
+        return int(n.value)
+
+    def forward(self, img, T=1, seed=0, dropout_on=True, want_boxes=False, want_nms=True, out=None, slot=0, first_image=0):
         """One sess.run of the reference (inference_epistemic.py:76).  Returns a dict of device
         tensors: rows [B,cap,D], kept [B,cap] int32, count [B,2] int32 and (want_boxes) boxes [B,N,D].
-        Everything is enqueued on torch's current stream; no host synchronisation."""
+        Everything is enqueued on torch's current stream; no host synchronisation.
+
+        first_image: position of img[0] in the logical batch (a shard of a data-parallel batch, a sub-batch): the
+        dropout masks are those the unsplit batch would draw.  Batches beyond max_images(T) are run as
+        consecutive sub-batches with exactly that mechanism, so the result does not depend on the split."""
         torch = _torch()
         self._check_img(img)
         B = int(img.shape[0])
+        cap_b = self.max_images(T)
+        if B > cap_b:
+            N, D = self.num_boxes()
+            res = dict(out) if out is not None else {}
+            if want_boxes and res.get("boxes") is None:
+                res["boxes"] = torch.empty((B, N, D), dtype=torch.float32, device=img.device)
+            if want_nms and res.get("rows") is None:
+                res["rows"] = torch.empty((B, self.out_cap, D), dtype=torch.float32, device=img.device)
+                res["kept"] = torch.empty((B, self.out_cap), dtype=torch.int32, device=img.device)
+                res["count"] = torch.empty((B, 2), dtype=torch.int32, device=img.device)
+            for lo in range(0, B, cap_b):
+                hi = min(B, lo + cap_b)
+                sub = {k: v[lo:hi] for k, v in res.items() if v is not None}
+                self.forward(img[lo:hi], T=T, seed=seed, dropout_on=dropout_on, want_boxes=want_boxes, want_nms=want_nms,
+                             out=sub, slot=slot, first_image=first_image + lo)
+            return dict(boxes=res.get("boxes"), rows=res.get("rows"), kept=res.get("kept"), count=res.get("count"))
+        check(self._h, lib.byolo_set_first_image(self._h, int(first_image)))
         ws = self._workspace(B, T, slot)
         N, D = self.num_boxes()
         dev = img.device

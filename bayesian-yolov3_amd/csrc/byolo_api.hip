@@ -121,6 +121,7 @@ struct byolo {
     int64_t n_boxes = 0; int row_len = 0, obj_idx = 0, cls_start = 0;
     Plan plan;
     void* last_ws = nullptr;
+    int64_t first_image = 0;       // position of a call's first image in the logical batch (dropout stream)
     int profiling = 0;             // 0 off, 1 stage events, 2 + one event per conv launch
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -789,6 +790,8 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
             if (l.drop_ordinal >= 0 && dropout_on) {
                 const byolo_drop_keys k = byolo_layer_keys(seed, (uint32_t)l.drop_ordinal, (double)h->cfg.drop_prob);
                 p.flags |= EPI_DROPOUT; p.k0 = k.k0; p.k1 = k.k1; p.thr = k.thr;
+                // element index of this call's first output element in the logical batch's [S,h,w,c] tensor
+                p.idx_base = (uint64_t)h->first_image * (uint64_t)(l.stacked ? T : 1) * l.H * l.W * l.filters;
                 p.inv_keep = 1.0f / (1.0f - h->cfg.drop_prob);
             }
             if (l.fused_residual >= 0) {
@@ -922,6 +925,29 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
 extern "C" int32_t byolo_set_profiling(byolo_t* h, int32_t on) {
     if (!h) return BYOLO_ERR_ARG;
     h->profiling = on < 0 ? 0 : (on > 2 ? 2 : on); h->ev_valid = false; h->step_valid = false;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_set_first_image(byolo_t* h, int64_t first_image) {
+    if (!h) return BYOLO_ERR_ARG;
+    if (first_image < 0) return fail(h, BYOLO_ERR_ARG, "byolo_set_first_image: negative index");
+    h->first_image = first_image;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images) {
+    if (!h || !max_images) return BYOLO_ERR_ARG;
+    if (T < 1) return fail(h, BYOLO_ERR_ARG, "byolo_max_images: T must be >= 1");
+    if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
+    uint64_t per_image = (uint64_t)h->cfg.img_h * h->cfg.img_w * h->cfg.img_c * 4;      // bytes per image of the largest tensor
+    int64_t rows = 0;                                                                  // pixels per image of the largest layer
+    for (const auto& l : h->layers) {
+        const uint64_t s = l.stacked ? (uint64_t)T : 1;
+        if (l.materialized) per_image = std::max(per_image, s * l.H * l.W * l.C * 4);
+        rows = std::max<int64_t>(rows, (int64_t)s * l.H * l.W);
+    }
+    const uint64_t by_bytes = CONV_MAX_SRC_BYTES / per_image, by_rows = (((uint64_t)1 << 31) - 1) / (uint64_t)rows;
+    *max_images = (int32_t)std::min<uint64_t>(std::min(by_bytes, by_rows), 1 << 20);
     return BYOLO_OK;
 }
 

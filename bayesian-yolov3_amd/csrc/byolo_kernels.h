@@ -54,6 +54,7 @@ struct ConvParams {
     int flags;                        // EPI_*
     float inv_keep;                   // 1/(1-p) when EPI_DROPOUT
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
+    uint64_t idx_base;                // dropout element index of dst[0] (sub-batch / shard of a logical batch)
     FastDiv d_hw, d_wout, d_sdiv0, d_sdiv1, d_addT;   // Hout*Wout, Wout, sdiv0, sdiv1, addend_T
     // split-K of the last partial round of tiles (conv_plan_split): blocks [0, full_tiles) compute whole
     // tiles, the remaining split_tiles tiles are computed by ksplit K-slice blocks each

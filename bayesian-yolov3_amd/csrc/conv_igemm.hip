@@ -434,7 +434,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                 const uint32_t mo = rep > 1 ? (row_img[i] * rep + t) * hw + row_pix[i] : row_m[i];
                 dst_row[i] = p.dst + (size_t)mo * p.ldc + nb;
                 res_row[i] = do_res ? p.residual + (size_t)mo * p.ldc + nb : nullptr;
-                idx_row[i] = (uint64_t)mo * (uint64_t)p.N + (uint64_t)nb;
+                idx_row[i] = p.idx_base + (uint64_t)mo * (uint64_t)p.N + (uint64_t)nb;
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {

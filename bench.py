@@ -128,12 +128,15 @@ def main():
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     eng.forward(subs[k]["x"], T=T, seed=1000 + i, dropout_on=not args.no_dropout, want_boxes=False, want_nms=True,
-                                out=subs[k]["out"], slot=k)
+                                out=subs[k]["out"], slot=k, first_image=rank * B + k * Bs)
             for st in streams:
                 cur.wait_stream(st)
             r = out
         else:
-            r = eng.forward(x, T=T, seed=1000 + i, dropout_on=not args.no_dropout, want_boxes=False, want_nms=True, out=out)
+            # rank r holds images [r*B, (r+1)*B) of the global batch and draws THEIR dropout masks: the N-GPU job
+            # computes what one GPU would compute on the whole batch
+            r = eng.forward(x, T=T, seed=1000 + i, dropout_on=not args.no_dropout, want_boxes=False, want_nms=True, out=out,
+                            first_image=rank * B)
         if world > 1:
             return bdist.allgather_boxes(r["rows"], r["kept"], r["count"], world)
         return r["rows"], r["kept"], r["count"]

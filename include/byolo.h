@@ -117,6 +117,14 @@ BYOLO_API int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t
 BYOLO_API int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
                       void* d_workspace, size_t workspace_bytes,
                       float* d_boxes, float* d_rows, int32_t* d_kept, int32_t* d_count, void* stream);
+/* The dropout stream is indexed by the element index in the [S,h,w,c] tensor, S = images*T.  When one logical
+ * batch is processed in several calls (sub-batches that respect byolo_max_images, or one shard per GPU), tell
+ * every call where its first image sits in the logical batch: image j of the call then draws the masks of image
+ * first_image + j, and the pieces equal the unsplit run.  Sticky per handle; 0 after byolo_create. */
+BYOLO_API int32_t byolo_set_first_image(byolo_t* h, int64_t first_image);
+/* Largest B byolo_forward accepts at this T: the convolutions address their sources with 32-bit byte offsets,
+ * so every activation tensor [B*T or B, h, w, c] must stay below 3 GiB (16 images at 608x608, T=30). */
+BYOLO_API int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images);
 /* After a forward with keep_all_outputs: device pointer + NHWC shape of layer `idx`'s output
  * (the reference's model.layers[idx], model.py:191); for detection layers the raw conv output
  * (DetLayer.raw_output, model.py:241). */

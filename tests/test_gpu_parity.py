@@ -307,6 +307,24 @@ def test_split_k_slices(ksplit, monkeypatch):
     assert not torch.equal(a["boxes"], ref["boxes"])        # the slices really ran (summation order differs)
 
 
+def test_first_image_makes_shards_equal_the_whole_batch():
+    """byolo_set_first_image: image j of a shard / sub-batch draws the dropout masks of image first_image + j of the
+    logical batch, so pieces equal the unsplit run (fp32 re-association aside: tile and split-K choices depend on
+    the batch size).  Without the offset the shard's masks are those of images 0.. and the rows differ."""
+    torch = _torch()
+    v = "bayesian_yolov3_aleatoric"
+    imgs = golden_images(2)
+    m, whole, _, _ = _run(v, 2, keep_all=False, imgs=np.concatenate([imgs, imgs[::-1]]))        # 4 images
+    x = torch.from_numpy(np.concatenate([imgs, imgs[::-1]])).cuda()
+    part = m.engine.forward(x[2:4], T=m.T, seed=42, want_boxes=True, first_image=2)
+    assert_close(part["boxes"].cpu().numpy(), whole["boxes"][2:4].cpu().numpy(), "shard with first_image=2")
+    for b in range(2):
+        assert set(part["kept"][b].tolist()) == set(whole["kept"][2 + b].tolist())
+    plain = m.engine.forward(x[2:4], T=m.T, seed=42, want_boxes=True)
+    assert not np.allclose(plain["boxes"].cpu().numpy(), whole["boxes"][2:4].cpu().numpy(), rtol=1e-3, atol=1e-3, equal_nan=True)
+    assert m.engine.max_images(m.T) > 1000            # 64x96: far from the 3 GiB bound
+
+
 def test_sources_beyond_2GiB(monkeypatch):
     """The convolution addresses its sources with 32-bit buffer offsets.  At 608x608, T=30 and 12 images the
     76x76x256 activation spans 2.13 GB (offsets with the top bit set): every image of the batch must equal

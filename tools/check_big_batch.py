@@ -3,6 +3,8 @@
 with the top bit set) and compare every image with its own batch-1 run.
 
     python tools/check_big_batch.py [B]        (default 12: the 76x76x256 activation is 2.13 GB)
+
+Beyond Engine.max_images(T) (17 at this geometry) Engine.forward runs consecutive sub-batches; B = 20 checks that.
 """
 import os
 import sys
@@ -28,6 +30,7 @@ def main():
     imgs = synth.synthetic_images(B, 608, 608, seed=1234)
     x = torch.from_numpy(imgs).cuda()
     eng.calibrate_bn(x[:2])
+    print("max images per call at T=30: %d" % eng.max_images(30))
     # dropout off: an image's rows then do not depend on its position in the batch
     big = eng.forward(x, T=30, seed=42, dropout_on=False, want_boxes=True)["boxes"].cpu().numpy()
     worst = 0.0
