@@ -307,6 +307,23 @@ def test_split_k_slices(ksplit, monkeypatch):
     assert not torch.equal(a["boxes"], ref["boxes"])        # the slices really ran (summation order differs)
 
 
+@pytest.mark.parametrize("ksplit", ["0", "3"])
+def test_without_dedup_two_source_loader(ksplit, monkeypatch):
+    """BYOLO_NO_DEDUP=1 lowers the graph as written: the convs after the concats read TWO sources (the stacked
+    route and the T-tiled, upsampled backbone output) through the general loader, conv #75 runs per MC sample.
+    Same rows as the golden fixture and as the de-duplicated lowering; also with K slices that start inside the
+    second source."""
+    v = "bayesian_yolov3_aleatoric"
+    monkeypatch.setenv("BYOLO_KSPLIT", ksplit)
+    _, dd, _, _ = _run(v, 2, keep_all=False)
+    monkeypatch.setenv("BYOLO_NO_DEDUP", "1")
+    m, nd, _, _ = _run(v, 2, keep_all=False)
+    assert m.engine.flops(2, 3) > 0
+    g = golden("fwd_bayesian_b2_loop.npz")
+    assert_close(nd["boxes"].cpu().numpy(), g["bbox"], "no-dedup rows vs golden")
+    assert_close(nd["boxes"].cpu().numpy(), dd["boxes"].cpu().numpy(), "no-dedup vs dedup")
+
+
 def test_first_image_makes_shards_equal_the_whole_batch():
     """byolo_set_first_image: image j of a shard / sub-batch draws the dropout masks of image first_image + j of the
     logical batch, so pieces equal the unsplit run (fp32 re-association aside: tile and split-K choices depend on
