@@ -40,10 +40,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int BK = 32;
 static constexpr int LDS_LD = 36;            // floats per staged row (32 + 4 pad)
 static constexpr int RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family)
-// the loads of K-tile t+2 are issued in the last MFMA group of tile t (right after the staging registers
-// were written to LDS) instead of the first group of tile t+1: three groups of MFMAs between issue and
-// the LDS write that waits for them instead of two (measured +0.3 %)
-static constexpr bool EARLY_LOADS = true;
 // Timing ablations of the K loop (build.py --ablate N -> libbyolo_ablN.so, loaded with BYOLO_LIB=...; the
 // results are WRONG by construction): 1 no global loads, 2 no LDS staging writes (the loads are still
 // waited for), 4 no barrier, 8 no fragment reads.
@@ -261,7 +257,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     //   group 1 | fragment reads of group 2
     //   group 2 | fragment reads of group 3, then the LDS writes of tile t+1 (other buffer)
     //   barrier   (every read of the current buffer is in registers, tile t+1 is visible afterwards)
-    //   group 3 | buffer loads of tile t+2 into the staging registers just freed,
+    //   group 3 | buffer loads of tile t+2 into the staging registers just freed (three MFMA groups before the
+    //           | LDS write that waits for them; issuing them in group 0 of tile t+1 measured -0.3 %),
     //           | fragment reads of group 0 of tile t+1  -> barrier + LDS latency hide under group 3
     constexpr int G = 4 * TM * TN, NFR = TM + TN, NLD = A_LD + B_LD;
     using c0 = std::integral_constant<int, 0>;
@@ -273,7 +270,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     next_tile();
     issue_loads();
     store_tile(c0{});
-    if constexpr (EARLY_LOADS) { if (KT > 1) { next_tile(); issue_loads(); } }
+    if (KT > 1) { next_tile(); issue_loads(); }   // tile 1 waits in the staging registers
     __syncthreads();
     read_frags(c0{}, c0{}, af0, bf0);
 
@@ -283,13 +280,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         using cur = std::integral_constant<int, BUF>;
         using nxt = std::integral_constant<int, BUF ^ 1>;
         constexpr bool HN = decltype(has_next_tag)::value;
-        constexpr bool LD0 = HN && !EARLY_LOADS && !(ABL & 1), LD3 = decltype(load_tag)::value && EARLY_LOADS && !(ABL & 1);
+        constexpr bool LD3 = decltype(load_tag)::value && !(ABL & 1);
         constexpr bool FR = !(ABL & 8), ST = HN && !(ABL & 2);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (LD0) issue_loads();
         if constexpr (FR) read_frags(cur{}, c1{}, af1, bf1);
         mfma_group(af0, bf0);
-        sched_interleave<G, LD0 ? NLD : 0, FR ? NFR : 0, 0>();
+        sched_interleave<G, 0, FR ? NFR : 0, 0>();
         __builtin_amdgcn_sched_barrier(0);
 
         if constexpr (FR) read_frags(cur{}, c2{}, af0, bf0);
@@ -314,26 +310,17 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     using no = std::false_type;
     // (s_setprio around this loop was measured: no effect.)
     int kt = 0;
-    if constexpr (EARLY_LOADS) {
-        for (; kt + 3 < KT; kt += 2) {                  // tiles kt, kt+1: both stage t+1 and fetch t+2
-            next_tile(); tile_body(c0{}, yes{}, yes{});
-            next_tile(); tile_body(c1{}, yes{}, yes{});
-        }
-        auto tail = [&](auto buf_tag, const int t) {      // the last 1..3 tiles (block-uniform branches)
-            if (t >= KT) return;
-            if (t + 2 < KT) { next_tile(); tile_body(buf_tag, yes{}, yes{}); }
-            else if (t + 1 < KT) tile_body(buf_tag, yes{}, no{});
-            else tile_body(buf_tag, no{}, no{});
-        };
-        tail(c0{}, kt); tail(c1{}, kt + 1); tail(c0{}, kt + 2);
-    } else {
-        for (; kt + 2 < KT; kt += 2) {
-            next_tile(); tile_body(c0{}, yes{}, no{});
-            next_tile(); tile_body(c1{}, yes{}, no{});
-        }
-        if (kt + 1 < KT) { next_tile(); tile_body(c0{}, yes{}, no{}); tile_body(c1{}, no{}, no{}); }
-        else tile_body(c0{}, no{}, no{});
+    for (; kt + 3 < KT; kt += 2) {                      // tiles kt, kt+1: both stage t+1 and fetch t+2
+        next_tile(); tile_body(c0{}, yes{}, yes{});
+        next_tile(); tile_body(c1{}, yes{}, yes{});
     }
+    auto tail = [&](auto buf_tag, const int t) {          // the last 1..3 tiles (block-uniform branches)
+        if (t >= KT) return;
+        if (t + 2 < KT) { next_tile(); tile_body(buf_tag, yes{}, yes{}); }
+        else if (t + 1 < KT) tile_body(buf_tag, yes{}, no{});
+        else tile_body(buf_tag, no{}, no{});
+    };
+    tail(c0{}, kt); tail(c1{}, kt + 1); tail(c0{}, kt + 2);
 
     // ---- split-K hand-off (block-uniform): slab write, ticket, ordered reduce by the last arriver ---------
     // Per-XCD L2s are not coherent with each other and a CU's L1 is not refreshed by other CUs' stores, so
