@@ -215,31 +215,34 @@ def test_nms_fast_path_and_fallbacks(case):
         assert res["count"].cpu().numpy().tolist() == [[100, 100], [0, 0]] or int(res["count"][1, 0]) == 0
 
 
+@pytest.mark.parametrize("cls_cnt", [2, 1, 3, 80])
 @pytest.mark.parametrize("kind,variant", [(0, "yolov3"), (1, "yolov3_aleatoric"), (2, "bayesian_yolov3_aleatoric")])
-def test_decode_stage(kind, variant):
-    """Staged decode on oracle-provided raw logits incl. saturated ones (NaN entropies, App. D.2)."""
+def test_decode_stage(kind, variant, cls_cnt):
+    """Staged decode on oracle-provided raw logits incl. saturated ones (NaN entropies, App. D.2), for the class
+    counts the decode kernels are instantiated for (ECP: 2; also 1, 3 and COCO's 80)."""
     torch = _torch()
     from byolo import Engine
     from oracle import cpu_ref
     g = np.random.default_rng(17)
+    C = cls_cnt
     B, T, lh, lw = 2, (5 if kind == 2 else 1), 5, 7
-    F = 21 if kind == 0 else 42
+    F = 3 * (5 + C) * (1 if kind == 0 else 2)
     raw = (g.standard_normal((B * T, lh, lw, F)) * 2.0).astype(np.float32)
     raw[0, 0, 0, :] = 120.0       # saturate: sigmoid -> 1, softmax ties, exp -> inf
     raw[-1, 1, 2, :] = -120.0
     pri = cpu_ref.ECP_9_PRIORS_HW[3:6]
-    D = cpu_ref.row_layout(variant, 2)[0]
-    eng = Engine((64, 64, 3), 2)
+    D = cpu_ref.row_layout(variant, C)[0]
+    eng = Engine((64, 64, 3), C)
     boxes = torch.zeros((B, 3 * lh * lw, D), device="cuda")
     eng.decode(kind, torch.from_numpy(raw).cuda(), B, T, pri, 1, boxes, 0)
     torch.cuda.synchronize()
     rt = torch.from_numpy(raw)
     if kind == 0:
-        ref = cpu_ref.concat_bbox([cpu_ref.decode_standard(rt, pri, 2)], True)
+        ref = cpu_ref.concat_bbox([cpu_ref.decode_standard(rt, pri, C)], True)
     elif kind == 1:
-        ref = cpu_ref.concat_bbox([cpu_ref.decode_aleatoric(rt, pri, 2, 1)], True)
+        ref = cpu_ref.concat_bbox([cpu_ref.decode_aleatoric(rt, pri, C, 1)], True)
     else:
-        ref = torch.stack([cpu_ref.concat_bbox([cpu_ref.decode_epistemic(rt[b * T:(b + 1) * T], pri, 2, 1)], False)
+        ref = torch.stack([cpu_ref.concat_bbox([cpu_ref.decode_epistemic(rt[b * T:(b + 1) * T], pri, C, 1)], False)
                            for b in range(B)])
     got = boxes.cpu().numpy()
     ref = ref.numpy()
