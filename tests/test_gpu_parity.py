@@ -82,6 +82,29 @@ def test_forward_vs_cpu_restatement(variant):
     assert_close(out["boxes"].cpu().numpy(), ref_boxes.numpy(), "%s pre-NMS rows" % variant)
 
 
+@pytest.mark.parametrize("variant,cls_cnt,H,W,B,T", [("yolov3", 80, 96, 64, 3, 1), ("yolov3_aleatoric", 3, 96, 64, 3, 1),
+                                                     ("bayesian_yolov3_aleatoric", 3, 96, 64, 3, 2),
+                                                     ("bayesian_yolov3_aleatoric", 1, 32, 160, 1, 7)])
+def test_other_shapes_vs_cpu_restatement(variant, cls_cnt, H, W, B, T):
+    """Away from the fixtures' geometry: other class counts (detection heads of 255 / 48 / 36 channels), portrait
+    and very wide images (1x5 coarsest grid), odd batch, T = 1 / 2 / 7 -- device-calibrated weights read back through
+    byolo_get_param, whole forward against the CPU restatement, tail against the oracle NMS."""
+    torch = _torch()
+    from byolo import synth
+    from oracle import cpu_ref
+    m = build_model(variant, H, W, T=T, cls_cnt=cls_cnt)[1]
+    eng = m.engine
+    eng.set_params(synth.base_params(eng.param_shapes(), variant, cls_cnt, seed=11))
+    eng.finalize()
+    eng.calibrate_bn(torch.from_numpy(synth.synthetic_images(8, H, W, seed=5)).cuda())
+    imgs = synth.synthetic_images(B, H, W, seed=77)
+    out = eng.forward(torch.from_numpy(imgs).cuda(), T=T, seed=3, want_boxes=True)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(eng.get_params()), imgs, variant, T=T, seed=3, cls_cnt=cls_cnt)
+    assert_close(out["boxes"].cpu().numpy(), ref.numpy(), "%s C=%d %dx%d rows" % (variant, cls_cnt, H, W))
+
+
 def test_batched_epistemic_equals_batch1_loop():
     """the reference asserts batch 1 in epistemic mode; the build's batched
     generalisation must equal a loop of batch-1 reference runs (fixture 7)."""
