@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch hipEvents in the timed region")
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many concurrent HIP streams")
+    ap.add_argument("--pipeline", type=int, default=1, help="[experiment] alternate whole steps over this many HIP streams")
     ap.add_argument("--no-dropout", action="store_true",
                     help="[experiment, not the metric] skip the dropout masks: isolates the epilogue's RNG cost")
     ap.add_argument("--dump-steps", default=None, help="write the per-launch table (layer, variant, M, N, K, ms, TF/s) here")
@@ -119,7 +120,21 @@ def main():
     Bs = B // nstreams
     subs = [dict(x=x[k * Bs:(k + 1) * Bs], out={n: t[k * Bs:(k + 1) * Bs] for n, t in out.items()}) for k in range(nstreams)]
 
+    # --pipeline P: whole steps alternate over P streams (own workspace slot and output buffers each), so the
+    # latency-bound tail of step i (decode, NMS) and its launch ramps overlap the convolutions of step i+1
+    npipe = max(1, args.pipeline)
+    pipes = [dict(st=torch.cuda.Stream(device=x.device), out={n: torch.empty_like(t) for n, t in out.items()})
+             for _ in range(npipe)] if npipe > 1 else []
+
     def step(i):
+        if npipe > 1:
+            pp = pipes[i % npipe]
+            with torch.cuda.stream(pp["st"]):
+                r = eng.forward(x, T=T, seed=1000 + i, dropout_on=not args.no_dropout, want_boxes=False, want_nms=True,
+                                out=pp["out"], slot=1 + i % npipe, first_image=rank * B)
+                if world > 1:
+                    return bdist.allgather_boxes(r["rows"], r["kept"], r["count"], world)
+            return r["rows"], r["kept"], r["count"]
         if nstreams > 1:
             # the batch as `nstreams` independent sub-batches on separate HIP streams: one sub-batch's
             # kernel tails / launch gaps are filled by the other's kernels (images are independent)
@@ -141,7 +156,7 @@ def main():
             return bdist.allgather_boxes(r["rows"], r["kept"], r["count"], world)
         return r["rows"], r["kept"], r["count"]
 
-    prof = not args.no_profile and nstreams == 1     # the handle's event set belongs to one forward at a time
+    prof = not args.no_profile and nstreams == 1 and npipe == 1    # the handle's event set belongs to one forward at a time
     for i in range(args.warmup):
         step(i)
     eng.set_profiling(2 if prof else 0)
