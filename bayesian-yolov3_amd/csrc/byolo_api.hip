@@ -85,16 +85,22 @@ struct Step {
     int out_tensor = -1;           // tensor id written (layer index, or n_layers + aux index)
     int addend_tensor = -1;        // STEP_MAIN: the PARTIAL result
     size_t w_off = 0; int Npad = 0, tile = 0;   // packed weights of this launch
+    bool wino_ok = false;          // 3x3 / stride 1 over one plain source: Winograd F(2x2,3x3) is possible
+    size_t wino_off = 0;           // the 16 transformed weight matrices U[xi], each packed [Cin/32][Npad][32]
 };
+// per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
+struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; };
 struct AuxTensor { int H, W, C; };
 
 struct Plan {
     int B = -1, T = -1;
     std::vector<int64_t> off;      // per layer tensor offset in bytes (-1: none)
     size_t arena = 0, boxes_off = 0, nms_off = 0, stats_off = 0, total = 0;
-    size_t slab_off = 0, cnt_off = 0, cnt_bytes = 0;   // split-K slabs (shared by all steps), per-step ticket counters
+    size_t slab_off = 0, slab_bytes = 0, cnt_off = 0, cnt_bytes = 0;   // split-K slabs (shared by all steps), per-step ticket counters
     std::vector<ConvSplit> split;  // per step
     std::vector<int> tile;         // per step: tile configuration of the launch
+    std::vector<WinoPlan> wino;    // per step
+    size_t wino_off = 0;           // scratch for V and M of one chunk (shared by all steps)
 };
 static constexpr int CNT_PER_STEP = 1024;      // >= resident workgroups of any tile configuration
 
@@ -125,9 +131,11 @@ struct byolo {
     int profiling = 0;             // 0 off, 1 stage events, 2 + one event per conv launch
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
-    std::vector<hipEvent_t> step_ev;   // steps + 1 events (level 2)
-    std::vector<int64_t> step_M;       // M of each launch in the last forward
-    std::vector<int> step_tile;        // tile variant it was launched with
+    // level 2: one entry per kernel launch of the convolution stack in the last forward (a Winograd layer
+    // contributes input transform / GEMM / output transform per chunk); event k is recorded before launch k
+    struct Launch { int layer, variant; int64_t m, n, k; double algo_flops; };
+    std::vector<Launch> launches;
+    std::vector<hipEvent_t> step_ev;   // pool, launches.size() + 1 in use
     bool step_valid = false;
 };
 
@@ -516,6 +524,9 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
             st.w_off = off; off += align_up((size_t)K * st.Npad, 64);
         }
         l.tile = st.tile; l.Npad = st.Npad;
+        st.wino_ok = !l.direct && l.op == OP_CONV && l.ksize == 3 && l.stride == 1 && st.mode == STEP_NORMAL &&
+                     st.in.n == 1 && st.in.s[0].sh == 0 && !st.in.s[0].tile && (l.Cin % 32) == 0 && (N % 4) == 0;
+        if (st.wino_ok) { st.wino_off = off; off += align_up((size_t)16 * Cs * st.Npad, 64); }
         if (st.mode == STEP_PARTIAL) continue;                  // raw accumulators: no scale / shift
         l.scale_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);   // readable (zeros) up to Npad
         l.shift_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
@@ -535,6 +546,18 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
                     const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
                     float* d = dst + ((size_t)kt * st.Npad) * 32 + kk;
                     for (int nn = 0; nn < N; ++nn) d[(size_t)nn * 32] = wr[nn];
+                }
+        }
+        if (st.wino_ok) {                                       // U[xi][c][n] = (G g G^T)[xi], each xi packed like a 1x1 conv
+            float* u = blob.data() + st.wino_off;
+            const size_t xi_stride = (size_t)(Cs / 32) * st.Npad * 32;
+            float g9[9], u16[16];
+            for (int c = 0; c < Cs; ++c)
+                for (int nn = 0; nn < N; ++nn) {
+                    for (int tap = 0; tap < 9; ++tap) g9[tap] = w[((size_t)tap * l.Cin + c) * N + nn];
+                    wino_weight_transform(g9, u16);
+                    float* d = u + ((size_t)(c >> 5) * st.Npad + nn) * 32 + (c & 31);
+                    for (int xi = 0; xi < 16; ++xi) d[(size_t)xi * xi_stride] = u16[xi];
                 }
         }
         if (st.mode == STEP_PARTIAL) continue;
@@ -643,7 +666,42 @@ static void make_plan(byolo_t* h, int B, int T) {
         p.split[si] = conv_plan_split(M, s.Npad, KT, tile);
         slab = std::max(slab, conv_split_slab_bytes(p.split[si], tile));
     }
-    p.slab_off = o; o += align_up(slab, 256);
+    // Winograd F(2x2,3x3) for the large 3x3 / stride-1 convolutions (winograd.hip): samples per chunk such that
+    // the transformed input V (4x the input) and the GEMM result M (4x the output) of a chunk fit the scratch.
+    // BYOLO_WINOGRAD=0 keeps every convolution direct.
+    p.wino.assign(h->steps.size(), WinoPlan{});
+    size_t wino_scratch = 0;
+    { const char* e = getenv("BYOLO_WINOGRAD");
+      const int on = e ? atoi(e) : 1;
+      const double min_flops = on >= 2 ? 0.0 : 1e11, budget = 2.6e9;      // 2: every eligible layer (tests)
+      for (size_t si = 0; on && si < h->steps.size(); ++si) {
+        const Step& s = h->steps[si];
+        const Layer& l = h->layers[s.layer];
+        if (!s.wino_ok) continue;
+        int M, KT; step_geometry(h, s, B, T, &M, &KT);
+        if (2.0 * M * l.filters * 9.0 * l.Cin < min_flops) continue;
+        // The transforms stream 4x the input + 4x the output through HBM (measured 5.2 TB/s); per output pixel the GEMM
+        // saves 5/9 of 2*9*Cin*cout FLOPs.  That pays when Cin*cout/(Cin+cout) is large: measured at config 4
+        // 512x1024 channels (19x19) -33 %, 256x512 (38x38) -24 %, 128x256 (76x76) +6 % -> direct below ~128.
+        if (on < 2 && (double)l.Cin * l.filters / (l.Cin + l.filters) < 128.0) continue;
+        WinoPlan& w = p.wino[si];
+        w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2;
+        const int S = M / (l.H * l.W);
+        const double per_sample = 16.0 * w.th * w.tw * (l.Cin + l.filters) * 4.0;
+        const int nchunks = (int)std::ceil(S * per_sample / budget);                 // equal chunks
+        w.chunk = (S + nchunks - 1) / nchunks;
+        const size_t P_pad = align_up((size_t)w.chunk * w.th * w.tw, 128);
+        w.v_bytes = align_up((size_t)16 * P_pad * l.Cin * 4, 256);
+        w.m_bytes = align_up((size_t)16 * P_pad * l.filters * 4, 256);
+        wino_scratch = std::max(wino_scratch, w.v_bytes + w.m_bytes);
+        const int rows = (int)(16 * P_pad);
+        p.split[si] = conv_plan_split(rows, s.Npad, l.Cin / 32, s.tile);
+        p.tile[si] = s.tile;
+        slab = std::max(slab, conv_split_slab_bytes(p.split[si], s.tile));
+      }
+    }
+    p.wino_off = o; o += align_up(wino_scratch, 256);
+    p.slab_off = o; p.slab_bytes = slab; o += align_up(slab, 256);
     p.cnt_bytes = h->steps.size() * CNT_PER_STEP * sizeof(unsigned);
     p.cnt_off = o; o += align_up(p.cnt_bytes, 256);
     p.total = o;
@@ -734,6 +792,68 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.d_addT = make_fastdiv((uint32_t)p.addend_T);
 }
 
+// profiling level 2: event + bookkeeping entry before a launch of the convolution stack
+static int32_t mark_launch(byolo_t* h, int layer, int variant, int64_t m, int64_t n, int64_t k, double algo, hipStream_t st) {
+    while (h->step_ev.size() < h->launches.size() + 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->step_ev.push_back(e); }
+    HIPCHK(h, hipEventRecord(h->step_ev[h->launches.size()], st));
+    h->launches.push_back({layer, variant, m, n, k, algo});
+    return BYOLO_OK;
+}
+
+// One 3x3 / stride-1 convolution as Winograd F(2x2,3x3): per chunk of samples, input transform -> ONE batched GEMM
+// launch of the implicit-GEMM kernel (16 row blocks, one weight matrix each, raw accumulators out) -> output
+// transform with the convolution's own epilogue.  `c` is the ConvParams of the direct launch (sources, dst, epilogue).
+static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const ConvParams& c, const WinoPlan& wp, int tile,
+                            double algo_flops, char* ws, hipStream_t st) {
+    const bool prof = h->profiling >= 2;
+    int32_t rc;
+    const int S = c.M / (l.H * l.W), tt = wp.th * wp.tw;
+    float* V = reinterpret_cast<float*>(ws + h->plan.wino_off);
+    float* Mb = reinterpret_cast<float*>(ws + h->plan.wino_off + wp.v_bytes);
+    for (int s0 = 0; s0 < S; s0 += wp.chunk) {
+        const int ns = std::min(wp.chunk, S - s0);
+        WinoParams w; memset(&w, 0, sizeof w);
+        w.x = c.src0; w.v = V; w.m = Mb; w.y = c.dst;
+        w.residual = (c.flags & EPI_RESIDUAL) ? c.residual : nullptr;
+        w.scale = c.scale; w.shift = c.shift;
+        w.H = l.H; w.W = l.W; w.C = c.C0; w.N = c.N; w.th = wp.th; w.tw = wp.tw;
+        w.s0 = s0; w.P = ns * tt; w.P_pad = (int)align_up((size_t)w.P, 128);
+        w.flags = c.flags; w.inv_keep = c.inv_keep; w.k0 = c.k0; w.k1 = c.k1; w.thr = c.thr; w.idx_base = c.idx_base;
+        w.d_tt = make_fastdiv((uint32_t)tt); w.d_tw = make_fastdiv((uint32_t)wp.tw);
+        w.d_c4 = make_fastdiv((uint32_t)(c.C0 / 4)); w.d_n4 = make_fastdiv((uint32_t)(c.N / 4));
+        // variants of the profile entries: -2 input transform, BN of the GEMM tile, -3 output transform; the GEMM
+        // entry carries the direct-convolution FLOPs its samples stand for, its m/n/k are the executed extents
+        if (prof && (rc = mark_launch(h, s.layer, -2, w.P, c.C0, 0, 0.0, st))) return rc;
+        HIPCHK(h, launch_wino_input(w, st));
+
+        const int rows = 16 * w.P_pad;
+        ConvParams g; memset(&g, 0, sizeof g);                  // a 1x1 convolution over a 1 x rows "image" of C0 channels
+        g.src0 = V; g.src1 = V; g.C0 = c.C0; g.C1 = 0;
+        g.src0_bytes = g.src1_bytes = (uint32_t)((uint64_t)rows * c.C0 * 4);
+        g.Hs0 = g.Hs1 = 1; g.Ws0 = g.Ws1 = rows; g.sdiv0 = g.sdiv1 = 1;
+        g.Hin = 1; g.Win = rows; g.Hout = 1; g.Wout = rows; g.ksize = 1; g.stride = 1; g.pad = 0;
+        g.M = rows; g.N = c.N; g.Npad = c.Npad; g.ldc = c.N; g.cin_tiles = c.C0 / 32; g.KT = g.cin_tiles;
+        g.wpk = dptr(h, s.wino_off);
+        g.wino_rows = (uint32_t)w.P_pad; g.d_wino = make_fastdiv((uint32_t)w.P_pad);
+        g.wino_wstride = (uint32_t)((size_t)g.cin_tiles * c.Npad * 32 * 4);
+        g.w_bytes = 16u * g.wino_wstride;
+        g.scale = h->d_ones; g.shift = h->d_zeros; g.flags = 0; g.inv_keep = 1.f; g.rep = 1; g.addend_T = 1;
+        g.dst = Mb;
+        g.d_hw = make_fastdiv((uint32_t)rows); g.d_wout = make_fastdiv((uint32_t)rows);
+        g.d_sdiv0 = g.d_sdiv1 = g.d_addT = make_fastdiv(1u);
+        const ConvSplit sp = conv_plan_split(rows, c.Npad, g.KT, tile);
+        if (conv_split_slab_bytes(sp, tile) <= h->plan.slab_bytes) {
+            g.full_tiles = sp.full_tiles; g.split_tiles = sp.split_tiles; g.split_blocks = sp.split_blocks; g.ksplit = sp.ksplit;
+            g.slabs = c.slabs; g.slab_bytes = (uint32_t)conv_split_slab_bytes(sp, tile); g.counters = c.counters;
+        }
+        if (prof && (rc = mark_launch(h, s.layer, conv_tile_bn(tile), rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
+        HIPCHK(h, launch_conv_igemm(g, tile, st));
+        if (prof && (rc = mark_launch(h, s.layer, -3, w.P, c.N, 0, 0.0, st))) return rc;
+        HIPCHK(h, launch_wino_output(w, st));
+    }
+    return BYOLO_OK;
+}
+
 static int32_t run_decode(byolo_t* h, char* ws, float* boxes, int B, int T, hipStream_t st) {
     for (const auto& l : h->layers) {
         if (l.op != OP_DETECTION) continue;
@@ -770,11 +890,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         HIPCHK(h, hipEventRecord(h->ev[0], st));
     }
     const bool per_step = h->profiling >= 2;
-    if (per_step) {
-        while (h->step_ev.size() < h->steps.size() + 1) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->step_ev.push_back(e); }
-        h->step_M.assign(h->steps.size(), 0);
-        h->step_tile.assign(h->steps.size(), 0);
-    }
+    if (per_step) { h->launches.clear(); h->step_valid = false; }
     bool backbone_marked = false;
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     for (size_t si = 0; si < h->steps.size(); ++si) {
@@ -784,7 +900,6 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
             HIPCHK(h, hipEventRecord(h->ev[1], st)); backbone_marked = true;
         }
         ConvParams p; fill_conv(h, s, d_img, ws, B, T, p);
-        if (per_step) { HIPCHK(h, hipEventRecord(h->step_ev[si], st)); h->step_M[si] = p.M; }
         if (l.op == OP_CONV && s.mode != STEP_PARTIAL) {
             p.flags = EPI_LEAKY;
             if (l.drop_ordinal >= 0 && dropout_on) {
@@ -806,10 +921,18 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         p.slabs = reinterpret_cast<float*>(ws + h->plan.slab_off);
         p.slab_bytes = (uint32_t)conv_split_slab_bytes(sp, tile);
         p.counters = reinterpret_cast<unsigned*>(ws + h->plan.cnt_off) + si * CNT_PER_STEP;
-        if (per_step) h->step_tile[si] = tile;
+        // ALGORITHMIC FLOPs the step stands for (graph as written): the whole layer on all MC
+        // samples for a de-duplicated launch, nothing for the auxiliary partial launch
+        const int64_t S_all = l.stacked ? (int64_t)B * T : B;
+        const double algo = s.mode == STEP_PARTIAL ? 0.0 : 2.0 * (double)(S_all * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);
+        if (h->plan.wino[si].chunk > 0) { rc = run_winograd(h, s, l, p, h->plan.wino[si], tile, algo, ws, st); if (rc) return rc; continue; }
+        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st); if (rc) return rc; }
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, tile, st));
     }
-    if (per_step) { HIPCHK(h, hipEventRecord(h->step_ev[h->steps.size()], st)); h->step_valid = true; }
+    if (per_step) {
+        while (h->step_ev.size() < h->launches.size() + 1) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->step_ev.push_back(e); }
+        HIPCHK(h, hipEventRecord(h->step_ev[h->launches.size()], st)); h->step_valid = true;
+    }
     if (h->profiling) { if (!backbone_marked) HIPCHK(h, hipEventRecord(h->ev[1], st)); HIPCHK(h, hipEventRecord(h->ev[2], st)); }
     float* boxes = d_boxes ? d_boxes : reinterpret_cast<float*>(ws + h->plan.boxes_off);
     if (d_boxes || d_rows) { rc = run_decode(h, ws, boxes, B, T, st); if (rc) return rc; }
@@ -953,27 +1076,20 @@ extern "C" int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images) 
 
 extern "C" int32_t byolo_num_steps(const byolo_t* h) {
     if (!h) return BYOLO_ERR_ARG;
-    if (!h->lowered) return fail(const_cast<byolo_t*>(h), BYOLO_ERR_STATE, "byolo_num_steps: graph not lowered yet");
-    return (int32_t)h->steps.size();
+    if (!h->step_valid) return fail(const_cast<byolo_t*>(h), BYOLO_ERR_STATE, "byolo_num_steps: no forward with profiling level 2");
+    return (int32_t)h->launches.size();
 }
 
 extern "C" int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms,
                                       double* algo_flops) {
-    if (!h || i < 0 || i >= (int)h->steps.size()) return fail(h, BYOLO_ERR_ARG, "byolo_step_profile: bad index");
+    if (!h) return BYOLO_ERR_ARG;
     if (!h->step_valid) return fail(h, BYOLO_ERR_STATE, "byolo_step_profile: no forward with profiling level 2");
-    const Step& s = h->steps[i];
-    const Layer& l = h->layers[s.layer];
-    if (layer) *layer = s.layer;
-    if (variant) *variant = l.direct ? -1 : conv_tile_bn(h->step_tile[i]);
-    // EXECUTED GEMM extents of this launch
-    if (mnk) { mnk[0] = h->step_M[i]; mnk[1] = l.filters; mnk[2] = (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo); }
-    // ALGORITHMIC FLOPs it stands for (graph as written): the whole layer on all MC
-    // samples for a de-duplicated launch, nothing for the auxiliary partial launch
-    if (algo_flops) {
-        const int64_t S = l.stacked ? (int64_t)h->plan.B * h->plan.T : h->plan.B;
-        *algo_flops = s.mode == STEP_PARTIAL ? 0.0
-                    : 2.0 * (double)(S * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);
-    }
+    if (i < 0 || i >= (int)h->launches.size()) return fail(h, BYOLO_ERR_ARG, "byolo_step_profile: bad index");
+    const byolo::Launch& e = h->launches[i];
+    if (layer) *layer = e.layer;
+    if (variant) *variant = e.variant;
+    if (mnk) { mnk[0] = e.m; mnk[1] = e.n; mnk[2] = e.k; }       // EXECUTED extents of this launch
+    if (algo_flops) *algo_flops = e.algo_flops;
     if (ms) {
         HIPCHK(h, hipSetDevice(h->device));
         HIPCHK(h, hipEventSynchronize(h->step_ev[i + 1]));

@@ -62,9 +62,29 @@ struct ConvParams {
     float* slabs;                     // [split_tiles][ksplit][128*BN] raw accumulators
     uint32_t slab_bytes;
     unsigned* counters;               // [split_tiles] arrival tickets, zero at launch
+    // Winograd-domain batched GEMM (winograd.hip): the rows are 16 blocks of wino_rows (a multiple of 128) rows, block
+    // xi multiplies with the weight matrix at wpk + xi * wino_wstride bytes; 0 = ordinary convolution
+    uint32_t wino_rows, wino_wstride;
+    FastDiv d_wino;
     // filled by the launcher for the tile it picked
     FastDiv d_ntiles, d_cin, d_ks, d_ksplit;   // Npad / BN, cin_tiles, ksize, ksplit
 };
+
+// Winograd F(2x2, 3x3) transforms around the GEMM (winograd.hip)
+struct WinoParams {
+    const float* x; float* v;         // input [S,H,W,C];  V [16][P_pad][C] (this chunk)
+    const float* m; float* y;         // M [16][P_pad][N] (this chunk);  output [S,H,W,N]
+    const float* residual;            // [S,H,W,N] or null
+    const float* scale; const float* shift;
+    int H, W, C, N, th, tw;           // th, tw = ceil(H/2), ceil(W/2) output tiles per image
+    int s0;                           // first sample of the chunk
+    int P, P_pad;                     // tiles of the chunk (samples * th * tw), rounded up to 128
+    int flags; float inv_keep; uint32_t k0, k1, thr; uint64_t idx_base;
+    FastDiv d_tt, d_tw, d_c4, d_n4;   // th*tw, tw, C/4, N/4
+};
+hipError_t launch_wino_input(const WinoParams& p, hipStream_t st);
+hipError_t launch_wino_output(const WinoParams& p, hipStream_t st);
+void wino_weight_transform(const float g[9], float u[16]);   // host: U = G g G^T
 
 struct ConvSplit { int full_tiles, split_tiles, split_blocks, ksplit; };
 ConvSplit conv_plan_split(int M, int Npad, int KT, int tile);      // decision (shape-only, deterministic)

@@ -151,6 +151,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     uint32_t a_bytes = p.src0_bytes;
     const uint32_t w_step = (uint32_t)p.Npad * BK * 4;
     uint32_t w_soff = (uint32_t)kt_begin * w_step;          // byte offset of the next weight tile
+    if (p.wino_rows) w_soff += fdiv(tile_m * BM, p.d_wino) * p.wino_wstride;   // Winograd: row block xi has its own matrix
     const uint32_t b_voff = (tile_n * BN * BK + (uint32_t)tid * 4) * 4;
 
     auto next_tile = [&]() {
@@ -352,7 +353,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         int* flag = reinterpret_cast<int*>(smem);
         if (tid == 0) {
             const unsigned ticket = __hip_atomic_fetch_add(p.counters + slice_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = ticket == (unsigned)p.ksplit - 1u;
+            const bool is_last = ticket == (unsigned)p.ksplit - 1u;
+            *flag = is_last;
+            // leave the counter at zero for the next launch that uses it (several launches of one step share them)
+            if (is_last) __hip_atomic_store(p.counters + slice_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         const int last = *flag;

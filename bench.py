@@ -172,8 +172,8 @@ def main():
         if prof:
             # reading the events waits for this step only; the timed region stays back-to-back
             for j, s in enumerate(eng.step_profile()):
-                a = acc.setdefault(s["variant"], [0.0, 0.0, 0])
-                a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1
+                a = acc.setdefault(s["variant"], [0.0, 0.0, 0, 0.0])
+                a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1; a[3] += s["flops_executed"]
                 if args.dump_steps:
                     per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / args.steps
             for k, v in eng.stage_ms().items():
@@ -203,9 +203,13 @@ def main():
                        "gflop_per_image": flops_img / 1e9},
         }
         if prof and 128 in acc:
-            f, ms, n = acc[128]
+            # dominant kernel: EXECUTED matrix-pipe FLOPs of its launches / their time.  For the direct convolutions
+            # that is the algorithmic 2*M*N*K; a Winograd-domain GEMM launch executes 1/2.25 of the direct-convolution
+            # FLOPs it stands for (x tile padding), and its transforms are separate, HBM-bound launches.
+            f, ms, n, fx = acc[128]
             tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for a in acc.values())
-            ach = f / (ms * 1e-3)
+            ach = fx / (ms * 1e-3)
+            wino_ms = sum(acc[v][1] for v in (-2, -3) if v in acc)
             # HBM/fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
             # over this same command (tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent
             traffic = None
@@ -216,7 +220,10 @@ def main():
                                 "frac": ach / PEAK_FP32_MFMA, "traffic": traffic,
                                 "kernel": "conv_igemm_kernel<128,128,2,2,*> (fp32 v_mfma_f32_32x32x2_f32)",
                                 "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
-                                "all_conv_achieved": tot_f / (tot_ms * 1e-3) / 1e12,
+                                "share_of_conv_time": ms / tot_ms, "winograd_transform_share_of_conv_time": wino_ms / tot_ms,
+                                # algorithmic (direct-convolution) FLOPs of the whole conv stack / its time, transforms
+                                # included: exceeds what the matrix pipe executes where Winograd F(2x2,3x3) is used
+                                "all_conv_algorithmic": tot_f / (tot_ms * 1e-3) / 1e12,
                                 "end_to_end_frac": (imgs / dt) * flops_img / (world * PEAK_FP32_MFMA)}
             line["stage_ms_per_step"] = {k: v / args.steps for k, v in stage.items()}
         if world == 1 and not args.no_cpu_baseline:
@@ -228,11 +235,12 @@ def main():
         print(json.dumps(line))
         if args.dump_steps and per_launch:
             with open(args.dump_steps, "w") as f:
-                f.write("| # | layer | variant | M | N | K | ms | TF/s |\n|---|---|---|---|---|---|---|---|\n")
+                f.write("| # | layer | variant | M | N | K | ms | executed TF/s | algorithmic TF/s |\n|---|---|---|---|---|---|---|---|---|\n")
                 for j in sorted(per_launch):
                     s = per_launch[j]
-                    f.write("| %d | %d | %d | %d | %d | %d | %.4f | %.1f |\n" % (j, s["layer"], s["variant"], s["M"], s["N"], s["K"],
-                                                                               s["ms"], s["flops"] / (s["ms"] * 1e-3) / 1e12))
+                    f.write("| %d | %d | %d | %d | %d | %d | %.4f | %.1f | %.1f |\n" % (
+                        j, s["layer"], s["variant"], s["M"], s["N"], s["K"], s["ms"],
+                        s["flops_executed"] / (s["ms"] * 1e-3) / 1e12, s["flops"] / (s["ms"] * 1e-3) / 1e12))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

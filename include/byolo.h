@@ -156,12 +156,14 @@ BYOLO_API int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B, 
  * enable with byolo_set_profiling(h, 1).  stage: 0 backbone, 1 heads, 2 decode, 3 sort+nms. */
 BYOLO_API int32_t byolo_set_profiling(byolo_t* h, int32_t on);   /* 0 off, 1 per stage, 2 + per conv launch */
 BYOLO_API int32_t byolo_stage_ms(byolo_t* h, float ms[4]);
-/* per conv launch of the LAST forward (profiling level 2): graph layer, kernel variant
- * (BN of the implicit-GEMM tile: 128 / 64 / 32, or -1 for the direct small-Cin kernel), the GEMM
- * EXECUTED extents {M, N, K}, the launch's device time and the ALGORITHMIC FLOPs it stands for (2*M*N*K of
- * the layer as written; differs from the executed work only for the T-invariant de-duplicated launches:
- * conv once per image + T masked epilogues, and the per-image partial sum of a concat's tiled half, which
- * carries 0).  byolo_num_steps = launches per forward. */
+/* per kernel launch of the convolution stack in the LAST forward (profiling level 2): graph layer, kernel
+ * variant (BN of the implicit-GEMM tile: 128 / 64 / 32; -1 the direct small-Cin kernels; -2 / -3 the Winograd
+ * input / output transforms), the EXECUTED extents {M, N, K} (for a Winograd-domain GEMM: 16 * tiles rows,
+ * cout, cin), the launch's device time and the ALGORITHMIC FLOPs it stands for (2*M*N*K of the layer as
+ * written; differs from the executed work for the T-invariant de-duplicated launches -- conv once per image +
+ * T masked epilogues; the per-image partial sum of a concat's tiled half carries 0 -- and for Winograd, where
+ * the GEMM launch carries the direct-convolution FLOPs of its samples and the transforms carry 0).
+ * byolo_num_steps = launches of the last profiled forward. */
 BYOLO_API int32_t byolo_num_steps(const byolo_t* h);
 BYOLO_API int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms,
                                      double* algo_flops);

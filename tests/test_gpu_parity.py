@@ -350,6 +350,27 @@ def test_without_dedup_two_source_loader(ksplit, monkeypatch):
     assert_close(nd["boxes"].cpu().numpy(), dd["boxes"].cpu().numpy(), "no-dedup vs dedup")
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_winograd_on_every_eligible_layer(variant, monkeypatch):
+    """The large 3x3 / stride-1 convolutions run as Winograd F(2x2,3x3) (input transform, one batched GEMM launch of
+    the implicit-GEMM kernel, output transform + epilogue).  BYOLO_WINOGRAD=2 forces it on EVERY eligible layer
+    (the planner would pick it only for the big head convolutions): odd spatial sizes (3x3 ... 12x... grids pad to
+    2x2 tiles), residual layers, dropout.  Same rows as the fixtures of the reference's graph, same tolerance, and
+    close to the direct path."""
+    B = 1 if variant.startswith("bayes") else 2
+    monkeypatch.setenv("BYOLO_WINOGRAD", "0")
+    _, direct, _, _ = _run(variant, B, keep_all=False)
+    monkeypatch.setenv("BYOLO_WINOGRAD", "2")
+    m, wino, _, _ = _run(variant, B)
+    g = golden("fwd_%s.npz" % variant)
+    for i in TAPS:
+        assert_close(_sub(i, m.engine.layer_output(i).cpu().numpy()), g["layer_%d" % i], "%s layer %d (winograd)" % (variant, i))
+    gb = g["bbox"] if g["bbox"].ndim == 3 else g["bbox"][None]
+    assert_close(wino["boxes"].cpu().numpy(), gb, "%s pre-NMS rows (winograd)" % variant)
+    assert_close(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy(), "%s winograd vs direct" % variant)
+    assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
+
+
 def test_first_image_makes_shards_equal_the_whole_batch():
     """byolo_set_first_image: image j of a shard / sub-batch draws the dropout masks of image first_image + j of the
     logical batch, so pieces equal the unsplit run (fp32 re-association aside: tile and split-K choices depend on
