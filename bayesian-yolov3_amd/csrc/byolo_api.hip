@@ -837,7 +837,7 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
         g.wino_rows = (uint32_t)w.P_pad; g.d_wino = make_fastdiv((uint32_t)w.P_pad);
         g.wino_wstride = (uint32_t)((size_t)g.cin_tiles * c.Npad * 32 * 4);
         g.w_bytes = 16u * g.wino_wstride;
-        g.scale = h->d_ones; g.shift = h->d_zeros; g.flags = 0; g.inv_keep = 1.f; g.rep = 1; g.addend_T = 1;
+        g.scale = h->d_ones; g.shift = h->d_zeros; g.flags = EPI_RAW; g.inv_keep = 1.f; g.rep = 1; g.addend_T = 1;
         g.dst = Mb;
         g.d_hw = make_fastdiv((uint32_t)rows); g.d_wout = make_fastdiv((uint32_t)rows);
         g.d_sdiv0 = g.d_sdiv1 = g.d_addT = make_fastdiv(1u);
@@ -914,6 +914,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
                 p.residual = reinterpret_cast<const float*>(ws + h->plan.off[h->layers[l.fused_residual].ref[0]]);
             }
         }
+        if (s.mode == STEP_PARTIAL) p.flags = EPI_RAW;          // raw partial sums for the STEP_MAIN launch
         // tile configuration and split-K of the last partial round: decided per (B, T) in make_plan
         const int tile = h->plan.tile[si];
         const ConvSplit& sp = h->plan.split[si];

@@ -6,7 +6,7 @@
 
 namespace byk {
 
-enum : int { EPI_LEAKY = 1, EPI_DROPOUT = 2, EPI_RESIDUAL = 4 };
+enum : int { EPI_LEAKY = 1, EPI_DROPOUT = 2, EPI_RESIDUAL = 4, EPI_RAW = 8 /* store the accumulators as they are */ };
 
 // n / d for n < 2^31 as (umulhi(n, mul) + n) >> shr: the kernels divide by launch constants only
 // (h*w, w, T, #column tiles), and a 32-bit integer division costs ~30 vector-ALU instructions that

@@ -401,6 +401,27 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     //               (raw accumulators, [B*hw][N]); it joins the accumulator here, before scale / mask.
     const int rep = p.rep;
     const int nb = (int)(tile_n * BN) + wn * TN * 32 + 4 * lh;       // first channel of this lane's (j=0, g=0) group
+    // EPI_RAW (the Winograd-domain GEMM): the accumulators are the result; nothing but the 16-byte stores
+    if ((p.flags & EPI_RAW) && ((p.N | p.ldc) & 3) == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t m = tile_m * BM + wm * TM * 32 + i * 32 + li;
+            if (m >= (uint32_t)p.M) continue;
+            float* d = p.dst + (size_t)m * p.ldc + nb;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dn = j * 32 + 8 * g;
+                    if (nb + dn >= p.N) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q];
+                    *reinterpret_cast<f32x4*>(d + dn) = v;
+                }
+        }
+        return;
+    }
     uint32_t row_m[TM], row_img[TM], row_pix[TM];
     const float* add_row[TM];
 #pragma unroll
