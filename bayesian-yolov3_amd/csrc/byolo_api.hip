@@ -673,7 +673,9 @@ static void make_plan(byolo_t* h, int B, int T) {
     size_t wino_scratch = 0;
     { const char* e = getenv("BYOLO_WINOGRAD");
       const int on = e ? atoi(e) : 1;
-      const double min_flops = on >= 2 ? 0.0 : 1e11, budget = 2.6e9;      // 2: every eligible layer (tests)
+      const char* mf = getenv("BYOLO_WINO_MIN_GFLOP");                     // tuning knob: smallest layer (direct GFLOP) to transform
+      // (measured at config 4: 100 -> 144.97, 20 -> 147.35, 5 -> 147.32 img/s)
+      const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 20.0) * 1e9, budget = 2.6e9;   // on == 2: every eligible layer (tests)
       for (size_t si = 0; on && si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
