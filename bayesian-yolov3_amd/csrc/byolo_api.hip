@@ -685,7 +685,8 @@ static void make_plan(byolo_t* h, int B, int T) {
         // The transforms stream 4x the input + 4x the output through HBM (measured 5.2 TB/s); per output pixel the GEMM
         // saves 5/9 of 2*9*Cin*cout FLOPs.  That pays when Cin*cout/(Cin+cout) is large: measured at config 4
         // 512x1024 channels (19x19) -33 %, 256x512 (38x38) -24 %, 128x256 (76x76) +6 % -> direct below ~128.
-        if (on < 2 && (double)l.Cin * l.filters / (l.Cin + l.filters) < 128.0) continue;
+        static const double min_ratio = [] { const char* e = getenv("BYOLO_WINO_MIN_RATIO"); return e ? atof(e) : 80.0; }();
+        if (on < 2 && (double)l.Cin * l.filters / (l.Cin + l.filters) < min_ratio) continue;
         WinoPlan& w = p.wino[si];
         w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2;
         const int S = M / (l.H * l.W);
@@ -829,6 +830,22 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
         HIPCHK(h, launch_wino_input(w, st));
 
         const int rows = 16 * w.P_pad;
+        static const bool stream_on = [] { const char* e = getenv("BYOLO_GEMM_STREAM"); return !e || atoi(e) != 0; }();
+        if (stream_on && gemm_stream_ok(c.C0, c.N)) {           // persistent row-streaming GEMM (gemm_stream.hip)
+            GemmStreamParams q; memset(&q, 0, sizeof q);
+            q.a = V; q.a_bytes = (uint32_t)((uint64_t)rows * c.C0 * 4);
+            q.w = dptr(h, s.wino_off); q.wstride = (uint32_t)((size_t)(c.C0 / 32) * c.N * 32 * 4); q.w_bytes = 16u * q.wstride;
+            q.dst = Mb; q.C = c.C0; q.N = c.N; q.KT = c.C0 / 32; q.n_tiles = c.N / 128;
+            q.RT = w.P_pad / 128;
+            const int R = 16 * q.RT;
+            q.slots = 512 / q.n_tiles; q.q = R / q.slots; q.rem = R % q.slots;
+            q.d_ntiles = make_fastdiv((uint32_t)q.n_tiles); q.d_RT = make_fastdiv((uint32_t)q.RT);
+            if (prof && (rc = mark_launch(h, s.layer, 129, rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
+            HIPCHK(h, launch_gemm_stream(q, st));
+            if (prof && (rc = mark_launch(h, s.layer, -3, w.P, c.N, 0, 0.0, st))) return rc;
+            HIPCHK(h, launch_wino_output(w, st));
+            continue;
+        }
         ConvParams g; memset(&g, 0, sizeof g);                  // a 1x1 convolution over a 1 x rows "image" of C0 channels
         g.src0 = V; g.src1 = V; g.C0 = c.C0; g.C1 = 0;
         g.src0_bytes = g.src1_bytes = (uint32_t)((uint64_t)rows * c.C0 * 4);

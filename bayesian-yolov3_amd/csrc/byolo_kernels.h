@@ -82,6 +82,19 @@ struct WinoParams {
     int flags; float inv_keep; uint32_t k0, k1, thr; uint64_t idx_base;
     FastDiv d_tt, d_tw, d_c4, d_n4;   // th*tw, tw, C/4, N/4
 };
+// The Winograd-domain GEMM as one persistent launch that streams row tiles (gemm_stream.hip)
+struct GemmStreamParams {
+    const float* a; uint32_t a_bytes;     // V: [16 * RT * 128 rows][C]
+    const float* w; uint32_t w_bytes;     // 16 matrices, each packed [C/32][N][32], wstride bytes apart
+    float* dst;                           // M: [rows][N]
+    int C, N, KT, n_tiles;                // KT = C / 32 (even), n_tiles = N / 128
+    int RT;                               // row tiles per transform point xi
+    int slots, q, rem;                    // 512 / n_tiles row ranges of q (+1 for the first rem) row tiles
+    uint32_t wstride;
+    FastDiv d_ntiles, d_RT;
+};
+bool gemm_stream_ok(int C, int N);
+hipError_t launch_gemm_stream(const GemmStreamParams& p, hipStream_t st);
 hipError_t launch_wino_input(const WinoParams& p, hipStream_t st);
 hipError_t launch_wino_output(const WinoParams& p, hipStream_t st);
 void wino_weight_transform(const float g[9], float u[16]);   // host: U = G g G^T
