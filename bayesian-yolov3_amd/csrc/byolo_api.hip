@@ -675,7 +675,8 @@ static void make_plan(byolo_t* h, int B, int T) {
       const int on = e ? atoi(e) : 1;
       const char* mf = getenv("BYOLO_WINO_MIN_GFLOP");                     // tuning knob: smallest layer (direct GFLOP) to transform
       // (measured at config 4: 100 -> 144.97, 20 -> 147.35, 5 -> 147.32 img/s)
-      const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 20.0) * 1e9, budget = 2.6e9;   // on == 2: every eligible layer (tests)
+      const char* bm = getenv("BYOLO_WINO_CHUNK_MB");                      // tuning knob: V + M bytes of one chunk
+      const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 20.0) * 1e9, budget = (bm ? atof(bm) : 2600.0) * 1e6;   // on == 2: every eligible layer (tests)
       for (size_t si = 0; on && si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
@@ -839,8 +840,7 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
             q.RT = w.P_pad / 128;
             const int R = 16 * q.RT;
             q.slots = 512 / q.n_tiles; q.q = R / q.slots; q.rem = R % q.slots;
-            q.d_ntiles = make_fastdiv((uint32_t)q.n_tiles); q.d_RT = make_fastdiv((uint32_t)q.RT);
-            if (prof && (rc = mark_launch(h, s.layer, 129, rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
+            q.d_ntiles = make_fastdiv((uint32_t)q.n_tiles); q.d_RT = make_fastdiv((uint32_t)q.RT);            if (prof && (rc = mark_launch(h, s.layer, 129, rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
             HIPCHK(h, launch_gemm_stream(q, st));
             if (prof && (rc = mark_launch(h, s.layer, -3, w.P, c.N, 0, 0.0, st))) return rc;
             HIPCHK(h, launch_wino_output(w, st));

@@ -8,6 +8,10 @@
 // ~40 row tiles: the loads of the next row tile's first K-tiles are already in flight while the last K-tiles of the
 // current one are multiplied; between two row tiles there is only the store of the 64 accumulator registers.
 // Same tile shape, LDS image, fragment scheme and MFMA / LDS / load interleaving as conv_igemm.hip (see there).
+// Measured (config 4 head layers, TFLOP/s executed):  K = 512: 131,  K = 256: 126,  K = 128: 113-116.  Timing ablations:
+// without the loads AND the stores the loop runs at 140-145 on all three; the stores alone cost 2 / 9 / 19 %, the loads
+// 5 / 8 / 11 %.  It is the memory system, not the pipeline: at K = 128 the GEMM writes 1 KB and reads 0.5 KB per 65.5
+// kFLOP = 43 FLOP/B, i.e. 3.3 TB/s at 140 TFLOP/s.  (A second A register set fetched three tiles ahead: no gain.)
 //
 // Work split: grid = 512 workgroups (2 per CU, what the LDS allows); slot s = one of 512 / n_tiles row ranges
 // (balanced to one row tile), its n_tiles workgroups (one per 128-column tile) sit on the SAME XCD and run the
