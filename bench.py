@@ -202,11 +202,17 @@ def main():
                        "images_per_gpu": B, "T": T, "img_size": [cfg["H"], cfg["W"]], "parallelism": "dp%d" % world,
                        "gflop_per_image": flops_img / 1e9},
         }
-        if prof and 128 in acc:
-            # dominant kernel: EXECUTED matrix-pipe FLOPs of its launches / their time.  For the direct convolutions
-            # that is the algorithmic 2*M*N*K; a Winograd-domain GEMM launch executes 1/2.25 of the direct-convolution
-            # FLOPs it stands for (x tile padding), and its transforms are separate, HBM-bound launches.
-            f, ms, n, fx = acc[128]
+        KERNELS = {129: "gemm_stream_kernel (Winograd-domain GEMM, fp32 v_mfma_f32_32x32x2_f32)",
+                   128: "conv_igemm_kernel<128,128,2,2,*> (fp32 v_mfma_f32_32x32x2_f32)",
+                   64: "conv_igemm_kernel<128,64,2,2,*>", 32: "conv_igemm_kernel<128,32,4,1,*>"}
+        mm = [v for v in acc if v in KERNELS]
+        if prof and mm:
+            # dominant kernel = the matrix-pipe kernel with the most time in the timed region.  achieved = EXECUTED
+            # matrix-pipe FLOPs of its launches / their time.  For the direct convolutions that is the algorithmic 2*M*N*K;
+            # a Winograd-domain GEMM launch executes 1/2.25 of the direct-convolution FLOPs it stands for (x tile padding),
+            # and its transforms are separate, HBM-bound launches.
+            dom = max(mm, key=lambda v: acc[v][1])
+            f, ms, n, fx = acc[dom]
             tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for a in acc.values())
             ach = fx / (ms * 1e-3)
             wino_ms = sum(acc[v][1] for v in (-2, -3) if v in acc)
@@ -215,15 +221,19 @@ def main():
             traffic = None
             tpath = os.path.join(REPO, "profiles", "traffic_cfg%d.json" % args.config)
             if os.path.exists(tpath) and not args.batch:
-                traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("kernel", "").split("<")[0].strip() in KERNELS[dom]:
+                    traffic = tj.get("traffic_bytes_per_launch")
             line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
                                 "frac": ach / PEAK_FP32_MFMA, "traffic": traffic,
-                                "kernel": "conv_igemm_kernel<128,128,2,2,*> (fp32 v_mfma_f32_32x32x2_f32)",
+                                "kernel": KERNELS[dom],
                                 "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
                                 "share_of_conv_time": ms / tot_ms, "winograd_transform_share_of_conv_time": wino_ms / tot_ms,
                                 # algorithmic (direct-convolution) FLOPs of the whole conv stack / its time, transforms
                                 # included: exceeds what the matrix pipe executes where Winograd F(2x2,3x3) is used
                                 "all_conv_algorithmic": tot_f / (tot_ms * 1e-3) / 1e12,
+                                "by_kernel": {KERNELS[v].split(" ")[0]: {"launches": acc[v][2], "ms": acc[v][1], "executed_tflops": acc[v][3] / (acc[v][1] * 1e-3) / 1e12}
+                                              for v in sorted(mm, key=lambda v: -acc[v][1])},
                                 "end_to_end_frac": (imgs / dt) * flops_img / (world * PEAK_FP32_MFMA)}
             line["stage_ms_per_step"] = {k: v / args.steps for k, v in stage.items()}
         if world == 1 and not args.no_cpu_baseline:
