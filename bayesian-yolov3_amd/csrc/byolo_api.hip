@@ -89,7 +89,7 @@ struct Step {
     size_t wino_off = 0;           // the 16 transformed weight matrices U[xi], each packed [Cin/32][Npad][32]
 };
 // per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
-struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; };
+struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; };
 struct AuxTensor { int H, W, C; };
 
 struct Plan {
@@ -694,9 +694,27 @@ static void make_plan(byolo_t* h, int B, int T) {
         const double per_sample = 16.0 * w.th * w.tw * (l.Cin + l.filters) * 4.0;
         const int nchunks = (int)std::ceil(S * per_sample / budget);                 // equal chunks
         w.chunk = (S + nchunks - 1) / nchunks;
+        // Fused kernel (wino_fused.hip; no M): its work unit is a row tile of 128 output tiles through all 16 transform
+        // points, dealt out statically to 512 / (cout/64) slots -- pick the chunk size (samples) whose row-tile count
+        // wastes the fewest slot rounds, and use the fused kernel only when every slot gets >= 3 row tiles.
+        static const int fused_mode = [] { const char* e = getenv("BYOLO_WINO_FUSED"); return e ? atoi(e) : 1; }();   // 0 never, 2 always (tests)
+        if (fused_mode && wino_fused_ok(l.Cin, l.filters)) {
+            const int slots = 512 / (l.filters / 64), tt = w.th * w.tw;
+            const int max_c = (int)std::max(1.0, std::min((double)S, std::floor(budget / (16.0 * tt * l.Cin * 4.0))));
+            auto rt = [&](int c) { return (c * tt + 127) / 128; };
+            auto rounds = [&](int c) { return (rt(c) + slots - 1) / slots; };
+            int best_c = 0; double best_cost = 1e30;
+            for (int c = std::max(1, max_c / 6); c <= max_c; ++c) {
+                const int full = S / c, last = S % c;
+                // cost in slot rounds (+ a little per chunk for the launches and the pipeline fill)
+                const double cost = full * (rounds(c) + 0.15) + (last ? rounds(last) + 0.15 : 0.0);
+                if (cost < best_cost - 1e-9 || (std::fabs(cost - best_cost) < 1e-9 && c > best_c)) { best_cost = cost; best_c = c; }
+            }
+            if (best_c > 0 && (fused_mode >= 2 || rt(best_c) / slots >= 3)) { w.fused = true; w.chunk = best_c; }
+        }
         const size_t P_pad = align_up((size_t)w.chunk * w.th * w.tw, 128);
         w.v_bytes = align_up((size_t)16 * P_pad * l.Cin * 4, 256);
-        w.m_bytes = align_up((size_t)16 * P_pad * l.filters * 4, 256);
+        w.m_bytes = w.fused ? 0 : align_up((size_t)16 * P_pad * l.filters * 4, 256);
         wino_scratch = std::max(wino_scratch, w.v_bytes + w.m_bytes);
         const int rows = (int)(16 * P_pad);
         p.split[si] = conv_plan_split(rows, s.Npad, l.Cin / 32, s.tile);
@@ -831,6 +849,22 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
         HIPCHK(h, launch_wino_input(w, st));
 
         const int rows = 16 * w.P_pad;
+        if (wp.fused) {                                         // GEMM + output transform + epilogue in one kernel: no M
+            WinoFusedParams f; memset(&f, 0, sizeof f);
+            f.v = V; f.v_bytes = (uint32_t)((uint64_t)rows * c.C0 * 4);
+            f.w = dptr(h, s.wino_off); f.wstride = (uint32_t)((size_t)(c.C0 / 32) * c.N * 32 * 4); f.w_bytes = 16u * f.wstride;
+            f.y = c.dst; f.residual = (c.flags & EPI_RESIDUAL) ? c.residual : nullptr; f.scale = c.scale; f.shift = c.shift;
+            f.C = c.C0; f.N = c.N; f.KT = c.C0 / 32; f.n_tiles = c.N / 64;
+            f.H = l.H; f.W = l.W; f.th = wp.th; f.tw = wp.tw; f.s0 = s0; f.P = w.P;
+            const int RT = w.P_pad / 128;
+            f.slots = 512 / f.n_tiles; f.q = RT / f.slots; f.rem = RT % f.slots;
+            f.xi_stride = (uint32_t)((uint64_t)w.P_pad * c.C0 * 4);
+            f.flags = c.flags; f.inv_keep = c.inv_keep; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base;
+            f.d_ntiles = make_fastdiv((uint32_t)f.n_tiles); f.d_tt = w.d_tt; f.d_tw = w.d_tw;
+            if (prof && (rc = mark_launch(h, s.layer, 130, rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
+            HIPCHK(h, launch_wino_fused(f, st));
+            continue;
+        }
         static const bool stream_on = [] { const char* e = getenv("BYOLO_GEMM_STREAM"); return !e || atoi(e) != 0; }();
         if (stream_on && gemm_stream_ok(c.C0, c.N)) {           // persistent row-streaming GEMM (gemm_stream.hip)
             GemmStreamParams q; memset(&q, 0, sizeof q);

@@ -93,6 +93,21 @@ struct GemmStreamParams {
     uint32_t wstride;
     FastDiv d_ntiles, d_RT;
 };
+// The same GEMM with the output transform and the convolution's epilogue fused in (wino_fused.hip): no M
+struct WinoFusedParams {
+    const float* v; uint32_t v_bytes;     // V: [16][P_pad][C]
+    const float* w; uint32_t w_bytes;     // 16 matrices, each packed [C/32][N][32]
+    float* y; const float* residual;      // output / residual [S,H,W,N]
+    const float* scale; const float* shift;
+    int C, N, KT, n_tiles;                // KT = C / 32 (even), n_tiles = N / 64
+    int H, W, th, tw, s0, P;              // as WinoParams
+    int slots, q, rem;                    // 512 / n_tiles ranges of q (+1 for the first rem) row tiles (128 output tiles each)
+    uint32_t xi_stride, wstride;          // bytes between consecutive transform points in V / in the weights
+    int flags; float inv_keep; uint32_t k0, k1, thr; uint64_t idx_base;
+    FastDiv d_ntiles, d_tt, d_tw;
+};
+bool wino_fused_ok(int C, int N);
+hipError_t launch_wino_fused(const WinoFusedParams& p, hipStream_t st);
 bool gemm_stream_ok(int C, int N);
 hipError_t launch_gemm_stream(const GemmStreamParams& p, hipStream_t st);
 hipError_t launch_wino_input(const WinoParams& p, hipStream_t st);

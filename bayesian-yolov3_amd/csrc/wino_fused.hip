@@ -1,0 +1,309 @@
+// wino_fused.hip -- the Winograd-domain GEMM with the OUTPUT TRANSFORM and the convolution's epilogue fused in:
+// M = V * U is never written to memory.
+//
+// gemm_stream.hip computes M[xi] (4x the size of the layer's output), winograd.hip reads it back, applies
+// Y = A^T M A and the epilogue.  At K = Cin = 128 that round trip is most of the traffic of a GEMM that already sits at
+// the memory system's edge (43 FLOP/B).  Here a workgroup owns 128 output TILES (2x2 pixels each) x 64 output
+// channels and runs, for one row tile after the other, ALL 16 transform points xi through one software pipeline
+// (16 * Cin/32 K-tiles per row tile): after the K-tiles of xi its accumulators are folded into the four 2x2-output
+// accumulators with the coefficients of A^T . A (0, +1, -1: 36 of the 64 (xi, output) pairs are non-zero), and after
+// xi = 15 the lanes hold finished pre-activation outputs: dropout mask, BN scale / shift, leaky, residual, 16-byte NHWC
+// stores -- the same epilogue as conv_igemm.hip / winograd.hip.
+//
+// Cost: the fold (72 vector-ALU instructions per xi on average + 32 to clear) and the epilogue run on the SIMDs that
+// multiply, where a vector-ALU instruction is paid in matrix-pipe time (tools/mfma_peak.hip): ~12 % at K = 128, ~3 % at
+// K = 512.  Gain: no M (write + read of 4x the output), no output-transform launch.
+// Block = 4 waves as 2 (rows) x 2 (columns), wave tile 64 tiles x 32 channels; LDS image, fragment scheme and
+// interleaving as in conv_igemm.hip; persistent grid and XCD placement as in gemm_stream.hip.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "byolo_kernels.h"
+#include "byolo_rng.h"
+
+namespace byk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WF_LD = 36;
+constexpr int WF_RSRC = 0x00020000;
+
+__device__ __forceinline__ uint32_t fdivw(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shr; }
+
+template <int N_MFMA, int N_VMEM, int N_DSR, int N_DSW>
+__device__ __forceinline__ void wf_interleave() {
+    constexpr int AUX = N_VMEM + N_DSR + N_DSW;
+    constexpr int PER = (AUX + N_MFMA - 1) / N_MFMA;
+#pragma unroll
+    for (int k = 0; k < N_MFMA; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = k * PER + u;
+            if (q < N_VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            else if (q < N_VMEM + N_DSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (q < AUX) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParams p) {
+    constexpr int BM = 128, BN = 64, NT = 256, TM = 2, TN = 1, A_LD = 4, B_LD = 2;
+    constexpr int ROWB = WF_LD * 4, A_BUF = BM * ROWB, B_BUF = BN * ROWB, B_BASE = 2 * A_BUF, JSTEP = (NT / 8) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x;
+
+    // ---- which tiles, which channels (placement as in gemm_stream.hip) ------------------------------------------
+    const uint32_t b = blockIdx.x, x = b & 7u, i8 = b >> 3;
+    const uint32_t sl = fdivw(i8, p.d_ntiles), tile_n = i8 - sl * (uint32_t)p.n_tiles;
+    const uint32_t slot = x * ((uint32_t)p.slots >> 3) + sl;
+    if (slot >= (uint32_t)p.slots) return;
+    const uint32_t r0 = slot * (uint32_t)p.q + (slot < (uint32_t)p.rem ? slot : (uint32_t)p.rem);   // first row tile
+    const int cnt = p.q + (slot < (uint32_t)p.rem ? 1 : 0);
+    if (cnt <= 0) return;
+    const int KT = p.KT, total = cnt * 16 * KT;
+
+    // ---- load stream: K-tile (row tile, xi, chunk), chunk fastest -----------------------------------------------------
+    const int a_q = tid & 7, a_r = tid >> 3;
+    uint32_t a_voff[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) a_voff[j] = (((r0 * BM + a_r + (NT / 8) * j) * (uint32_t)p.C) + a_q * 4) * 4u;
+    const uint32_t a_tile_step = (uint32_t)BM * p.C * 4u;
+    const uint32_t w_step = (uint32_t)p.N * 32 * 4;
+    const uint32_t b_voff = (tile_n * BN * 32 + (uint32_t)tid * 4) * 4;
+    uint32_t a_xi_off = 0, w_base = 0, a_soff = 0, w_soff = 0;      // xi part of the V and U offsets (scalar)
+    int ld_chunk = 0, ld_xi = 0;
+    bool ld_first = true;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, p.v_bytes, WF_RSRC);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, WF_RSRC);
+    f32x4 a_reg[A_LD], b_reg[B_LD];
+
+    auto next_tile = [&]() {
+        if (ld_chunk == 0 && !ld_first) {
+            if (++ld_xi == 16) {                 // next row tile
+                ld_xi = 0; a_xi_off = 0; w_base = 0;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) a_voff[j] += a_tile_step;
+            } else { a_xi_off += p.xi_stride; w_base += p.wstride; }
+        }
+        ld_first = false;
+        a_soff = a_xi_off + (uint32_t)ld_chunk * 128u;
+        w_soff = w_base + (uint32_t)ld_chunk * w_step;
+        if (++ld_chunk == KT) ld_chunk = 0;
+    };
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j)
+            a_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[j], a_soff, 0));
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            b_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff, w_soff + j * (NT * 16), 0));
+    };
+    const int st_off = (a_r * WF_LD + a_q * 4) * 4;
+    auto store_tile = [&](auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (BUF * A_BUF + j * JSTEP)) = a_reg[j];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (B_BASE + BUF * B_BUF + j * JSTEP)) = b_reg[j];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int fa_off = ((wm * TM * 32 + li) * WF_LD + lh * 4) * 4;
+    const int fb_off = ((wn * TN * 32 + li) * WF_LD + lh * 4) * 4;
+    auto read_frags = [&](auto buf_tag, auto kq_tag, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+        constexpr int BUF = decltype(buf_tag)::value, KQ = decltype(kq_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(lds + fa_off + (BUF * A_BUF + KQ * 32 + i * 32 * ROWB));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(lds + fb_off + (B_BASE + BUF * B_BUF + KQ * 32 + j * 32 * ROWB));
+    };
+
+    f32x16 acc[TM];                               // M[xi] of this wave's 64 tiles x 32 channels (transposed: rows = channels)
+    f32x16 Y[4][TM];                              // the four outputs (dy, dx) of every tile
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    };
+    auto zero_y = [&]() {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[o][i][r] = 0.f;
+    };
+    zero_acc(); zero_y();
+    auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[0][s], af[i][s], acc[i], 0, 0, 0);
+    };
+
+    // Y[dy][dx] += A^T[dy][i] * A^T[dx][j] * M[xi = 4 i + j];   A^T = [1 1 1 0; 0 1 -1 -1]
+    auto fold = [&](const int xi) {
+        const int i = xi >> 2, j = xi & 3;
+        const float cy[2] = {i < 3 ? 1.f : 0.f, i == 0 ? 0.f : (i == 1 ? 1.f : -1.f)};
+        const float cx[2] = {j < 3 ? 1.f : 0.f, j == 0 ? 0.f : (j == 1 ? 1.f : -1.f)};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const float c = cy[dy] * cx[dx];
+                if (c != 0.f) {                   // block-uniform
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Y[dy * 2 + dx][t][r] += c * acc[t][r];
+                }
+            }
+        zero_acc();
+    };
+
+    // ---- epilogue of one finished row tile (128 output tiles): lane = tile li (+32 per t), 4 x 4 consecutive channels ----
+    const bool do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
+    const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
+    const float keep_scale = do_drop ? p.inv_keep : 1.f;
+    const int nb = (int)(tile_n * BN) + wn * 32 + 4 * lh;          // first channel of this lane's group g = 0
+    const uint32_t tt = (uint32_t)(p.th * p.tw);
+    auto epilogue = [&](const uint32_t row_tile) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const uint32_t tile = row_tile * BM + wm * TM * 32 + t * 32 + li;
+            if (tile < (uint32_t)p.P) {
+                const uint32_t s = fdivw(tile, p.d_tt), r = tile - s * tt;
+                const uint32_t ty = fdivw(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const uint32_t oy = 2 * ty + (o >> 1), ox = 2 * tx + (o & 1);
+                    if (oy >= (uint32_t)p.H || ox >= (uint32_t)p.W) continue;
+                    const uint64_t pix = ((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox;
+                    const size_t off = (size_t)pix * p.N + nb;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n0 = nb + 8 * g;
+                        f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n0);
+                        const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + n0);
+                        sc *= keep_scale;
+                        bool keep[4] = {true, true, true, true};
+                        if (do_drop) {
+                            const uint64_t idx0 = p.idx_base + pix * (uint64_t)p.N + (uint64_t)n0;
+                            const uint64_t gp = idx0 >> 1;
+                            const uint32_t k1h = p.k1 + (uint32_t)(gp >> 32) * 0x9E3779B9u;
+                            const uint32_t h0 = byolo_pair_hash((uint32_t)gp, p.k0, k1h);
+                            const uint32_t h1 = byolo_pair_hash((uint32_t)gp + 1u, p.k0, k1h);
+                            keep[0] = (h0 & 0xFFFFu) < p.thr; keep[1] = (h0 >> 16) < p.thr;
+                            keep[2] = (h1 & 0xFFFFu) < p.thr; keep[3] = (h1 >> 16) < p.thr;
+                        }
+                        f32x4 v;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float xv = Y[o][t][4 * g + q] * sc[q];
+                            xv = keep[q] ? xv : 0.f;
+                            xv += sf[q];
+                            v[q] = fmaxf(xv, slope * xv);
+                        }
+                        if (do_res) v += *reinterpret_cast<const f32x4*>(p.residual + off + 8 * g);
+                        *reinterpret_cast<f32x4*>(p.y + off + 8 * g) = v;
+                    }
+                }
+            }
+        }
+        zero_y();
+    };
+
+    // ---- the pipeline ---------------------------------------------------------------------------------------------
+    constexpr int G = 4 * TM * TN, NFR = TM + TN, NLD = A_LD + B_LD;
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    using c3 = std::integral_constant<int, 3>;
+    using yes = std::true_type;
+    using no = std::false_type;
+    f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    next_tile(); issue_loads(); store_tile(c0{});
+    next_tile(); issue_loads();                   // total >= 16 * KT >= 32
+    __syncthreads();
+    read_frags(c0{}, c0{}, af0, bf0);
+
+    auto tile_body = [&](auto buf_tag, auto has_next_tag, auto load_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        using cur = std::integral_constant<int, BUF>;
+        using nxt = std::integral_constant<int, BUF ^ 1>;
+        constexpr bool HN = decltype(has_next_tag)::value, LD = decltype(load_tag)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(cur{}, c1{}, af1, bf1);
+        mfma_group(af0, bf0);
+        wf_interleave<G, 0, NFR, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+
+        read_frags(cur{}, c2{}, af0, bf0);
+        mfma_group(af1, bf1);
+        wf_interleave<G, 0, NFR, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+
+        read_frags(cur{}, c3{}, af1, bf1);
+        if constexpr (HN) store_tile(nxt{});
+        mfma_group(af0, bf0);
+        wf_interleave<G, 0, NFR, HN ? NLD : 0>();
+        __builtin_amdgcn_sched_barrier(0);
+
+        __syncthreads();
+        if constexpr (LD) issue_loads();
+        if constexpr (HN) read_frags(nxt{}, c0{}, af0, bf0);
+        mfma_group(af1, bf1);
+        wf_interleave<G, LD ? NLD : 0, HN ? NFR : 0, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // KT is even: a transform point ends after the second tile of a pair
+    const int half = KT >> 1;
+    int pair_in_xi = 0, xi = 0;
+    uint32_t row_tile = r0;
+    auto after_pair = [&]() {
+        if (++pair_in_xi == half) {
+            pair_in_xi = 0;
+            fold(xi);
+            if (++xi == 16) { xi = 0; epilogue(row_tile); ++row_tile; }
+        }
+    };
+    int t = 0;
+    for (; t + 3 < total; t += 2) {
+        next_tile(); tile_body(c0{}, yes{}, yes{});
+        next_tile(); tile_body(c1{}, yes{}, yes{});
+        after_pair();
+    }
+    tile_body(c0{}, yes{}, no{});
+    tile_body(c1{}, no{}, no{});
+    after_pair();
+}
+
+hipError_t launch_wino_fused(const WinoFusedParams& p, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (128 + 64) * WF_LD * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wino_fused_kernel, dim3(512), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+bool wino_fused_ok(int C, int N) {
+    const int nt = N / 64;
+    return (N % 64) == 0 && (C % 64) == 0 && (nt == 1 || nt == 2 || nt == 4 || nt == 8 || nt == 16 || nt == 32);
+}
+
+}  // namespace byk
