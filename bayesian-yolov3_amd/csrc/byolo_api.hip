@@ -697,7 +697,8 @@ static void make_plan(byolo_t* h, int B, int T) {
         // Fused kernel (wino_fused.hip; no M): its work unit is a row tile of 128 output tiles through all 16 transform
         // points, dealt out statically to 512 / (cout/64) slots -- pick the chunk size (samples) whose row-tile count
         // wastes the fewest slot rounds, and use the fused kernel only when every slot gets >= 3 row tiles.
-        static const int fused_mode = [] { const char* e = getenv("BYOLO_WINO_FUSED"); return e ? atoi(e) : 1; }();   // 0 never, 2 always (tests)
+        const char* fe = getenv("BYOLO_WINO_FUSED");
+        const int fused_mode = fe ? atoi(fe) : 1;                              // 0 never, 2 always (tests); read per plan
         if (fused_mode && wino_fused_ok(l.Cin, l.filters)) {
             const int slots = 512 / (l.filters / 64), tt = w.th * w.tw;
             const int max_c = (int)std::max(1.0, std::min((double)S, std::floor(budget / (16.0 * tt * l.Cin * 4.0))));

@@ -202,7 +202,8 @@ def main():
                        "images_per_gpu": B, "T": T, "img_size": [cfg["H"], cfg["W"]], "parallelism": "dp%d" % world,
                        "gflop_per_image": flops_img / 1e9},
         }
-        KERNELS = {129: "gemm_stream_kernel (Winograd-domain GEMM, fp32 v_mfma_f32_32x32x2_f32)",
+        KERNELS = {130: "wino_fused_kernel (Winograd-domain GEMM + output transform + epilogue, fp32 v_mfma_f32_32x32x2_f32)",
+                   129: "gemm_stream_kernel (Winograd-domain GEMM, fp32 v_mfma_f32_32x32x2_f32)",
                    128: "conv_igemm_kernel<128,128,2,2,*> (fp32 v_mfma_f32_32x32x2_f32)",
                    64: "conv_igemm_kernel<128,64,2,2,*>", 32: "conv_igemm_kernel<128,32,4,1,*>"}
         mm = [v for v in acc if v in KERNELS]

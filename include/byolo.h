@@ -158,8 +158,8 @@ BYOLO_API int32_t byolo_set_profiling(byolo_t* h, int32_t on);   /* 0 off, 1 per
 BYOLO_API int32_t byolo_stage_ms(byolo_t* h, float ms[4]);
 /* per kernel launch of the convolution stack in the LAST forward (profiling level 2): graph layer, kernel
  * variant (BN of the implicit-GEMM tile: 128 / 64 / 32; -1 the direct small-Cin kernels; -2 / -3 the Winograd
- * input / output transforms), the EXECUTED extents {M, N, K} (for a Winograd-domain GEMM: 16 * tiles rows,
- * cout, cin), the launch's device time and the ALGORITHMIC FLOPs it stands for (2*M*N*K of the layer as
+ * input / output transforms; 129 the row-streaming Winograd-domain GEMM; 130 the same with output transform and
+ * epilogue fused in), the EXECUTED extents {M, N, K} (for a Winograd-domain GEMM: 16 * tiles rows, cout, cin), the launch's device time and the ALGORITHMIC FLOPs it stands for (2*M*N*K of the layer as
  * written; differs from the executed work for the T-invariant de-duplicated launches -- conv once per image +
  * T masked epilogues; the per-image partial sum of a concat's tiled half carries 0 -- and for Winograd, where
  * the GEMM launch carries the direct-convolution FLOPs of its samples and the transforms carry 0).

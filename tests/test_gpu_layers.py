@@ -57,14 +57,15 @@ def _random_params(eng, seed):
     return p
 
 
-@pytest.mark.parametrize("wino", ["0", "2"])             # direct / Winograd F(2x2,3x3) on every eligible 3x3 (layer d)
+@pytest.mark.parametrize("wino", ["0", "2", "2f"])       # direct / Winograd F(2x2,3x3) on every eligible 3x3 (layer d) / fused kernel
 @pytest.mark.parametrize("ksplit", ["-1", "3"])          # planner's choice / K slices forced on every launch
 @pytest.mark.parametrize("H,W,B", [(64, 64, 1), (32, 96, 3)])
 def test_custom_graph_layer_by_layer(H, W, B, ksplit, wino, monkeypatch):
     import torch
     from byolo import Engine
     monkeypatch.setenv("BYOLO_KSPLIT", ksplit)
-    monkeypatch.setenv("BYOLO_WINOGRAD", wino)
+    monkeypatch.setenv("BYOLO_WINOGRAD", wino[0])
+    monkeypatch.setenv("BYOLO_WINO_FUSED", "2" if wino.endswith("f") else "0")
     eng = Engine((H, W, 3), 2, drop_prob=0.25, keep_all_outputs=True)
     L = {}
     L["a"] = eng.add_conv("a", 32, 3, 1, BN)               # 3 -> 32: stem kernel

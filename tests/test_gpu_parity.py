@@ -350,8 +350,9 @@ def test_without_dedup_two_source_loader(ksplit, monkeypatch):
     assert_close(nd["boxes"].cpu().numpy(), dd["boxes"].cpu().numpy(), "no-dedup vs dedup")
 
 
+@pytest.mark.parametrize("fused", ["0", "2"])    # transform / GEMM / transform launches, or the fused GEMM kernel (forced)
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_winograd_on_every_eligible_layer(variant, monkeypatch):
+def test_winograd_on_every_eligible_layer(variant, fused, monkeypatch):
     """The large 3x3 / stride-1 convolutions run as Winograd F(2x2,3x3) (input transform, one batched GEMM launch of
     the implicit-GEMM kernel, output transform + epilogue).  BYOLO_WINOGRAD=2 forces it on EVERY eligible layer
     (the planner would pick it only for the big head convolutions): odd spatial sizes (3x3 ... 12x... grids pad to
@@ -361,6 +362,7 @@ def test_winograd_on_every_eligible_layer(variant, monkeypatch):
     monkeypatch.setenv("BYOLO_WINOGRAD", "0")
     _, direct, _, _ = _run(variant, B, keep_all=False)
     monkeypatch.setenv("BYOLO_WINOGRAD", "2")
+    monkeypatch.setenv("BYOLO_WINO_FUSED", fused)
     m, wino, _, _ = _run(variant, B)
     g = golden("fwd_%s.npz" % variant)
     for i in TAPS:
