@@ -10,10 +10,12 @@ Darknet-53 once per image, the three heads on B*T MC samples (dropout masks from
 per-box T-reduction + decode, sort + NMS, and (N > 1) ONE RCCL all-gather of the padded box lists.
 Weights are random-init with BN statistics calibrated on the device (no checkpoints, no network).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, the 128x128-tile fp32-MFMA
-implicit-GEMM conv (conv_igemm_kernel<128,128,2,2>): algorithmic FLOPs (2*M*N*K per launch, graph as
-written -- SURVEY.md section 8d) of all its launches in the timed region divided by their device time,
-measured with hipEvents recorded around every launch on the launch stream (byolo_step_profile).
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel = the fp32-MFMA kernel with the most
+device time in the timed region (the fused Winograd-domain GEMM at this config; `by_kernel` lists all of them):
+EXECUTED matrix-pipe FLOPs (2*M*N*K of every launch) divided by their device time, measured with hipEvents
+recorded around every launch on the launch stream (byolo_step_profile).  The ALGORITHMIC view (direct-convolution
+FLOPs of the graph as written) is `all_conv_algorithmic` and `end_to_end_frac`; with Winograd
+F(2x2,3x3) on the large 3x3 layers these exceed what the matrix pipe executes.
 `cpu_baseline` is the oracle's CPU restatement (PyTorch/oneDNN, NOT TensorFlow) on a bounded sample.
 """
 import argparse
@@ -78,8 +80,8 @@ def cpu_baseline(cfg, params, n_img=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
