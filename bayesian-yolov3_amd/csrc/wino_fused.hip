@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     bool ld_first = true;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, p.v_bytes, WF_RSRC);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, WF_RSRC);
-    f32x4 a_reg[A_LD], b_reg[B_LD];
+    // staging registers: the V rows of the next K-tile; the weight tiles of the next TWO (the 16 weight matrices of a
+    // layer are 2 .. 32 MB per XCD and round -- they come from the Infinity Cache, not from L2, every time)
+    f32x4 a_reg[A_LD], b_reg0[B_LD], b_reg1[B_LD];
 
     auto next_tile = [&]() {
         if (ld_chunk == 0 && !ld_first) {
@@ -97,16 +99,18 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
         w_soff = w_base + (uint32_t)ld_chunk * w_step;
         if (++ld_chunk == KT) ld_chunk = 0;
     };
-    auto issue_loads = [&]() {
+    auto load_a = [&]() {
 #pragma unroll
         for (int j = 0; j < A_LD; ++j)
             a_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[j], a_soff, 0));
+    };
+    auto load_b = [&](f32x4 (&b_reg)[B_LD]) {
 #pragma unroll
         for (int j = 0; j < B_LD; ++j)
             b_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff, w_soff + j * (NT * 16), 0));
     };
     const int st_off = (a_r * WF_LD + a_q * 4) * 4;
-    auto store_tile = [&](auto buf_tag) {
+    auto store_tile = [&](auto buf_tag, const f32x4 (&b_reg)[B_LD]) {
         constexpr int BUF = decltype(buf_tag)::value;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (BUF * A_BUF + j * JSTEP)) = a_reg[j];
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     using yes = std::true_type;
     using no = std::false_type;
     f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
-    next_tile(); issue_loads(); store_tile(c0{});
-    next_tile(); issue_loads();                   // total >= 16 * KT >= 32
+    next_tile(); load_a(); load_b(b_reg0); store_tile(c0{}, b_reg0);
+    next_tile(); load_a(); load_b(b_reg1);        // total >= 16 * KT >= 32
     __syncthreads();
     read_frags(c0{}, c0{}, af0, bf0);
 
@@ -242,10 +246,14 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
         using cur = std::integral_constant<int, BUF>;
         using nxt = std::integral_constant<int, BUF ^ 1>;
         constexpr bool HN = decltype(has_next_tag)::value, LD = decltype(load_tag)::value;
+        // tile t+1's weights wait in set (t+1) & 1; tile t+2's are fetched into set t & 1 in group 0 already
+        f32x4 (&b_far)[B_LD] = BUF == 0 ? b_reg0 : b_reg1;
+        f32x4 (&b_near)[B_LD] = BUF == 0 ? b_reg1 : b_reg0;
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LD) load_b(b_far);
         read_frags(cur{}, c1{}, af1, bf1);
         mfma_group(af0, bf0);
-        wf_interleave<G, 0, NFR, 0>();
+        wf_interleave<G, LD ? B_LD : 0, NFR, 0>();
         __builtin_amdgcn_sched_barrier(0);
 
         read_frags(cur{}, c2{}, af0, bf0);
@@ -254,16 +262,16 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
         __builtin_amdgcn_sched_barrier(0);
 
         read_frags(cur{}, c3{}, af1, bf1);
-        if constexpr (HN) store_tile(nxt{});
+        if constexpr (HN) store_tile(nxt{}, b_near);
         mfma_group(af0, bf0);
         wf_interleave<G, 0, NFR, HN ? NLD : 0>();
         __builtin_amdgcn_sched_barrier(0);
 
         __syncthreads();
-        if constexpr (LD) issue_loads();
+        if constexpr (LD) load_a();
         if constexpr (HN) read_frags(nxt{}, c0{}, af0, bf0);
         mfma_group(af1, bf1);
-        wf_interleave<G, LD ? NLD : 0, HN ? NFR : 0, 0>();
+        wf_interleave<G, LD ? A_LD : 0, HN ? NFR : 0, 0>();
         __builtin_amdgcn_sched_barrier(0);
     };
 
