@@ -176,3 +176,27 @@ def test_darknet_weight_loader(tmp_path):
     with pytest.raises((AssertionError, ValueError)):
         yolo2, _ = build_model("yolov3", 64, 64)
         yolo2.load_darknet53_weights(str(tmp_path / "short"))
+
+
+def test_winograd_f2x2_3x3_identity():
+    """The algebra behind csrc/winograd.hip / wino_fused.hip, with the matrices as written there:
+    for one 4x4 input patch d and one 3x3 filter g, A^T [(G g G^T) * (B^T d B)] A equals the 2x2 outputs of the
+    stride-1 correlation, and the fused kernel's fold coefficients A^T[dy][i] * A^T[dx][j] reproduce A^T M A."""
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        d, g = rng.standard_normal((4, 4)), rng.standard_normal((3, 3))
+        M = (G @ g @ G.T) * (Bt @ d @ Bt.T)
+        y = At @ M @ At.T
+        ref = np.array([[(d[i:i + 3, j:j + 3] * g).sum() for j in range(2)] for i in range(2)])
+        assert np.allclose(y, ref, atol=1e-12)
+        folded = np.zeros((2, 2))
+        for xi in range(16):
+            i, j = xi >> 2, xi & 3
+            for dy in range(2):
+                for dx in range(2):
+                    folded[dy, dx] += At[dy, i] * At[dx, j] * M[i, j]
+        assert np.allclose(folded, y, atol=1e-12)
+    assert int((np.abs(np.kron(At, At)) > 0).sum()) == 36      # the 36 non-zero (xi, output) pairs of the fold
