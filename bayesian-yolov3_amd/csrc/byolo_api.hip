@@ -481,6 +481,15 @@ static int32_t lower(byolo_t* h) {
         if (l.fused_residual >= 0) h->last_use[h->layers[l.fused_residual].ref[0]] = step_idx;
         h->steps.push_back(st);
     }
+    // launch geometry that depends on the graph only (byolo_workspace_bytes may plan before byolo_finalize)
+    for (auto& st : h->steps) {
+        const Layer& l = h->layers[st.layer];
+        const int N = l.filters;
+        if (l.direct) { st.tile = -1; st.Npad = N; }
+        else { st.tile = conv_pick_tile(N); const int bn = conv_tile_bn(st.tile); st.Npad = (N + bn - 1) / bn * bn; }
+        st.wino_ok = !l.direct && l.op == OP_CONV && l.ksize == 3 && l.stride == 1 && st.mode == STEP_NORMAL &&
+                     st.in.n == 1 && st.in.s[0].sh == 0 && !st.in.s[0].tile && (l.Cin % 32) == 0 && (N % 4) == 0;
+    }
     h->maxC = 1;
     for (const auto& l : h->layers) h->maxC = std::max(h->maxC, l.C);
     h->lowered = true;
@@ -516,16 +525,8 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
     for (auto& st : h->steps) {
         Layer& l = h->layers[st.layer];
         const int Cs = st.c_hi - st.c_lo, K = l.ksize * l.ksize * Cs, N = l.filters;
-        if (l.direct) { st.tile = -1; st.Npad = N; st.w_off = off; off += align_up((size_t)K * N, 64); }
-        else {
-            st.tile = conv_pick_tile(N);
-            const int bn = conv_tile_bn(st.tile);
-            st.Npad = (N + bn - 1) / bn * bn;
-            st.w_off = off; off += align_up((size_t)K * st.Npad, 64);
-        }
+        st.w_off = off; off += align_up((size_t)K * st.Npad, 64);      // tile / Npad / wino_ok: set by lower()
         l.tile = st.tile; l.Npad = st.Npad;
-        st.wino_ok = !l.direct && l.op == OP_CONV && l.ksize == 3 && l.stride == 1 && st.mode == STEP_NORMAL &&
-                     st.in.n == 1 && st.in.s[0].sh == 0 && !st.in.s[0].tile && (l.Cin % 32) == 0 && (N % 4) == 0;
         if (st.wino_ok) { st.wino_off = off; off += align_up((size_t)16 * Cs * st.Npad, 64); }
         if (st.mode == STEP_PARTIAL) continue;                  // raw accumulators: no scale / shift
         l.scale_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);   // readable (zeros) up to Npad
@@ -676,7 +677,9 @@ static void make_plan(byolo_t* h, int B, int T) {
       const char* mf = getenv("BYOLO_WINO_MIN_GFLOP");                     // tuning knob: smallest layer (direct GFLOP) to transform
       // (measured at config 4: 100 -> 144.97, 20 -> 147.35, 5 -> 147.32 img/s)
       const char* bm = getenv("BYOLO_WINO_CHUNK_MB");                      // tuning knob: V + M bytes of one chunk
-      const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 20.0) * 1e9, budget = (bm ? atof(bm) : 2600.0) * 1e6;   // on == 2: every eligible layer (tests)
+      // (chunk budget measured at config 4: 2600 MB 177.6, 600 MB 179.4, 300 MB 150.6 img/s -- below ~500 MB the fused
+      //  kernel's slots run out of row tiles; 800 MB keeps the scratch small without costing rounds)
+      const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 20.0) * 1e9, budget = (bm ? atof(bm) : 800.0) * 1e6;   // on == 2: every eligible layer (tests)
       for (size_t si = 0; on && si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
