@@ -12,13 +12,16 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for world size 1).
-    Returns (rank, local_rank, world)."""
+def init(backend=None, force=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1 unless `force`, or
+    BYOLO_DIST_FORCE=1, asks for a one-rank group: that is how the RCCL calls of the N > 1 path are exercised on a
+    one-GPU box).  Returns (rank, local_rank, world)."""
     import torch
     import torch.distributed as dist
     rank, local, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("BYOLO_DIST_FORCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -45,7 +48,7 @@ def allgather_boxes(rows, kept, count, world=None):
     import torch.distributed as dist
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return rows, kept, count
     Bl, cap, D = rows.shape
     n_r, n_k, n_c = rows.numel(), kept.numel(), count.numel()

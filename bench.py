@@ -102,6 +102,7 @@ def main():
     rank, local, world = bdist.init()
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % args.gpus
     device = local if world > 1 else 0
+    pg = dist.is_initialized()         # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
     torch.cuda.set_device(device)
 
     cfg = dict(CONFIGS[args.config])
@@ -134,7 +135,7 @@ def main():
             with torch.cuda.stream(pp["st"]):
                 r = eng.forward(x, T=T, seed=1000 + i, dropout_on=not args.no_dropout, want_boxes=False, want_nms=True,
                                 out=pp["out"], slot=1 + i % npipe, first_image=rank * B)
-                if world > 1:
+                if pg:
                     return bdist.allgather_boxes(r["rows"], r["kept"], r["count"], world)
             return r["rows"], r["kept"], r["count"]
         if nstreams > 1:
@@ -154,7 +155,7 @@ def main():
             # computes what one GPU would compute on the whole batch
             r = eng.forward(x, T=T, seed=1000 + i, dropout_on=not args.no_dropout, want_boxes=False, want_nms=True, out=out,
                             first_image=rank * B)
-        if world > 1:
+        if pg:
             return bdist.allgather_boxes(r["rows"], r["kept"], r["count"], world)
         return r["rows"], r["kept"], r["count"]
 
@@ -165,7 +166,7 @@ def main():
     acc = {}                      # variant -> [flops, ms, launches]
     per_launch = {}
     stage = {"backbone": 0.0, "heads": 0.0, "decode": 0.0, "sort_nms": 0.0}
-    if world > 1:
+    if pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -181,10 +182,10 @@ def main():
             for k, v in eng.stage_ms().items():
                 stage[k] += v
     torch.cuda.synchronize()
-    if world > 1:
+    if pg:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if pg:
         t = torch.tensor([dt], dtype=torch.float64, device=x.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -254,7 +255,7 @@ def main():
                     f.write("| %d | %d | %d | %d | %d | %d | %.4f | %.1f | %.1f |\n" % (
                         j, s["layer"], s["variant"], s["M"], s["N"], s["K"], s["ms"],
                         s["flops_executed"] / (s["ms"] * 1e-3) / 1e12, s["flops"] / (s["ms"] * 1e-3) / 1e12))
-    if world > 1:
+    if pg:
         dist.barrier()
         dist.destroy_process_group()
 

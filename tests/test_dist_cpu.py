@@ -40,3 +40,24 @@ def test_shard_range_covers_batch():
             spans = [bdist.shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_line_through_rccl_one_rank():
+    """bench.py as the driver launches it (torch.distributed.run, one rank per GPU), on the only GPU of the box:
+    a forced one-rank RCCL group runs every collective of the N > 1 path (barriers, the all-gather of the packed box
+    lists incl. the int32 bit-casts, the MAX all-reduce of the times) and the JSON line keeps its contract."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BYOLO_DIST_FORCE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(os.path.dirname(HERE), "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and line["roofline"]["frac"] > 0
