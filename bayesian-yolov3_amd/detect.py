@@ -19,46 +19,44 @@ from byolo import inference as _inf
 from lib_yolo import yolov3, model as _model
 
 
-def box_op_standard(model):
-    bbox = inference_standard_yolov3.concat_bbox([det_layer.bbox for det_layer in model.det_layers])
-    return inference_standard_yolov3.nms(bbox, model)[0]
+def _box_op(driver, first_only):
+    """One of the reference's three `box_op_*` (`detect.py:21-33`): concat the detection layers' rows and run the
+    driver module's NMS; the two non-Bayesian drivers return a batch and the reference takes image 0."""
+    def op(model):
+        kept = driver.nms(driver.concat_bbox([d.bbox for d in model.det_layers]), model)
+        return kept[0] if first_only else kept
+    return op
 
 
-def box_op_aleatoric(model):
-    bbox = inference_aleatoric.concat_bbox([det_layer.bbox for det_layer in model.det_layers])
-    return inference_aleatoric.nms(bbox, model)[0]
-
-
-def box_op_bayes(model):
-    bbox = inference_epistemic.concat_bbox([det_layer.bbox for det_layer in model.det_layers])
-    return inference_epistemic.nms(bbox, model)
+box_op_standard = _box_op(inference_standard_yolov3, True)
+box_op_aleatoric = _box_op(inference_aleatoric, True)
+box_op_bayes = _box_op(inference_epistemic, False)
 
 
 def filter_boxes(boxes, obj_idx, thresh):
-    return [box for box in boxes if box[obj_idx] > thresh]
+    """Rows whose objectness exceeds `thresh`, order kept (`detect.py:36-37`)."""
+    boxes = np.asarray(boxes)
+    if boxes.size == 0:
+        return []
+    return list(boxes[boxes[:, obj_idx] > thresh])
 
 
 def preproces_boxes(img_size, boxes, obj_idx, cls_start_idx, cls_cnt, config, cls_mapping=None):
-    """`detect.py:40-63`.  Kept as is, including the reference's quirk that with
-    `implicit_background_class` the class score is read one column to the right of the winning class
-    (`cls_idx` is incremented before `box[cls_idx + cls_start_idx]`, :43-51)."""
+    """Box rows -> the dicts `detect.py:40-63` hands to its drawing code (cls, score, obj_score, cls_score and the
+    clipped pixel corners).  With `implicit_background_class` the reference shifts the winning class index by one
+    BEFORE it reads the class score, so the score comes from the column right of the winner (:43-51); reproduced."""
+    rows = np.asarray(boxes, dtype=np.float64).reshape(len(boxes), -1) if len(boxes) else np.zeros((0, cls_start_idx + cls_cnt + 1))
+    winner = rows[:, cls_start_idx:cls_start_idx + cls_cnt].argmax(axis=1) if len(rows) else np.zeros(0, dtype=np.int64)
+    winner = winner + (1 if config['implicit_background_class'] else 0)
+    corners = np.clip(rows[:, :4], 0, 1) * np.asarray([img_size[0], img_size[1], img_size[0], img_size[1]], dtype=np.float64)
     out = []
-    for box in boxes:
-        cls_idx = np.argmax(box[cls_start_idx:cls_start_idx + cls_cnt])
-        if config['implicit_background_class']:
-            cls_idx += 1
-        cls = cls_mapping[cls_idx] if cls_mapping else cls_idx
-        cls_score = box[cls_idx + cls_start_idx]
-        out.append({
-            'cls': cls,
-            'score': box[obj_idx] * cls_score,
-            'obj_score': box[obj_idx],
-            'cls_score': cls_score,
-            'y0': np.clip(box[0], 0, 1) * img_size[0],
-            'x0': np.clip(box[1], 0, 1) * img_size[1],
-            'y1': np.clip(box[2], 0, 1) * img_size[0],
-            'x1': np.clip(box[3], 0, 1) * img_size[1],
-        })
+    for k, box in enumerate(boxes):
+        c = int(winner[k])
+        cls_score = box[cls_start_idx + c]
+        rec = {'cls': cls_mapping[c] if cls_mapping else c, 'score': box[obj_idx] * cls_score,
+               'obj_score': box[obj_idx], 'cls_score': cls_score}
+        rec.update(zip(('y0', 'x0', 'y1', 'x1'), (box.dtype.type(v) if hasattr(box, 'dtype') else v for v in corners[k])))
+        out.append(rec)
     return out
 
 
@@ -102,12 +100,8 @@ def load_model(config, model_cls):
 
 def do_it(files, thresh, config, model_cls, cls_mapping, show=False, save_dir=None):
     import torch
-    box_op = {
-        yolov3.yolov3: box_op_standard,
-        yolov3.yolov3_aleatoric: box_op_aleatoric,
-        yolov3.bayesian_yolov3_aleatoric: box_op_bayes,
-    }[model_cls]
-
+    box_op = {'yolov3': box_op_standard, 'yolov3_aleatoric': box_op_aleatoric,
+              'bayesian_yolov3_aleatoric': box_op_bayes}[model_cls.variant]
     model, img_tensor = load_model(config, model_cls)
     img_size = list(img_tensor.shape[1:])
     results = {}
@@ -145,30 +139,39 @@ def _draw(img, boxes, file, show, save_dir):
     plt.close(fig)
 
 
-def main():
-    config = {
-        'checkpoint_path': './checkpoints/',
-        'run_id': 'epi_ale',  # edit
-        'step': 'last',  # edit: int or 'last'
-        'crop_img_size': [768, 1440, 3],
-        'full_img_size': [1024, 1920, 3],  # edit if not ecp
-        'cls_cnt': 2,  # edit if not ecp
-        'T': 35,  # only relevant for bayesian model
-        'cpu_thread_cnt': 10,
-        'freeze_darknet53': False,  # actual value irrelevant
-        'crop': False,  # edit
-        'training': False,
-        'aleatoric_loss': True,  # actual value irrelevant
-        'priors': yolov3.ECP_9_PRIORS,  # actual value irrelevant
-        'out_path': './uncertainty_visualization',  # edit
-        'implicit_background_class': True,  # whether the label ids start at 1 or 0. True = 1, False = 0
-    }
-    class_name_mapping_implicit_background_cls = {1: 'ped', 2: 'rider'}   # edit, or None
-    thresh = 0.1  # edit
-    files = glob.glob('./test_images/*')  # edit
-    # EDIT: chose appropriate model class (yolov3.yolov3 / yolov3.yolov3_aleatoric / yolov3.bayesian_yolov3_aleatoric)
-    model_cls = yolov3.bayesian_yolov3_aleatoric
-    do_it(files, thresh, config, model_cls, class_name_mapping_implicit_background_cls)
+# What the reference's `main()` hard-codes and asks the user to edit (`detect.py:138-167`); every key can be
+# overridden on the command line here instead.
+DEFAULTS = dict(
+    checkpoint_path='./checkpoints/', run_id='epi_ale', step='last',
+    full_img_size=[1024, 1920, 3], crop_img_size=[768, 1440, 3], crop=False,
+    cls_cnt=2, implicit_background_class=True,      # label ids start at 1 (True) or 0 (False)
+    T=35,                                           # MC-dropout samples, Bayesian model only
+    out_path='./uncertainty_visualization',
+    # read by the model classes but without effect on inference:
+    cpu_thread_cnt=10, training=False, freeze_darknet53=False, aleatoric_loss=True,
+)
+MODELS = {'standard': yolov3.yolov3, 'aleatoric': yolov3.yolov3_aleatoric, 'bayesian': yolov3.bayesian_yolov3_aleatoric}
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.split('\n\n')[0])
+    ap.add_argument('files', nargs='*', default=None, help="images (default: ./test_images/*)")
+    ap.add_argument('--model', choices=sorted(MODELS), default='bayesian')
+    ap.add_argument('--thresh', type=float, default=0.1)
+    ap.add_argument('--run-id'), ap.add_argument('--step'), ap.add_argument('--checkpoint-path')
+    ap.add_argument('--T', type=int), ap.add_argument('--crop', action='store_true')
+    ap.add_argument('--save-dir', default=None, help="write annotated PNGs here")
+    ap.add_argument('--show', action='store_true', help="open a window per image like the reference")
+    args = ap.parse_args(argv)
+    config = dict(DEFAULTS, priors=yolov3.ECP_9_PRIORS)
+    for key in ('run_id', 'step', 'checkpoint_path', 'T'):
+        if getattr(args, key) is not None:
+            config[key] = getattr(args, key)
+    config['crop'] = args.crop
+    names = {1: 'ped', 2: 'rider'} if config['implicit_background_class'] else None
+    return do_it(args.files or glob.glob('./test_images/*'), args.thresh, config, MODELS[args.model], names,
+                 show=args.show, save_dir=args.save_dir)
 
 
 if __name__ == '__main__':
