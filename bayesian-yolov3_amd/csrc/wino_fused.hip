@@ -28,6 +28,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// timing ablations (build.py --ablate-wf N -> libbyolo_wfN.so, loaded with BYOLO_LIB; results are wrong by design):
+// 1 no fold, 2 epilogue stores raw Y (no hash / BN / leaky), 4 no epilogue, 8 V loads pinned to the first K-tile rows,
+// 16 weight loads pinned to xi = 0, 32 no global loads in the loop
+#ifndef BYOLO_WF_ABLATE
+#define BYOLO_WF_ABLATE 0
+#endif
+constexpr int WFA = BYOLO_WF_ABLATE;
+
 constexpr int WF_LD = 36;
 constexpr int WF_RSRC = 0x00020000;
 
@@ -87,16 +95,19 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     f32x4 a_reg[A_LD], b_reg0[B_LD], b_reg1[B_LD];
 
     auto next_tile = [&]() {
+        if constexpr ((WFA & 8) != 0) { a_soff = (uint32_t)ld_chunk * 128u; }
+        if constexpr ((WFA & 16) != 0) { w_soff = (uint32_t)ld_chunk * w_step; }
+        if constexpr ((WFA & 24) == 24) { if (++ld_chunk == KT) ld_chunk = 0; return; }
         if (ld_chunk == 0 && !ld_first) {
             if (++ld_xi == 16) {                 // next row tile
                 ld_xi = 0; a_xi_off = 0; w_base = 0;
 #pragma unroll
-                for (int j = 0; j < A_LD; ++j) a_voff[j] += a_tile_step;
+                for (int j = 0; j < A_LD; ++j) a_voff[j] += (WFA & 8) ? 0u : a_tile_step;
             } else { a_xi_off += p.xi_stride; w_base += p.wstride; }
         }
         ld_first = false;
-        a_soff = a_xi_off + (uint32_t)ld_chunk * 128u;
-        w_soff = w_base + (uint32_t)ld_chunk * w_step;
+        if constexpr (!(WFA & 8)) a_soff = a_xi_off + (uint32_t)ld_chunk * 128u;
+        if constexpr (!(WFA & 16)) w_soff = w_base + (uint32_t)ld_chunk * w_step;
         if (++ld_chunk == KT) ld_chunk = 0;
     };
     auto load_a = [&]() {
@@ -157,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
 
     // Y[dy][dx] += A^T[dy][i] * A^T[dx][j] * M[xi = 4 i + j];   A^T = [1 1 1 0; 0 1 -1 -1]
     auto fold = [&](const int xi) {
+        if constexpr ((WFA & 1) != 0) { if (xi != 15) return; }
         const int i = xi >> 2, j = xi & 3;
         const float cy[2] = {i < 3 ? 1.f : 0.f, i == 0 ? 0.f : (i == 1 ? 1.f : -1.f)};
         const float cx[2] = {j < 3 ? 1.f : 0.f, j == 0 ? 0.f : (j == 1 ? 1.f : -1.f)};
@@ -182,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     const int nb = (int)(tile_n * BN) + wn * 32 + 4 * lh;          // first channel of this lane's group g = 0
     const uint32_t tt = (uint32_t)(p.th * p.tw);
     auto epilogue = [&](const uint32_t row_tile) {
+        if constexpr ((WFA & 4) != 0) { if (p.P >= 0) return; }
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const uint32_t tile = row_tile * BM + wm * TM * 32 + t * 32 + li;
@@ -196,6 +209,13 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
                     const size_t off = (size_t)pix * p.N + nb;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
+                        if constexpr ((WFA & 2) != 0) {
+                            f32x4 raw;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) raw[q] = Y[o][t][4 * g + q];
+                            *reinterpret_cast<f32x4*>(p.y + off + 8 * g) = raw;
+                            continue;
+                        }
                         const int n0 = nb + 8 * g;
                         f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n0);
                         const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + n0);
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
         constexpr int BUF = decltype(buf_tag)::value;
         using cur = std::integral_constant<int, BUF>;
         using nxt = std::integral_constant<int, BUF ^ 1>;
-        constexpr bool HN = decltype(has_next_tag)::value, LD = decltype(load_tag)::value;
+        constexpr bool HN = decltype(has_next_tag)::value, LD = decltype(load_tag)::value && !(WFA & 32);
         // tile t+1's weights wait in set (t+1) & 1; tile t+2's are fetched into set t & 1 in group 0 already
         f32x4 (&b_far)[B_LD] = BUF == 0 ? b_reg0 : b_reg1;
         f32x4 (&b_near)[B_LD] = BUF == 0 ? b_reg1 : b_reg0;
