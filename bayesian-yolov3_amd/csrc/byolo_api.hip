@@ -62,6 +62,7 @@ struct Layer {
     int fused_residual = -1;       // residual layer fused into this conv's epilogue
     // packed weights (offsets in floats into the device blob)
     size_t w_off = 0, scale_off = 0, shift_off = 0;
+    size_t scalek_off = 0;             // dropout layers: scale / (1 - p), what the epilogue multiplies with when the masks are on
     int tile = 0, Npad = 0;
     bool direct = false;
     int64_t box_base = 0;
@@ -516,6 +517,12 @@ static void fold_layer(const byolo_t* h, const Layer& l, std::vector<float>& sca
     }
 }
 
+// inverted dropout's 1 / (1 - p) (layers.py:520-527 via tf.layers.dropout) is folded into the per-channel scale
+static void scale_keep(const byolo_t* h, std::vector<float>& scale) {
+    const float inv_keep = 1.0f / (1.0f - h->cfg.drop_prob);
+    for (float& v : scale) v *= inv_keep;
+}
+
 extern "C" int32_t byolo_finalize(byolo_t* h) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_finalize: null handle");
     if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
@@ -531,6 +538,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         if (st.mode == STEP_PARTIAL) continue;                  // raw accumulators: no scale / shift
         l.scale_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);   // readable (zeros) up to Npad
         l.shift_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
+        if (l.drop_ordinal >= 0) { l.scalek_off = off; off += align_up((size_t)std::max(N, st.Npad), 64); }
     }
     std::vector<float> blob(off, 0.f);
     std::vector<float> sc, sf;
@@ -565,6 +573,10 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         fold_layer(h, l, sc, sf);
         memcpy(blob.data() + l.scale_off, sc.data(), sizeof(float) * N);
         memcpy(blob.data() + l.shift_off, sf.data(), sizeof(float) * N);
+        if (l.drop_ordinal >= 0) {
+            scale_keep(h, sc);
+            memcpy(blob.data() + l.scalek_off, sc.data(), sizeof(float) * N);
+        }
     }
     if (h->d_blob && h->blob_floats != off) { HIPCHK(h, hipFree(h->d_blob)); h->d_blob = nullptr; }
     if (!h->d_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, sizeof(float) * off));
@@ -809,7 +821,6 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.w_bytes = (uint32_t)((uint64_t)p.KT * p.Npad * 32 * 4);
     p.d_hw = make_fastdiv((uint32_t)(l.H * l.W)); p.d_wout = make_fastdiv((uint32_t)l.W);
     p.d_sdiv0 = make_fastdiv((uint32_t)sdiv[0]); p.d_sdiv1 = make_fastdiv((uint32_t)sdiv[1]);
-    p.inv_keep = 1.f;
     p.rep = st.mode == STEP_REP ? T : 1;
     if (st.mode == STEP_MAIN) {
         p.addend = reinterpret_cast<const float*>(ws + h->plan.off[st.addend_tensor]);
@@ -844,7 +855,7 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
         w.scale = c.scale; w.shift = c.shift;
         w.H = l.H; w.W = l.W; w.C = c.C0; w.N = c.N; w.th = wp.th; w.tw = wp.tw;
         w.s0 = s0; w.P = ns * tt; w.P_pad = (int)align_up((size_t)w.P, 128);
-        w.flags = c.flags; w.inv_keep = c.inv_keep; w.k0 = c.k0; w.k1 = c.k1; w.thr = c.thr; w.idx_base = c.idx_base;
+        w.flags = c.flags; w.k0 = c.k0; w.k1 = c.k1; w.thr = c.thr; w.idx_base = c.idx_base;
         w.d_tt = make_fastdiv((uint32_t)tt); w.d_tw = make_fastdiv((uint32_t)wp.tw);
         w.d_c4 = make_fastdiv((uint32_t)(c.C0 / 4)); w.d_n4 = make_fastdiv((uint32_t)(c.N / 4));
         // variants of the profile entries: -2 input transform, BN of the GEMM tile, -3 output transform; the GEMM
@@ -863,7 +874,7 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
             const int RT = w.P_pad / 128;
             f.slots = 512 / f.n_tiles; f.q = RT / f.slots; f.rem = RT % f.slots;
             f.xi_stride = (uint32_t)((uint64_t)w.P_pad * c.C0 * 4);
-            f.flags = c.flags; f.inv_keep = c.inv_keep; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base;
+            f.flags = c.flags; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base;
             f.d_ntiles = make_fastdiv((uint32_t)f.n_tiles); f.d_tt = w.d_tt; f.d_tw = w.d_tw;
             if (prof && (rc = mark_launch(h, s.layer, 130, rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
             HIPCHK(h, launch_wino_fused(f, st));
@@ -894,7 +905,7 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
         g.wino_rows = (uint32_t)w.P_pad; g.d_wino = make_fastdiv((uint32_t)w.P_pad);
         g.wino_wstride = (uint32_t)((size_t)g.cin_tiles * c.Npad * 32 * 4);
         g.w_bytes = 16u * g.wino_wstride;
-        g.scale = h->d_ones; g.shift = h->d_zeros; g.flags = EPI_RAW; g.inv_keep = 1.f; g.rep = 1; g.addend_T = 1;
+        g.scale = h->d_ones; g.shift = h->d_zeros; g.flags = EPI_RAW; g.rep = 1; g.addend_T = 1;
         g.dst = Mb;
         g.d_hw = make_fastdiv((uint32_t)rows); g.d_wout = make_fastdiv((uint32_t)rows);
         g.d_sdiv0 = g.d_sdiv1 = g.d_addT = make_fastdiv(1u);
@@ -964,7 +975,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
                 p.flags |= EPI_DROPOUT; p.k0 = k.k0; p.k1 = k.k1; p.thr = k.thr;
                 // element index of this call's first output element in the logical batch's [S,h,w,c] tensor
                 p.idx_base = (uint64_t)h->first_image * (uint64_t)(l.stacked ? T : 1) * l.H * l.W * l.filters;
-                p.inv_keep = 1.0f / (1.0f - h->cfg.drop_prob);
+                p.scale = dptr(h, l.scalek_off);             // scale / (1 - p)
             }
             if (l.fused_residual >= 0) {
                 p.flags |= EPI_RESIDUAL;
@@ -1092,6 +1103,11 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         HIPCHK(h, hipMemcpyAsync(dptr(h, l.scale_off), sc.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
         HIPCHK(h, hipMemcpyAsync(dptr(h, l.shift_off), sf.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
         HIPCHK(h, hipStreamSynchronize(st));
+        if (l.drop_ordinal >= 0) {
+            std::vector<float> sk = sc; scale_keep(h, sk);
+            HIPCHK(h, hipMemcpyAsync(dptr(h, l.scalek_off), sk.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+        }
         const float* res = l.fused_residual >= 0
             ? reinterpret_cast<const float*>(ws + h->plan.off[h->layers[l.fused_residual].ref[0]]) : nullptr;
         HIPCHK(h, launch_bn_act_inplace(p.dst, p.M, N, dptr(h, l.scale_off), dptr(h, l.shift_off), res, 1, st));

@@ -52,7 +52,6 @@ struct ConvParams {
     int M, N, Npad, ldc;
     int KT, cin_tiles;                // K/32, (C0+C1)/32
     int flags;                        // EPI_*
-    float inv_keep;                   // 1/(1-p) when EPI_DROPOUT
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
     uint64_t idx_base;                // dropout element index of dst[0] (sub-batch / shard of a logical batch)
     FastDiv d_hw, d_wout, d_sdiv0, d_sdiv1, d_addT;   // Hout*Wout, Wout, sdiv0, sdiv1, addend_T
@@ -79,7 +78,7 @@ struct WinoParams {
     int H, W, C, N, th, tw;           // th, tw = ceil(H/2), ceil(W/2) output tiles per image
     int s0;                           // first sample of the chunk
     int P, P_pad;                     // tiles of the chunk (samples * th * tw), rounded up to 128
-    int flags; float inv_keep; uint32_t k0, k1, thr; uint64_t idx_base;
+    int flags; uint32_t k0, k1, thr; uint64_t idx_base;
     FastDiv d_tt, d_tw, d_c4, d_n4;   // th*tw, tw, C/4, N/4
 };
 // The Winograd-domain GEMM as one persistent launch that streams row tiles (gemm_stream.hip)
@@ -103,7 +102,7 @@ struct WinoFusedParams {
     int H, W, th, tw, s0, P;              // as WinoParams
     int slots, q, rem;                    // 512 / n_tiles ranges of q (+1 for the first rem) row tiles (128 output tiles each)
     uint32_t xi_stride, wstride;          // bytes between consecutive transform points in V / in the weights
-    int flags; float inv_keep; uint32_t k0, k1, thr; uint64_t idx_base;
+    int flags; uint32_t k0, k1, thr; uint64_t idx_base;
     FastDiv d_ntiles, d_tt, d_tw;
 };
 bool wino_fused_ok(int C, int N);

@@ -391,7 +391,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     // (and residual loads) are 16-byte vectors.  The row part of every address (dst, residual, addend,
     // dropout element index) is derived once per row; the (j, g) channel-group part is an immediate.
     const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
-    const float keep_scale = do_drop ? p.inv_keep : 1.f;
     const float slope = do_leaky ? 0.1f : 1.f;
     // T-invariant de-duplication (lowering in byolo_api.hip):
     //   rep > 1     the conv ran once per IMAGE (its input does not depend on the MC sample); only the
@@ -441,12 +440,17 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
             float* dst_row[TM];
             const float* res_row[TM];
             uint64_t idx_row[TM];
+            uint32_t gp_lo[TM], k1h_row[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const uint32_t mo = rep > 1 ? (row_img[i] * rep + t) * hw + row_pix[i] : row_m[i];
                 dst_row[i] = p.dst + (size_t)mo * p.ldc + nb;
                 res_row[i] = do_res ? p.residual + (size_t)mo * p.ldc + nb : nullptr;
                 idx_row[i] = p.idx_base + (uint64_t)mo * (uint64_t)p.N + (uint64_t)nb;
+                // VEC: pair index of the row's first element and the key word of its high half (and of high half + 1:
+                // a group further along the row may sit past a 2^32 pair boundary) -- once per row, not per group
+                gp_lo[i] = (uint32_t)(idx_row[i] >> 1);
+                k1h_row[i] = p.k1 + (uint32_t)(idx_row[i] >> 33) * 0x9E3779B9u;
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -472,9 +476,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                         const int dn = j * 32 + 8 * g;                        // channel offset of the group from nb
                         const int n0 = nb + dn;                               // 4 channels n0 .. n0+3
                         if (n0 >= p.N) continue;
-                        f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);     // arrays are padded to Npad
+                        // arrays are padded to Npad; with the masks on, scale already holds 1 / (1 - p) (host)
+                        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);
                         const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
-                        sc4 *= keep_scale;
                         f32x4 a4;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
@@ -490,10 +494,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                         bool keep[4] = {true, true, true, true};
                         if (do_drop) {
                             if constexpr (VEC) {
-                                const uint64_t gp = idx0 >> 1;            // even: gp + 1 never carries
-                                const uint32_t k1h = p.k1 + (uint32_t)(gp >> 32) * 0x9E3779B9u;
-                                const uint32_t h0 = byolo_pair_hash((uint32_t)gp, p.k0, k1h);
-                                const uint32_t h1 = byolo_pair_hash((uint32_t)gp + 1u, p.k0, k1h);
+                                const uint32_t g_lo = gp_lo[i] + (uint32_t)(dn >> 1);       // even: g_lo + 1 never carries
+                                const uint32_t k1h = g_lo < gp_lo[i] ? k1h_row[i] + 0x9E3779B9u : k1h_row[i];
+                                const uint32_t h0 = byolo_pair_hash(g_lo, p.k0, k1h);
+                                const uint32_t h1 = byolo_pair_hash(g_lo + 1u, p.k0, k1h);
                                 keep[0] = (h0 & 0xFFFFu) < p.thr; keep[1] = (h0 >> 16) < p.thr;
                                 keep[2] = (h1 & 0xFFFFu) < p.thr; keep[3] = (h1 >> 16) < p.thr;
                             } else {
@@ -504,9 +508,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                         f32x4 v;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            float x = a4[q] * sc4[q];
-                            x = keep[q] ? x : 0.f;
-                            x += sf4[q];
+                            const float x = __builtin_fmaf(a4[q], keep[q] ? sc4[q] : 0.f, sf4[q]);   // mask * scale, + shift
                             v[q] = fmaxf(x, slope * x);                   // slope = 0.1 (leaky) or 1 (linear)
                         }
                         float* d = dst_row[i] + dn;

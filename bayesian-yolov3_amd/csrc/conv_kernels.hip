@@ -98,7 +98,6 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
             const int n = g * 8 + o;
             float v = acc[o] * p.scale[n];
             if (p.flags & EPI_DROPOUT) {
-                v *= p.inv_keep;
                 if (!byolo_keep(p.idx_base + (uint64_t)m * (uint64_t)N + (uint64_t)n, p.k0, p.k1, p.thr)) v = 0.f;
             }
             v += p.shift[n];

@@ -30,7 +30,7 @@ namespace {
 
 // timing ablations (build.py --ablate-wf N -> libbyolo_wfN.so, loaded with BYOLO_LIB; results are wrong by design):
 // 1 no fold, 2 epilogue stores raw Y (no hash / BN / leaky), 4 no epilogue, 8 V loads pinned to the first K-tile rows,
-// 16 weight loads pinned to xi = 0, 32 no global loads in the loop
+// 16 weight loads pinned to xi = 0, 32 no global loads in the loop, 64 epilogue computes but does not store
 #ifndef BYOLO_WF_ABLATE
 #define BYOLO_WF_ABLATE 0
 #endif
@@ -63,6 +63,7 @@ __device__ __forceinline__ void wf_interleave() {
 __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParams p) {
     constexpr int BM = 128, BN = 64, NT = 256, TM = 2, TN = 1, A_LD = 4, B_LD = 2;
     constexpr int ROWB = WF_LD * 4, A_BUF = BM * ROWB, B_BUF = BN * ROWB, B_BASE = 2 * A_BUF, JSTEP = (NT / 8) * ROWB;
+    constexpr int SS_BASE = 2 * (A_BUF + B_BUF);  // scale[64], shift[64] of this workgroup's channels
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x;
@@ -76,6 +77,11 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     const int cnt = p.q + (slot < (uint32_t)p.rem ? 1 : 0);
     if (cnt <= 0) return;
     const int KT = p.KT, total = cnt * 16 * KT;
+    // The epilogue's per-channel constants live in LDS: read from global memory inside the epilogue, every group
+    // of 4 channels waited on vmcnt -- which also counts the stores of the group before it -- and the epilogue ran at
+    // memory latency (32 round trips per row tile).  (Visible after the pipeline's first barrier.)
+    if (tid < 2 * BN)
+        reinterpret_cast<float*>(lds + SS_BASE)[tid] = tid < BN ? p.scale[tile_n * BN + tid] : p.shift[tile_n * BN + tid - BN];
 
     // ---- load stream: K-tile (row tile, xi, chunk), chunk fastest -----------------------------------------------------
     const int a_q = tid & 7, a_r = tid >> 3;
@@ -190,7 +196,6 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     // ---- epilogue of one finished row tile (128 output tiles): lane = tile li (+32 per t), 4 x 4 consecutive channels ----
     const bool do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
     const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
-    const float keep_scale = do_drop ? p.inv_keep : 1.f;
     const int nb = (int)(tile_n * BN) + wn * 32 + 4 * lh;          // first channel of this lane's group g = 0
     const uint32_t tt = (uint32_t)(p.th * p.tw);
     auto epilogue = [&](const uint32_t row_tile) {
@@ -207,6 +212,10 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
                     if (oy >= (uint32_t)p.H || ox >= (uint32_t)p.W) continue;
                     const uint64_t pix = ((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox;
                     const size_t off = (size_t)pix * p.N + nb;
+                    // pair index of the pixel's first element here and the key word of its high half: once per pixel
+                    const uint64_t idx_px = p.idx_base + pix * (uint64_t)p.N + (uint64_t)nb;
+                    const uint32_t gp_lo = (uint32_t)(idx_px >> 1);
+                    const uint32_t k1h_px = p.k1 + (uint32_t)(idx_px >> 33) * 0x9E3779B9u;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if constexpr ((WFA & 2) != 0) {
@@ -217,28 +226,26 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
                             continue;
                         }
                         const int n0 = nb + 8 * g;
-                        f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n0);
-                        const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + n0);
-                        sc *= keep_scale;
+                        // scale (x 1 / (1 - p) with the masks on: host) and shift of channels n0 .. n0 + 3
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + SS_BASE + (wn * 32 + 4 * lh + 8 * g) * 4);
+                        const f32x4 sf = *reinterpret_cast<const f32x4*>(lds + SS_BASE + (BN + wn * 32 + 4 * lh + 8 * g) * 4);
                         bool keep[4] = {true, true, true, true};
                         if (do_drop) {
-                            const uint64_t idx0 = p.idx_base + pix * (uint64_t)p.N + (uint64_t)n0;
-                            const uint64_t gp = idx0 >> 1;
-                            const uint32_t k1h = p.k1 + (uint32_t)(gp >> 32) * 0x9E3779B9u;
-                            const uint32_t h0 = byolo_pair_hash((uint32_t)gp, p.k0, k1h);
-                            const uint32_t h1 = byolo_pair_hash((uint32_t)gp + 1u, p.k0, k1h);
+                            const uint32_t g_lo = gp_lo + 4u * g;                  // even: g_lo + 1 never carries
+                            const uint32_t k1h = g_lo < gp_lo ? k1h_px + 0x9E3779B9u : k1h_px;
+                            const uint32_t h0 = byolo_pair_hash(g_lo, p.k0, k1h);
+                            const uint32_t h1 = byolo_pair_hash(g_lo + 1u, p.k0, k1h);
                             keep[0] = (h0 & 0xFFFFu) < p.thr; keep[1] = (h0 >> 16) < p.thr;
                             keep[2] = (h1 & 0xFFFFu) < p.thr; keep[3] = (h1 >> 16) < p.thr;
                         }
                         f32x4 v;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            float xv = Y[o][t][4 * g + q] * sc[q];
-                            xv = keep[q] ? xv : 0.f;
-                            xv += sf[q];
+                            const float xv = __builtin_fmaf(Y[o][t][4 * g + q], keep[q] ? sc[q] : 0.f, sf[q]);
                             v[q] = fmaxf(xv, slope * xv);
                         }
                         if (do_res) v += *reinterpret_cast<const f32x4*>(p.residual + off + 8 * g);
+                        if constexpr ((WFA & 64) != 0) { if (p.P >= 0) continue; }
                         *reinterpret_cast<f32x4*>(p.y + off + 8 * g) = v;
                     }
                 }
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
 }
 
 hipError_t launch_wino_fused(const WinoFusedParams& p, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (128 + 64) * WF_LD * sizeof(float);
+    constexpr size_t lds = (size_t)2 * (128 + 64) * WF_LD * sizeof(float) + 2 * 64 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -86,10 +86,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
         u[0][j] = a[0][j] + a[1][j] + a[2][j];
         u[1][j] = a[1][j] - a[2][j] - a[3][j];
     }
-    f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n0);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n0);     // includes 1 / (1 - p) when the masks are on
     const f32x4 sf = *reinterpret_cast<const f32x4*>(p.shift + n0);
     const bool do_drop = p.flags & EPI_DROPOUT;
-    if (do_drop) sc *= p.inv_keep;
     const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
