@@ -232,6 +232,9 @@ def main():
                                 "frac": ach / PEAK_FP32_MFMA, "traffic": traffic,
                                 "kernel": KERNELS[dom],
                                 "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
+                                # the same launches priced by the direct-convolution FLOPs they stand for (SURVEY 8d's
+                                # per-image figure is made of these): not a matrix-pipe utilisation where Winograd runs
+                                "achieved_algorithmic": f / (ms * 1e-3) / 1e12,
                                 "share_of_conv_time": ms / tot_ms, "winograd_transform_share_of_conv_time": wino_ms / tot_ms,
                                 # algorithmic (direct-convolution) FLOPs of the whole conv stack / its time, transforms
                                 # included: exceeds what the matrix pipe executes where Winograd F(2x2,3x3) is used
