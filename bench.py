@@ -33,6 +33,8 @@ CONFIGS = {   # BASELINE.json configs[1..4]  (per-GPU batch)
     3: dict(variant="bayesian_yolov3_aleatoric", H=416, W=416, B=16, T=10, nms=0),
     4: dict(variant="bayesian_yolov3_aleatoric", H=608, W=608, B=8, T=30, nms=0),
     5: dict(variant="bayesian_yolov3_aleatoric", H=1024, W=1024, B=1, T=50, nms=1),
+    # the reference's own default frame (inference_epistemic.py:218, full ECP image), not a BASELINE line
+    6: dict(variant="bayesian_yolov3_aleatoric", H=1024, W=1920, B=1, T=50, nms=1),
 }
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
@@ -198,9 +200,10 @@ def main():
             "value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" [EXPERIMENT: dropout off, invalid]" if args.no_dropout else ""),
-            "config": {"workload": "BASELINE configs[%d]: %s %dx%d T=%d, %d images/GPU (global batch %d), "
+            "config": {"workload": "%s: %s %dx%d T=%d, %d images/GPU (global batch %d), "
                                    "class-%s NMS max_out=1000, random-init weights with device-calibrated BN"
-                                   % (args.config - 1, cfg["variant"], cfg["H"], cfg["W"], T, B, B * world,
+                                   % ("BASELINE configs[%d]" % (args.config - 1) if args.config <= 5 else "reference default frame",
+                                      cfg["variant"], cfg["H"], cfg["W"], T, B, B * world,
                                       "wise 2-class" if cfg["nms"] else "agnostic"),
                        "images_per_gpu": B, "T": T, "img_size": [cfg["H"], cfg["W"]], "parallelism": "dp%d" % world,
                        "gflop_per_image": flops_img / 1e9},
