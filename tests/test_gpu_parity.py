@@ -428,6 +428,33 @@ def test_full_size_vs_cpu_restatement():
     _check_nms_against_oracle(boxes, out, v)
 
 
+def test_reference_default_frame_vs_cpu_restatement():
+    """The reference's own default input (inference_epistemic.py:218: the full 1024x1920 ECP frame; the largest,
+    non-square geometry: 32x60 / 64x120 / 128x240 cells, 120 960 boxes), T kept at 2 so that the CPU side finishes in
+    seconds: pre-NMS rows within 1e-4, 2-class NMS bit-exact on the GPU's rows."""
+    torch = _torch()
+    from byolo import synth
+    from oracle import cpu_ref
+    v, H, W, T = "bayesian_yolov3_aleatoric", 1024, 1920, 2
+    m = build_model(v, H, W, T=T, engine_options={"nms_mode": 1})[1]
+    eng = m.engine
+    eng.set_params(synth.base_params(eng.param_shapes(), v, 2, seed=7))
+    eng.finalize()
+    imgs = synth.synthetic_images(1, H, W, seed=1234)
+    x = torch.from_numpy(imgs).cuda()
+    eng.calibrate_bn(x)
+    out = eng.forward(x, T=T, seed=42, want_boxes=True)
+    torch.cuda.synchronize()
+    assert out["boxes"].shape == (1, 3 * (32 * 60 + 64 * 120 + 128 * 240), 23)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        ref, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(eng.get_params()), imgs, v, T=T, seed=42)
+    boxes = out["boxes"].cpu().numpy()
+    err = assert_close(boxes, ref.numpy(), "1024x1920 T=2 pre-NMS rows")
+    print("1024x1920 T=2: max |err| = %.3e over %d values" % (err, boxes.size))
+    _check_nms_against_oracle(boxes, out, v, two_class=True)
+
+
 def test_full_size_properties():
     """BASELINE config 4 geometry (608x608, T=30) on one image: size-independent properties."""
     torch = _torch()
