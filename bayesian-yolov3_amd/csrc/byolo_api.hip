@@ -165,7 +165,8 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
     // lib_yolo/yolov3.py:207-208: input size must be a multiple of the biggest stride
     if (cfg->img_h % 32 || cfg->img_w % 32)
         return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: full_img_size must be a multiple of 32 (yolov3.py:207-208)");
-    if (cfg->cls_cnt < 1) return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: cls_cnt < 1");
+    if (cfg->cls_cnt < 1 || cfg->cls_cnt > byk::BYOLO_MAX_CLASSES)
+        return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: cls_cnt outside 1 .. 128");
     if (cfg->max_out < 1 || cfg->max_out > 2048) return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: max_out out of [1,2048]");
     if (!(cfg->drop_prob >= 0.f && cfg->drop_prob < 1.f)) return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: drop_prob");
     byolo_t* h = new (std::nothrow) byolo();
@@ -1047,7 +1048,7 @@ extern "C" int32_t byolo_decode(byolo_t* h, int32_t kind, const float* d_raw, in
     for (int k = 0; k < 3; ++k) { d.ph[k] = priors_hw[2 * k]; d.pw[k] = priors_hw[2 * k + 1]; }
     hipError_t e = launch_decode(kind, d, reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? BYOLO_ERR_ARG : BYOLO_ERR_HIP,
-                                     "byolo_decode: %s (cls_cnt %d supported: 1,2,3,4,8,80)", hipGetErrorString(e), d.C);
+                                     "byolo_decode: %s (cls_cnt %d)", hipGetErrorString(e), d.C);
     return BYOLO_OK;
 }
 

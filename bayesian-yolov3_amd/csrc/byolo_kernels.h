@@ -136,10 +136,11 @@ hipError_t launch_fold_bn(const float* gamma, const float* beta, const float* me
                           float* scale, float* shift, int C, hipStream_t st);
 
 // ---- tail ------------------------------------------------------------------------------------
+constexpr int BYOLO_MAX_CLASSES = 128;   // register capacity of the largest decode build (tail_kernels.hip)
 struct DecodeParams {
     const float* raw;        // [S, lh, lw, 3*blk]
     float* boxes;            // [B, n_total, D]
-    int B, T, lh, lw, C;     // C = cls_cnt
+    int B, T, lh, lw, C;     // C = cls_cnt (1 .. BYOLO_MAX_CLASSES)
     int64_t n_total, box_base;
     float ph[3], pw[3];
     int layer_id;

@@ -23,22 +23,24 @@ __device__ __forceinline__ float logistic_entropy_(float s) {          // layers
     const float obj = s * logf(s);
     return -(no_obj + obj);
 }
-template <int C>
-__device__ __forceinline__ void softmax_(const float* x, float* p) {   // tf.nn.softmax (max-subtracted)
+// Class counts: the kernels are compiled for a capacity CM of class slots held in registers.  EXACT: the class count
+// IS CM (the common counts: every loop bound is a constant); otherwise the runtime count C <= CM masks the slots.
+template <int CM, bool EXACT>
+__device__ __forceinline__ void softmax_(const float* x, float* p, int C) {   // tf.nn.softmax (max-subtracted)
     float mx = x[0];
 #pragma unroll
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+    for (int c = 1; c < CM; ++c) if (EXACT || c < C) mx = fmaxf(mx, x[c]);
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) { p[c] = expf(x[c] - mx); sum += p[c]; }
+    for (int c = 0; c < CM; ++c) if (EXACT || c < C) { p[c] = expf(x[c] - mx); sum += p[c]; }
 #pragma unroll
-    for (int c = 0; c < C; ++c) p[c] = p[c] / sum;
+    for (int c = 0; c < CM; ++c) if (EXACT || c < C) p[c] = p[c] / sum;
 }
-template <int C>
-__device__ __forceinline__ float softmax_entropy_(const float* p) {    // layers.py:356-358
+template <int CM, bool EXACT>
+__device__ __forceinline__ float softmax_entropy_(const float* p, int C) {    // layers.py:356-358
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) s += p[c] * logf(p[c]);
+    for (int c = 0; c < CM; ++c) if (EXACT || c < C) s += p[c] * logf(p[c]);
     return -s;
 }
 __device__ __forceinline__ void corners_(float tx, float ty, float tw, float th, int col, int row, int lw, int lh,
@@ -52,9 +54,10 @@ __device__ __forceinline__ void corners_(float tx, float ty, float tw, float th,
 }
 
 // thread <-> (image b, cell, prior p), prior fastest: a wave reads 64 * blk contiguous floats.
-template <int C>
+template <int CM, bool EXACT>
 __global__ void decode_std_kernel(const DecodeParams p) {
-    constexpr int BLK = 5 + C, D = 5 + C;
+    const int C = EXACT ? CM : p.C;
+    const int BLK = 5 + C, D = 5 + C;
     const int cells = p.lh * p.lw;
     const int64_t total = (int64_t)p.B * cells * 3;
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
@@ -63,22 +66,23 @@ __global__ void decode_std_kernel(const DecodeParams p) {
         const int64_t bc = gid / 3;
         const int cell = (int)(bc % cells), b = (int)(bc / cells);
         const float* d = p.raw + (size_t)bc * (3 * BLK) + pr * BLK;
-        float v[BLK];
+        float v[5 + CM];
 #pragma unroll
-        for (int i = 0; i < BLK; ++i) v[i] = d[i];
-        float out[D];
+        for (int i = 0; i < 5 + CM; ++i) if (EXACT || i < BLK) v[i] = d[i];
+        float out[5 + CM];
         corners_(v[0], v[1], v[2], v[3], cell % p.lw, cell / p.lw, p.lw, p.lh, p.pw[pr], p.ph[pr], out);
         out[4] = sigmoidf_(v[4]);
-        softmax_<C>(v + 5, out + 5);
+        softmax_<CM, EXACT>(v + 5, out + 5, C);
         float* o = p.boxes + ((size_t)b * p.n_total + p.box_base + (size_t)pr * cells + cell) * D;
 #pragma unroll
-        for (int i = 0; i < D; ++i) o[i] = out[i];
+        for (int i = 0; i < 5 + CM; ++i) if (EXACT || i < D) o[i] = out[i];
     }
 }
 
-template <int C>
+template <int CM, bool EXACT>
 __global__ void decode_ale_kernel(const DecodeParams p) {
-    constexpr int BLK = 2 * (5 + C), D = 14 + C;
+    const int C = EXACT ? CM : p.C;
+    const int BLK = 2 * (5 + C), D = 14 + C;
     const int cells = p.lh * p.lw;
     const int64_t total = (int64_t)p.B * cells * 3;
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
@@ -87,11 +91,11 @@ __global__ void decode_ale_kernel(const DecodeParams p) {
         const int64_t bc = gid / 3;
         const int cell = (int)(bc % cells), b = (int)(bc / cells);
         const float* d = p.raw + (size_t)bc * (3 * BLK) + pr * BLK;
-        float v[BLK];
+        // [x,y,w,h, logvar x4, obj, log_obj_std, cls xC, log_cls_std xC]   (layers.py:41-84); the stds are not decoded
+        float v[10 + CM];
 #pragma unroll
-        for (int i = 0; i < BLK; ++i) v[i] = d[i];
-        // [x,y,w,h, logvar x4, obj, log_obj_std, cls xC, log_cls_std xC]   (layers.py:41-84)
-        float out[D];
+        for (int i = 0; i < 10 + CM; ++i) if (EXACT || i < 10 + C) v[i] = d[i];
+        float out[11 + CM];
         corners_(v[0], v[1], v[2], v[3], cell % p.lw, cell / p.lw, p.lw, p.lh, p.pw[pr], p.ph[pr], out);
         float prod = 1.f;
 #pragma unroll
@@ -101,13 +105,14 @@ __global__ void decode_ale_kernel(const DecodeParams p) {
         const float obj = sigmoidf_(v[8]);
         out[9] = obj;
         out[10] = logistic_entropy_(obj);
-        softmax_<C>(v + 10, out + 11);
-        out[11 + C] = softmax_entropy_<C>(out + 11);
-        out[12 + C] = (float)p.layer_id;
-        out[13 + C] = (float)pr;
+        softmax_<CM, EXACT>(v + 10, out + 11, C);
+        const float clsH = softmax_entropy_<CM, EXACT>(out + 11, C);
         float* o = p.boxes + ((size_t)b * p.n_total + p.box_base + (size_t)pr * cells + cell) * D;
 #pragma unroll
-        for (int i = 0; i < D; ++i) o[i] = out[i];
+        for (int i = 0; i < 11 + CM; ++i) if (EXACT || i < 11 + C) o[i] = out[i];
+        o[11 + C] = clsH;
+        o[12 + C] = (float)p.layer_id;
+        o[13 + C] = (float)pr;
     }
 }
 
@@ -140,9 +145,10 @@ __device__ __forceinline__ float det4_(float a[4][4]) {
 
 // One lane per (image, cell, prior): a single pass over the image's T samples keeps
 // 4 + 10 + 4 + 1 + 1 + C + 1 running sums in registers.
-template <int C>
+template <int CM, bool EXACT>
 __global__ void decode_epi_kernel(const DecodeParams p) {
-    constexpr int BLK = 2 * (5 + C), D = 21 + C;
+    const int C = EXACT ? CM : p.C;
+    const int BLK = 2 * (5 + C), D = 21 + C;
     const int cells = p.lh * p.lw;
     const int64_t total = (int64_t)p.B * cells * 3;
     const size_t sample_stride = (size_t)cells * 3 * BLK;
@@ -154,14 +160,14 @@ __global__ void decode_epi_kernel(const DecodeParams p) {
         const int cell = (int)(bc % cells), b = (int)(bc / cells);
         const float* d0 = p.raw + ((size_t)b * p.T) * sample_stride + (size_t)cell * (3 * BLK) + pr * BLK;
         float s_loc[4] = {0, 0, 0, 0}, s_ll[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s_var[4] = {0, 0, 0, 0};
-        float s_obj = 0.f, s_objH = 0.f, s_cls[C], s_clsH = 0.f;
+        float s_obj = 0.f, s_objH = 0.f, s_cls[CM], s_clsH = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) s_cls[c] = 0.f;
+        for (int c = 0; c < CM; ++c) s_cls[c] = 0.f;
         for (int t = 0; t < p.T; ++t) {
             const float* d = d0 + (size_t)t * sample_stride;
-            float v[BLK];
+            float v[10 + CM];                                   // the two std logit groups are not decoded
 #pragma unroll
-            for (int i = 0; i < BLK; ++i) v[i] = d[i];
+            for (int i = 0; i < 10 + CM; ++i) if (EXACT || i < 10 + C) v[i] = d[i];
             int q = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -173,11 +179,11 @@ __global__ void decode_epi_kernel(const DecodeParams p) {
             const float obj = sigmoidf_(v[8]);
             s_obj += obj;
             s_objH += logistic_entropy_(obj);
-            float pc[C];
-            softmax_<C>(v + 10, pc);
+            float pc[CM];
+            softmax_<CM, EXACT>(v + 10, pc, C);
 #pragma unroll
-            for (int c = 0; c < C; ++c) s_cls[c] += pc[c];
-            s_clsH += softmax_entropy_<C>(pc);
+            for (int c = 0; c < CM; ++c) if (EXACT || c < C) s_cls[c] += pc[c];
+            s_clsH += softmax_entropy_<CM, EXACT>(pc, C);
         }
         float ev[4], cov[4][4];
 #pragma unroll
@@ -192,7 +198,7 @@ __global__ void decode_epi_kernel(const DecodeParams p) {
                     cov[i][j] = c; cov[j][i] = c;
                 }
         }
-        float out[D];
+        float out[17 + CM];
         corners_(ev[0], ev[1], ev[2], ev[3], cell % p.lw, cell / p.lw, p.lw, p.lh, p.pw[pr], p.ph[pr], out);
         float ale_sum = 0.f;
 #pragma unroll
@@ -209,42 +215,48 @@ __global__ void decode_epi_kernel(const DecodeParams p) {
         out[14] = obj_mean;
         out[15] = objH - s_objH * invT;
         out[16] = objH;
-        float cm[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) { cm[c] = s_cls[c] * invT; out[17 + c] = cm[c]; }
-        const float clsH = softmax_entropy_<C>(cm);
-        out[17 + C] = clsH - s_clsH * invT;
-        out[18 + C] = clsH;
-        out[19 + C] = (float)p.layer_id;
-        out[20 + C] = (float)pr;
+        for (int c = 0; c < CM; ++c) if (EXACT || c < C) out[17 + c] = s_cls[c] * invT;
+        const float clsH = softmax_entropy_<CM, EXACT>(out + 17, C);
         float* o = p.boxes + ((size_t)b * p.n_total + p.box_base + (size_t)pr * cells + cell) * D;
 #pragma unroll
-        for (int i = 0; i < D; ++i) o[i] = out[i];
+        for (int i = 0; i < 17 + CM; ++i) if (EXACT || i < 17 + C) o[i] = out[i];
+        o[17 + C] = clsH - s_clsH * invT;
+        o[18 + C] = clsH;
+        o[19 + C] = (float)p.layer_id;
+        o[20 + C] = (float)pr;
     }
 }
 
-template <int C>
+template <int CM, bool EXACT>
 static hipError_t launch_decode_c(int kind, const DecodeParams& p, hipStream_t st) {
     const int64_t total = (int64_t)p.B * p.lh * p.lw * 3;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    if (kind == 0) hipLaunchKernelGGL(decode_std_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, st, p);
-    else if (kind == 1) hipLaunchKernelGGL(decode_ale_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(decode_epi_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (kind == 0) hipLaunchKernelGGL((decode_std_kernel<CM, EXACT>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else if (kind == 1) hipLaunchKernelGGL((decode_ale_kernel<CM, EXACT>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((decode_epi_kernel<CM, EXACT>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
+// The reference takes any cls_cnt (lib_yolo/yolov3.py:180): exact builds for the usual counts, capacity builds
+// (slots masked by the runtime count; the large ones spill to scratch -- correct, not fast) for everything else.
 hipError_t launch_decode(int kind, const DecodeParams& p, hipStream_t st) {
     switch (p.C) {
-        case 1: return launch_decode_c<1>(kind, p, st);
-        case 2: return launch_decode_c<2>(kind, p, st);
-        case 3: return launch_decode_c<3>(kind, p, st);
-        case 4: return launch_decode_c<4>(kind, p, st);
-        case 8: return launch_decode_c<8>(kind, p, st);
-        case 80: return launch_decode_c<80>(kind, p, st);
-        default: return hipErrorInvalidValue;
+        case 1: return launch_decode_c<1, true>(kind, p, st);
+        case 2: return launch_decode_c<2, true>(kind, p, st);
+        case 3: return launch_decode_c<3, true>(kind, p, st);
+        case 4: return launch_decode_c<4, true>(kind, p, st);
+        case 8: return launch_decode_c<8, true>(kind, p, st);
+        case 80: return launch_decode_c<80, true>(kind, p, st);
+        default: break;
     }
+    if (p.C < 1 || p.C > BYOLO_MAX_CLASSES) return hipErrorInvalidValue;
+    if (p.C <= 8) return launch_decode_c<8, false>(kind, p, st);
+    if (p.C <= 24) return launch_decode_c<24, false>(kind, p, st);
+    if (p.C <= 48) return launch_decode_c<48, false>(kind, p, st);
+    return launch_decode_c<BYOLO_MAX_CLASSES, false>(kind, p, st);
 }
 
 // ------------------------------------------------------------------------------------------------

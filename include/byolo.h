@@ -48,7 +48,7 @@ enum { BYOLO_NORM_BN = 1, BYOLO_NORM_DROPOUT = 2 };
 
 typedef struct byolo_cfg {
     int32_t img_h, img_w, img_c;  /* config['full_img_size'] (yolov3.py:207-208: h, w % 32 == 0)   */
-    int32_t cls_cnt;              /* config['cls_cnt']                                              */
+    int32_t cls_cnt;              /* config['cls_cnt'], 1 .. 128                                    */
     float   drop_prob;            /* 0.1 hard-coded at lib_yolo/yolov3.py:462                       */
     int32_t max_out;              /* 1000: tf.image.non_max_suppression(.., 1000)                   */
     float   iou_thresh;           /* 0.5: TF default                                                */

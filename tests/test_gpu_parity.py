@@ -238,11 +238,12 @@ def test_nms_fast_path_and_fallbacks(case):
         assert res["count"].cpu().numpy().tolist() == [[100, 100], [0, 0]] or int(res["count"][1, 0]) == 0
 
 
-@pytest.mark.parametrize("cls_cnt", [2, 1, 3, 80])
+@pytest.mark.parametrize("cls_cnt", [2, 1, 3, 80, 5, 20, 33, 128])
 @pytest.mark.parametrize("kind,variant", [(0, "yolov3"), (1, "yolov3_aleatoric"), (2, "bayesian_yolov3_aleatoric")])
 def test_decode_stage(kind, variant, cls_cnt):
-    """Staged decode on oracle-provided raw logits incl. saturated ones (NaN entropies, App. D.2), for the class
-    counts the decode kernels are instantiated for (ECP: 2; also 1, 3 and COCO's 80)."""
+    """Staged decode on oracle-provided raw logits incl. saturated ones (NaN entropies, App. D.2): the class counts
+    with exact kernel builds (ECP: 2; also 1, 3 and COCO's 80) and counts served by the capacity builds (5 -> 8 slots,
+    20 -> 24, 33 -> 48, 128 = the limit)."""
     torch = _torch()
     from byolo import Engine
     from oracle import cpu_ref

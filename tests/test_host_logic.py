@@ -77,6 +77,8 @@ def test_crop_rescales_and_mutates_priors():
 
 def test_graph_errors():
     from byolo import Engine, ByoloError
+    with pytest.raises(ByoloError, match="cls_cnt outside"):
+        Engine((64, 64, 3), 129)
     e = Engine((64, 64, 3), 2)
     with pytest.raises(ByoloError, match="invalid kernel size"):
         e.add_conv("a", 8, 5, 1, 1)
