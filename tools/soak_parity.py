@@ -24,20 +24,24 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 VARIANTS = ("yolov3", "yolov3_aleatoric", "bayesian_yolov3_aleatoric")
 
 
-def one_case(rng, idx):
+def one_case(rng, idx, a):
     import torch
     from conftest import build_model, assert_close
     from byolo import synth
     from oracle import cpu_ref
     variant = VARIANTS[rng.integers(0, 3)]
     cls_cnt = int(rng.choice([1, 2, 2, 3, 5, 20, 80]))
-    H, W = int(rng.integers(1, 11)) * 32, int(rng.integers(1, 11)) * 32
     bayes = variant.startswith("bayes")
-    T = int(rng.integers(1, 9)) if bayes else 1
-    B = int(rng.integers(1, 6))
+    while True:                                 # bounded CPU work per case (the float64 restatement is the slow side)
+        H, W = int(rng.integers(1, a.max_cells + 1)) * 32, int(rng.integers(1, a.max_cells + 1)) * 32
+        T = int(rng.integers(1, a.max_T + 1)) if bayes else 1
+        B = int(rng.integers(1, a.max_B + 1))
+        if (H // 32) * (W // 32) * B * max(T, 3) <= a.budget:
+            break
     nms_mode = int(rng.integers(0, 2)) if cls_cnt == 2 else 0      # the 2-class mode is defined for C = 2
     env = {"BYOLO_WINOGRAD": str(rng.choice(["", "0", "2"])), "BYOLO_WINO_FUSED": str(rng.choice(["", "0", "2"])),
-           "BYOLO_KSPLIT": str(rng.choice(["", "", "0", "2", "3", "5"]))}
+           "BYOLO_KSPLIT": str(rng.choice(["", "", "0", "2", "3", "5"])),
+           "BYOLO_WINO_CHUNK_MB": str(rng.choice(["", "", "1", "8", "64"]))}       # small budgets: many chunks per layer
     for k, v in env.items():
         if v:
             os.environ[k] = v
@@ -97,6 +101,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-cells", type=int, default=10, help="image sides up to 32 * this")
+    ap.add_argument("--max-T", type=int, default=8)
+    ap.add_argument("--max-B", type=int, default=5)
+    ap.add_argument("--budget", type=int, default=4000, help="cap on coarsest-grid cells * B * T per case")
     a = ap.parse_args()
     import torch
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
@@ -105,7 +113,7 @@ def main():
     bad = 0
     for i in range(a.cases):
         try:
-            print(one_case(rng, i), flush=True)
+            print(one_case(rng, i, a), flush=True)
         except Exception as e:                      # keep sweeping: report every failing case
             bad += 1
             print("| %d | FAILED: %s |" % (i, str(e).replace("\n", " ")[:300]), flush=True)
