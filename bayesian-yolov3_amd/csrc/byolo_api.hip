@@ -1200,18 +1200,19 @@ extern "C" int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops) 
 // Slicing-by-8, tables built on first use.
 // ------------------------------------------------------------------------------------------------
 extern "C" uint32_t byolo_crc32c(const void* data, size_t n) {
-    static uint32_t tab[8][256];
-    static bool init = false;
-    if (!init) {
+    struct Tab { uint32_t t[8][256]; };
+    static const Tab table = [] {                   // initialised once, thread-safe (C++11 function-local static)
+        Tab x;
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-            tab[0][i] = c;
+            x.t[0][i] = c;
         }
         for (uint32_t i = 0; i < 256; ++i)
-            for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xFF];
-        init = true;
-    }
+            for (int t = 1; t < 8; ++t) x.t[t][i] = (x.t[t - 1][i] >> 8) ^ x.t[0][x.t[t - 1][i] & 0xFF];
+        return x;
+    }();
+    const uint32_t (&tab)[8][256] = table.t;
     const uint8_t* p = static_cast<const uint8_t*>(data);
     uint32_t crc = 0xFFFFFFFFu;
     while (n >= 8) {

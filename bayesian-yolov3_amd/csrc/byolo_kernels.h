@@ -3,8 +3,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace byk {
+
+// Opt a kernel into more than 64 KB of dynamic LDS, once per DEVICE (the attribute belongs to the device's copy of the
+// function; a process may hold engines on several devices) and safely from several host threads.
+inline hipError_t set_dynamic_lds_once(const void* fn, size_t bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 
 enum : int { EPI_LEAKY = 1, EPI_DROPOUT = 2, EPI_RESIDUAL = 4, EPI_RAW = 8 /* store the accumulators as they are */ };
 

@@ -572,12 +572,8 @@ template <int BM, int BN, int WM, int WN, bool FAST>
 static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
     auto k = conv_igemm_kernel<BM, BN, WM, WN, FAST>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), lds, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, st, p);
     return hipGetLastError();
 }

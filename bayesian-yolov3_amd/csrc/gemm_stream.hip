@@ -236,12 +236,8 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmStreamPar
 
 hipError_t launch_gemm_stream(const GemmStreamParams& p, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (128 + 128) * GS_LD * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(gemm_stream_kernel), lds, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(gemm_stream_kernel, dim3(512), dim3(256), lds, st, p);
     return hipGetLastError();
 }

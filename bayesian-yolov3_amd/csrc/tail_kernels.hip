@@ -738,14 +738,9 @@ hipError_t launch_sort_nms(const NmsParams& p, hipStream_t st) {
     static const bool general_only = [] { const char* e = getenv("BYOLO_NMS_GENERAL"); return e && atoi(e); }();
     const int* need = nullptr;
     if (!general_only) {
-        static bool attr_done = false;
+        static std::atomic<uint64_t> attr_done{0};
         const size_t lds = (size_t)NMS_CAP * sizeof(unsigned long long);
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
+        if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(topk_select_kernel), lds, attr_done); e != hipSuccess) return e;
         const int npass = p.two_class ? 2 : 1;
         for (int pass = 0; pass < npass; ++pass) {
             hipLaunchKernelGGL(topk_select_kernel, dim3(p.B), dim3(1024), lds, st, p.boxes, p.N, p.D, p.obj_idx, p.cls_start,
