@@ -425,6 +425,14 @@ static int32_t lower(byolo_t* h) {
         Layer& l = h->layers[i];
         if (l.op != OP_RESIDUAL) continue;
         Layer& c = h->layers[l.prev];
+        // the epilogue reads the shortcut as a dense [rows][C] tensor: it must be a tensor of its own (the output of a
+        // convolution or of an earlier residual), possibly seen through identity routes -- not an upsample / stack /
+        // concat view, which exists only inside a loader
+        int a = l.ref[0];
+        while (h->layers[a].op == OP_ROUTE && h->layers[a].nref == 1) a = h->layers[a].ref[0];
+        if (!(h->layers[a].materialized && h->layers[a].out_tensor == a))
+            return fail(h, BYOLO_ERR_ARG, "byolo_finalize: residual layer %d: the shortcut must be the output of a convolution or residual layer", i);
+        l.ref[0] = a;
         if (c.op == OP_CONV && refs[l.prev] == 1 && c.fused_residual < 0 && l.ref[0] != l.prev) {
             c.materialized = false; c.fused_residual = i; c.out_tensor = i; l.materialized = true; l.out_tensor = i;
         } else {
@@ -449,10 +457,9 @@ static int32_t lower(byolo_t* h) {
             if (l.stacked && !src_stacked && !s.tile) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d mixes stacked and unstacked inputs", i);
         }
         if (ctot != l.Cin) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d channel mismatch", i);
-        l.direct = (l.Cin % 32) != 0;
-        if (l.direct && (st.in.n != 1 || st.in.s[0].sh || (l.filters % 8) || l.op == OP_DETECTION))
-            return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d: unsupported small-Cin convolution", i);
-        if (st.in.n == 2 && (st.in.s[0].C % 32)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d: concat split not a multiple of 32", i);
+        // the implicit-GEMM loader walks the input channels in tiles of 32 (per source); everything else takes the
+        // general direct kernel (conv_kernels.hip): slow, but the builder accepts what the reference's does
+        l.direct = (l.Cin % 32) != 0 || (st.in.n == 2 && (st.in.s[0].C % 32) != 0);
         // ---- T-invariant de-duplication ----------------------------------------------------------
         if (h->dedup && l.op == OP_CONV && l.stacked && !l.direct) {
             bool all_tile = true, any_tile = false;

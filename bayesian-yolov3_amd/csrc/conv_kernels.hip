@@ -59,15 +59,22 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Direct convolution for tiny Cin, any shape (fallback of the stem kernel above): thread = (pixel, group
-// of 8 output channels); weights (HWIO, k*k*Cin x cout) broadcast from LDS.
+// Direct convolution, the general fallback: whatever the implicit-GEMM kernel does not take (an input-channel count
+// that is not a multiple of 32 -- the stem's 3 when the fast stem kernel above does not apply, or a user graph's
+// 24 / 40 / ...), with everything its loader folds in: two concatenated sources, nearest x2 upsampling, the T-fold
+// sample tile, any output-channel count, the detection bias.  thread = (output pixel, group of 8 output channels);
+// weights (HWIO, k*k*Cin x cout) are broadcast from LDS when they fit in 48 KB, read through the caches otherwise.
+// Correct, not fast: Darknet-53 / YOLOv3 never come here except for the stem.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];    // [K][N]
-    const int Cin = p.C0, K = p.ksize * p.ksize * Cin, N = p.N;
-    for (int i = threadIdx.x; i < K * N; i += blockDim.x) wl[i] = p.wpk[i];
-    __syncthreads();
-    const int groups = N >> 3;
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, const int w_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];    // [K][N] if w_in_lds
+    const int Cin = p.C0 + p.C1, K = p.ksize * p.ksize * Cin, N = p.N;
+    if (w_in_lds) {
+        for (int i = threadIdx.x; i < K * N; i += blockDim.x) wl[i] = p.wpk[i];
+        __syncthreads();
+    }
+    const float* wsrc = w_in_lds ? wl : p.wpk;
+    const int groups = (N + 7) >> 3;
     const int64_t total = (int64_t)p.M * groups;
     const int hw = p.Hout * p.Wout;
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
@@ -75,6 +82,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
         const int m = (int)(gid / groups), g = (int)(gid - (int64_t)m * groups);
         const int s = m / hw, rem = m - s * hw;
         const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        const int nv = N - g * 8 < 8 ? N - g * 8 : 8;          // valid channels of this group
         float acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.f;
@@ -82,36 +90,34 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
             const int iy = oy * p.stride - p.pad + ky;
             for (int kx = 0; kx < p.ksize; ++kx) {
                 const int ix = ox * p.stride - p.pad + kx;
-                const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                const float* px = p.src0 + (((size_t)(s / p.sdiv0) * p.Hs0 + (ok ? iy : 0)) * p.Ws0 + (ok ? ix : 0)) * Cin;
-                for (int c = 0; c < Cin; ++c) {
-                    const float x = ok ? px[c] : 0.f;
-                    const float* w = wl + ((ky * p.ksize + kx) * Cin + c) * N + g * 8;
-#pragma unroll
-                    for (int o = 0; o < 8; ++o) acc[o] = fmaf(x, w[o], acc[o]);
+                if ((unsigned)iy >= (unsigned)p.Hin || (unsigned)ix >= (unsigned)p.Win) continue;     // zero padding
+                const float* w = wsrc + (size_t)((ky * p.ksize + kx) * Cin) * N + g * 8;
+                // source 0 then source 1 (channel concat, layers.py:588); each at its own resolution / sample divisor
+                const float* px = p.src0 + (((size_t)(s / p.sdiv0) * p.Hs0 + (iy >> p.sh0)) * p.Ws0 + (ix >> p.sh0)) * p.C0;
+                for (int c = 0; c < p.C0; ++c, w += N) {
+                    const float x = px[c];
+                    for (int o = 0; o < nv; ++o) acc[o] = fmaf(x, w[o], acc[o]);
+                }
+                if (p.C1) {
+                    px = p.src1 + (((size_t)(s / p.sdiv1) * p.Hs1 + (iy >> p.sh1)) * p.Ws1 + (ix >> p.sh1)) * p.C1;
+                    for (int c = 0; c < p.C1; ++c, w += N) {
+                        const float x = px[c];
+                        for (int o = 0; o < nv; ++o) acc[o] = fmaf(x, w[o], acc[o]);
+                    }
                 }
             }
         }
-        float out[8];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
+        float* d = p.dst + (size_t)m * p.ldc + g * 8;
+        for (int o = 0; o < nv; ++o) {
             const int n = g * 8 + o;
-            float v = acc[o] * p.scale[n];
+            float v = acc[o] * p.scale[n];                     // scale includes 1 / (1 - p) when the masks are on
             if (p.flags & EPI_DROPOUT) {
                 if (!byolo_keep(p.idx_base + (uint64_t)m * (uint64_t)N + (uint64_t)n, p.k0, p.k1, p.thr)) v = 0.f;
             }
             v += p.shift[n];
             if (p.flags & EPI_LEAKY) v = fmaxf(v, 0.1f * v);
             if (p.flags & EPI_RESIDUAL) v += p.residual[(size_t)m * p.ldc + n];
-            out[o] = v;
-        }
-        float* d = p.dst + (size_t)m * p.ldc + g * 8;
-        if ((p.ldc & 3) == 0) {
-            *reinterpret_cast<f32x4*>(d) = f32x4{out[0], out[1], out[2], out[3]};
-            *reinterpret_cast<f32x4*>(d + 4) = f32x4{out[4], out[5], out[6], out[7]};
-        } else {
-#pragma unroll
-            for (int o = 0; o < 8; ++o) d[o] = out[o];
+            d[o] = v;
         }
     }
 }
@@ -122,13 +128,14 @@ hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st) {
         hipLaunchKernelGGL(conv_stem3x3_kernel<32>, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st, p);
         return hipGetLastError();
     }
-    const int K = p.ksize * p.ksize * p.C0;
-    const size_t lds = (size_t)K * p.N * sizeof(float);
-    const int64_t total = (int64_t)p.M * (p.N >> 3);
+    if (p.rep != 1 || p.addend) return hipErrorInvalidValue;          // the de-duplicated forms are implicit-GEMM only
+    const size_t wbytes = (size_t)p.ksize * p.ksize * (p.C0 + p.C1) * p.N * sizeof(float);
+    const int w_in_lds = wbytes <= 48 * 1024;
+    const int64_t total = (int64_t)p.M * ((p.N + 7) >> 3);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)blocks), dim3(256), w_in_lds ? wbytes : 0, st, p, w_in_lds);
     return hipGetLastError();
 }
 

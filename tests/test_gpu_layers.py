@@ -111,3 +111,44 @@ def test_custom_graph_layer_by_layer(H, W, B, ksplit, wino, monkeypatch):
     except ByoloError:
         got = eng.layer_output(L["d"])
     assert_close(got.cpu().numpy(), d.numpy(), "fused residual")
+
+
+def test_general_direct_convolution_and_view_shortcuts():
+    """Found by tools/fuzz_graph.py.  (1) Convolutions the implicit-GEMM loader does not take -- input channels not a
+    multiple of 32 -- run on the general direct kernel with everything the loader folds in: a two-source concat, a x2
+    upsampled source, an output-channel count that is not a multiple of 8, weights too large for LDS, a detection head.
+    (2) A residual whose shortcut is seen through an identity route is resolved to the tensor behind it."""
+    import torch
+    from byolo import Engine
+    H, W, B = 64, 96, 2
+    eng = Engine((H, W, 3), 2, drop_prob=0.25, keep_all_outputs=True)
+    L = {}
+    L["a"] = eng.add_conv("a", 24, 3, 1, BN)               # 3 -> 24 (not the 32-channel stem kernel)
+    L["b"] = eng.add_conv("b", 40, 3, 2, BN | DROP)        # Cin = 24, stride 2
+    L["id"] = eng.add_route([L["b"]])                      # identity view of b
+    L["c"] = eng.add_conv("c", 40, 3, 1, BN)               # Cin = 40
+    L["res"] = eng.add_residual(L["id"])                   # shortcut through the view
+    L["d"] = eng.add_conv("d", 256, 3, 2, BN)              # Cin = 40, 9 * 40 * 256 weights = 368 KB: not in LDS
+    L["up"] = eng.add_upsample()
+    L["cat"] = eng.add_route([L["up"], L["res"]])          # 256 (x2 upsampled) + 40 channels: 296, not a multiple of 32
+    L["e"] = eng.add_conv("e", 20, 1, 1, BN)               # two-source direct convolution, 20 output channels
+    L["det"] = eng.add_detection("h/detection", 0, [(0.1, 0.2), (0.3, 0.1), (0.5, 0.5)])    # Cin = 20, 21 channels, bias
+    p = _random_params(eng, 5)
+    eng.set_params(p)
+    eng.finalize()
+    img = np.random.default_rng(9).random((B, H, W, 3)).astype(np.float32)
+    seed = 5
+    eng.forward(torch.from_numpy(img).cuda(), T=1, seed=seed, want_boxes=True, want_nms=False)
+    torch.cuda.synchronize()
+    x = torch.from_numpy(img)
+    a = _ref_conv(x, p, "a", 3, 1, BN)
+    b = _ref_conv(a, p, "b", 3, 2, BN, drop=(seed, 0, 0.25))
+    c = _ref_conv(b, p, "c", 3, 1, BN) + b
+    d = _ref_conv(c, p, "d", 3, 2, BN)
+    cat = torch.cat([d.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2), c], dim=3)
+    e = _ref_conv(cat, p, "e", 1, 1, BN)
+    wdet = torch.from_numpy(p["h/detection/conv2d/kernel"]).permute(3, 2, 0, 1)
+    det = torch.nn.functional.conv2d(e.permute(0, 3, 1, 2), wdet).permute(0, 2, 3, 1) + torch.from_numpy(p["h/detection/conv2d/bias"])
+    for name, ref in (("a", a), ("b", b), ("res", c), ("d", d), ("e", e), ("det", det)):
+        assert_close(eng.layer_output(L[name]).cpu().numpy(), ref.numpy(), "layer %s" % name)
+

@@ -117,6 +117,20 @@ def test_graph_errors():
         e2.workspace_bytes(1, 1)
 
 
+def test_residual_shortcut_must_be_a_tensor():
+    """A shortcut that only exists as a loader view (stack / upsample / concat) is refused at lowering (it used to be
+    read as if it were a tensor: a device fault)."""
+    from byolo import Engine, ByoloError
+    eng = Engine((64, 64, 3), 2)
+    eng.add_conv("a", 32, 3, 1, 1)
+    s = eng.add_stack(0)
+    eng.add_conv("b", 32, 3, 1, 1)
+    eng.add_residual(s)
+    eng.add_detection("d/detection", 2, [(0.1, 0.2), (0.3, 0.1), (0.5, 0.5)])
+    with pytest.raises(ByoloError, match="shortcut must be the output"):
+        eng.workspace_bytes(1, 2)
+
+
 def test_forward_requires_finalize_and_device_tensors():
     import torch
     from byolo import ByoloError
