@@ -65,7 +65,17 @@ BYOLO_API const char* byolo_version(void);
 /* ---- graph construction: one call per ModelBuilder.make_* (lib_yolo/model.py:52-185).
  * Each returns the new layer's index (>= 0) in the reference's `ModelBuilder.__layers` numbering
  * (model.py:40-41) or a negative error.  Layer references (`shortcut`, `routes`, `src`) follow
- * the reference: negative = relative to the end of the list, non-negative = absolute. ---------- */
+ * the reference: negative = relative to the end of the list, non-negative = absolute.
+ *
+ * Route / upsample / stack layers are VIEWS: they exist only inside the loader of the convolution that reads them.
+ * What the reference's three models build is covered; a general ModelBuilder graph meets these limits, reported by
+ * byolo_finalize / byolo_workspace_bytes (never at run time):
+ *   - a convolution reads at most two concatenated sources, each upsampled at most once ("nested concat",
+ *     "double upsample" need a convolution in between);
+ *   - a residual add follows a convolution whose output nothing else reads, and its shortcut is the output of a
+ *     convolution or residual layer (identity routes in between are resolved);
+ *   - channel counts are free: input channels that are not a multiple of 32 (per concatenated source) take a general
+ *     direct kernel instead of the matrix-pipe one -- correct, slow. ------------------------------------------ */
 
 /* make_conv_layer / make_downsample_layer / make_darknet_conv_layer / make_darknet_downsample_layer
  * (model.py:52-81 -> layers.conv, lib_yolo/layers.py:545-575): conv(no bias) -> [dropout] -> BN
