@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""soak_decode.py -- randomised sweep of the staged decode (split + anchor decode + entropies, and for the Bayesian
+model the reduction over the T samples: lib_yolo/layers.py:11-84, :191-502) on the GPU against the CPU restatement:
+random grid sizes, batch, T, class counts 1 .. 128, logit scales up to saturation (exp -> inf, 0 * log 0 -> NaN).
++-inf must match exactly, the NaN pattern must match, finite values within 1e-4 (abs / rel); the determinant of the
+epistemic covariance is compared at the scale of Hadamard's bound (it is ill-conditioned by construction: rank <= T-1).
+
+    python tools/soak_decode.py --cases 300 --seed 1 > gpurun_out/soak_decode.md
+
+Test infrastructure (imports oracle/ as the checker)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "bayesian-yolov3_amd"))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+VARIANTS = ("yolov3", "yolov3_aleatoric", "bayesian_yolov3_aleatoric")
+
+
+def one_case(g, idx):
+    import torch
+    from byolo import Engine
+    from conftest import assert_close
+    from oracle import cpu_ref
+    kind = int(g.integers(0, 3))
+    variant = VARIANTS[kind]
+    C = int(g.choice([1, 2, 2, 3, 4, 5, 8, 9, 20, 24, 25, 48, 49, 80, 81, 128]))
+    B, T = int(g.integers(1, 5)), (int(g.integers(1, 12)) if kind == 2 else 1)
+    lh, lw = int(g.integers(1, 20)), int(g.integers(1, 20))
+    scale = float(g.choice([0.5, 2.0, 2.0, 8.0, 30.0]))
+    F = 3 * (5 + C) * (1 if kind == 0 else 2)
+    raw = (g.standard_normal((B * T, lh, lw, F)) * scale).astype(np.float32)
+    if g.random() < 0.5:
+        raw[0, 0, 0, :] = 120.0
+        raw[-1, lh - 1, lw - 1, :] = -120.0
+    pri = [(float(g.random() * 0.5 + 0.01), float(g.random() * 0.5 + 0.01)) for _ in range(3)]
+    layer_id = int(g.integers(0, 3))
+    D = cpu_ref.row_layout(variant, C)[0]
+    eng = Engine((64, 64, 3), C)
+    n_before = int(g.integers(0, 50))                              # the layer's rows sit at an offset in the concat
+    boxes = torch.zeros((B, n_before + 3 * lh * lw, D), device="cuda")
+    eng.decode(kind, torch.from_numpy(raw).cuda(), B, T, pri, layer_id, boxes, n_before)
+    torch.cuda.synchronize()
+    rt = torch.from_numpy(raw)
+    if kind == 0:
+        ref = cpu_ref.concat_bbox([cpu_ref.decode_standard(rt, pri, C)], True)
+    elif kind == 1:
+        ref = cpu_ref.concat_bbox([cpu_ref.decode_aleatoric(rt, pri, C, layer_id)], True)
+    else:
+        ref = torch.stack([cpu_ref.concat_bbox([cpu_ref.decode_epistemic(rt[b * T:(b + 1) * T], pri, C, layer_id)], False)
+                           for b in range(B)])
+    got = boxes.cpu().numpy()
+    assert (got[:, :n_before] == 0).all(), "rows before the layer's offset were touched"
+    got = got[:, n_before:]
+    ref = ref.numpy()
+    if kind > 0:
+        # The entropies are NaN exactly where a probability is exactly 0 or 1 (0 * log 0, layers.py:349-358).  WHERE
+        # float32 gets there is the implementation's business, not the reference's (sigmoid rounds to 1 around
+        # |x| = 17 +- an ulp of exp; exp underflows -- or is flushed -- between e^-87 and e^-104): rows with a logit in
+        # those two bands are left out of the entropy columns' comparison.
+        r6 = raw.reshape(B, T, lh, lw, 3, -1).astype(np.float64)
+        xo = np.abs(r6[..., 8])
+        risk = ((xo > 15.5) & (xo < 18.5)) | ((xo > 85.0) & (xo < 106.0))
+        cl = r6[..., 10:10 + C]
+        dd = cl.max(-1, keepdims=True) - cl
+        risk |= ((dd > 85.0) & (dd < 106.0)).any(-1)
+        risk = risk.any(1).transpose(0, 3, 1, 2).reshape(B, -1)                         # any sample; prior-major rows
+        cols = [10, 11 + C] if kind == 1 else [15, 16, 17 + C, 18 + C]
+        got = got.copy(); ref = ref.copy()
+        for c in cols:
+            got[..., c][risk] = 0; ref[..., c][risk] = 0
+        if kind == 1:
+            # exp(logvar) below the float32 normal range: the device flushes the denormal to 0 (as TensorFlow's CPU
+            # kernels do), torch keeps it -- and the product of the four variances (column 8) inherits the difference
+            den = (r6[:, 0, ..., 4:8] < -87.0).any(-1).transpose(0, 3, 1, 2).reshape(B, -1)
+            for c in range(4, 9):
+                got[..., c][den] = 0; ref[..., c][den] = 0
+    inf_mask = np.isinf(ref)
+    assert np.array_equal(np.isinf(got), inf_mask), "inf pattern"
+    assert np.array_equal(got[inf_mask], ref[inf_mask]), "inf signs"
+    got = np.where(inf_mask, 0, got); ref = np.where(inf_mask, 0, ref)
+    if kind == 2:
+        with np.errstate(all="ignore"):
+            hb = np.maximum(1.0, np.abs(np.prod(ref[..., 4:8].astype(np.float64), axis=-1)))
+            derr = np.abs(got[..., 12].astype(np.float64) - ref[..., 12]) / hb
+        assert not (np.nan_to_num(derr, nan=0.0) >= 1e-4).any(), "det(epi covar): scaled error %.3e" % np.nanmax(derr)
+        assert np.array_equal(np.isnan(got[..., 12]), np.isnan(ref[..., 12])), "det NaN pattern"
+        got = got.copy(); ref = ref.copy()
+        got[..., 12] = 0; ref[..., 12] = 0
+        if scale >= 8.0:
+            # E[l l^T] - E[l] E[l]^T in one pass (layers.py:383) cancels catastrophically for logits of tens: the
+            # variances (columns 4-7) are compared at the scale of E[l^2]
+            raw5 = raw.reshape(B, T, lh, lw, 3, -1)[..., :4].astype(np.float64)
+            m2 = (raw5 ** 2).mean(1).transpose(0, 3, 1, 2, 4).reshape(B, -1, 4)          # prior-major like concat_bbox
+            verr = np.abs(got[..., 4:8].astype(np.float64) - ref[..., 4:8]) / np.maximum(1.0, m2)
+            assert np.nanmax(verr) < 1e-4, "epistemic variance: scaled error %.3e" % np.nanmax(verr)
+            got[..., 4:8] = 0; ref[..., 4:8] = 0
+    err = assert_close(got, ref, "decode kind %d" % kind)
+    eng.close()
+    return "| %d | %s | %d | %d | %d | %dx%d | %.1f | %.1e |" % (idx, variant, C, B, T, lh, lw, scale, err)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    g = np.random.default_rng(a.seed)
+    print("| # | variant | C | B | T | grid | logit scale | max abs err |\n|---|---|---|---|---|---|---|---|")
+    bad = 0
+    for i in range(a.cases):
+        try:
+            print(one_case(g, i), flush=True)
+        except Exception as e:
+            bad += 1
+            print("| %d | FAILED: %s |" % (i, str(e).replace("\n", " ")[:300]), flush=True)
+    print("\n%d cases, %d failed" % (a.cases, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
