@@ -60,6 +60,8 @@ struct Layer {
     bool materialized = false;     // owns an activation tensor
     int out_tensor = -1;           // layer index whose tensor receives this conv's output
     int fused_residual = -1;       // residual layer fused into this conv's epilogue
+    bool standalone = false;       // residual layer computed by its own element-wise step (STEP_ADD)
+    int add_a = -1;                // ... its left operand (tensor id)
     // packed weights (offsets in floats into the device blob)
     size_t w_off = 0, scale_off = 0, shift_off = 0;
     size_t scalek_off = 0;             // dropout layers: scale / (1 - p), what the epilogue multiplies with when the masks are on
@@ -78,10 +80,16 @@ struct View { Src s[2]; int n = 0; };
 //   STEP_PARTIAL  the tiled (T-invariant) half of a channel concat, convolved once per image into an
 //                 auxiliary raw-accumulator tensor ...
 //   STEP_MAIN     ... which the conv over the stacked half picks up as an addend before scale / mask.
-enum StepMode { STEP_NORMAL = 0, STEP_REP = 1, STEP_PARTIAL = 2, STEP_MAIN = 3 };
+// Two more step kinds keep the builder general (the reference's models never need them):
+//   STEP_GATHER   a route / upsample / stack VIEW that a loader cannot express on the fly (the inner view of a nested
+//                 concat or double upsample, a view used as a residual shortcut) is copied into a tensor of its own;
+//   STEP_ADD      a residual add that cannot ride in a convolution's epilogue (its left operand is not a convolution,
+//                 or that convolution's output has other readers) runs as an element-wise kernel.
+enum StepMode { STEP_NORMAL = 0, STEP_REP = 1, STEP_PARTIAL = 2, STEP_MAIN = 3, STEP_GATHER = 4, STEP_ADD = 5 };
 struct Step {
     int layer; View in;
     int mode = STEP_NORMAL;
+    bool is_conv() const { return mode <= STEP_MAIN; }
     int c_lo = 0, c_hi = 0;        // input-channel range of the layer's Cin this launch convolves
     int out_tensor = -1;           // tensor id written (layer index, or n_layers + aux index)
     int addend_tensor = -1;        // STEP_MAIN: the PARTIAL result
@@ -118,6 +126,8 @@ struct byolo {
     int backbone_end = -1;
     bool finalized = false;        // weights folded, packed and uploaded
     bool lowered = false;          // graph frozen and lowered to steps (host only)
+    std::vector<char> need_mat;    // per layer: this view is copied into a tensor of its own (STEP_GATHER)
+    mutable int want_mat = -1;     // lowering: the view whose materialisation would resolve the last failure
     std::vector<Step> steps;
     std::vector<AuxTensor> aux;    // auxiliary tensors (ids n_layers + k): partial sums of split convs
     bool dedup = true;             // T-invariant de-duplication (BYOLO_NO_DEDUP=1 disables, for A/B)
@@ -379,9 +389,13 @@ extern "C" int32_t byolo_get_param(const byolo_t* h, const char* name, float* da
 // ------------------------------------------------------------------------------------------------
 // lowering
 // ------------------------------------------------------------------------------------------------
-static bool resolve_view(const byolo_t* h, int idx, View& v, std::string& why) {
+// `self`: resolve the sources of view `idx` itself (for its STEP_GATHER), not the tensor it was materialised into
+static bool resolve_view(const byolo_t* h, int idx, View& v, std::string& why, bool self = false) {
     if (idx < 0) { v.n = 1; v.s[0] = {-1, h->cfg.img_c, 0, false}; return true; }
     const Layer& l = h->layers[idx];
+    if (!self && idx < (int)h->need_mat.size() && h->need_mat[idx]) {       // a view with a tensor of its own
+        v.n = 1; v.s[0] = {idx, l.C, 0, false}; return true;
+    }
     switch (l.op) {
         case OP_CONV: case OP_DETECTION: case OP_RESIDUAL:
             if (!l.materialized) { why = "layer " + std::to_string(idx) + " is fused away but referenced"; return false; }
@@ -390,12 +404,12 @@ static bool resolve_view(const byolo_t* h, int idx, View& v, std::string& why) {
             if (l.nref == 1) return resolve_view(h, l.ref[0], v, why);
             View a, b;
             if (!resolve_view(h, l.ref[0], a, why) || !resolve_view(h, l.ref[1], b, why)) return false;
-            if (a.n != 1 || b.n != 1) { why = "nested concat"; return false; }
+            if (a.n != 1 || b.n != 1) { why = "nested concat"; h->want_mat = a.n != 1 ? l.ref[0] : l.ref[1]; return false; }
             v.n = 2; v.s[0] = a.s[0]; v.s[1] = b.s[0]; return true;
         }
         case OP_UPSAMPLE:
             if (!resolve_view(h, l.prev, v, why)) return false;
-            for (int i = 0; i < v.n; ++i) { if (v.s[i].sh) { why = "double upsample"; return false; } v.s[i].sh = 1; }
+            for (int i = 0; i < v.n; ++i) { if (v.s[i].sh) { why = "double upsample"; h->want_mat = l.prev; return false; } v.s[i].sh = 1; }
             return true;
         case OP_STACK:
             if (!resolve_view(h, l.ref[0], v, why)) return false;
@@ -405,10 +419,10 @@ static bool resolve_view(const byolo_t* h, int idx, View& v, std::string& why) {
     return false;
 }
 
-static int32_t lower(byolo_t* h) {
+static bool is_view_op(Op op) { return op == OP_ROUTE || op == OP_UPSAMPLE || op == OP_STACK; }
+
+static int32_t lower_once(byolo_t* h) {
     const int n = (int)h->layers.size();
-    if (!n) return fail(h, BYOLO_ERR_STATE, "byolo_finalize: empty graph");
-    if (!h->n_det) return fail(h, BYOLO_ERR_STATE, "byolo_finalize: no detection layer (model.py:190: assert len(det_layers) > 0)");
     // reference counts
     std::vector<int> refs(n, 0);
     for (int i = 0; i < n; ++i) {
@@ -416,27 +430,32 @@ static int32_t lower(byolo_t* h) {
         if ((l.op == OP_CONV || l.op == OP_DETECTION || l.op == OP_RESIDUAL || l.op == OP_UPSAMPLE) && l.prev >= 0) refs[l.prev]++;
         for (int k = 0; k < l.nref; ++k) refs[l.ref[k]]++;
     }
-    for (auto& l : h->layers) { l.materialized = false; l.out_tensor = -1; l.fused_residual = -1; }
+    for (auto& l : h->layers) { l.materialized = false; l.out_tensor = -1; l.fused_residual = -1; l.standalone = false; l.add_a = -1; }
     for (int i = 0; i < n; ++i) {
         Layer& l = h->layers[i];
-        if (l.op == OP_CONV || l.op == OP_DETECTION) { l.materialized = true; l.out_tensor = i; }
+        if (l.op == OP_CONV || l.op == OP_DETECTION || (is_view_op(l.op) && h->need_mat[i])) { l.materialized = true; l.out_tensor = i; }
     }
+    // an operand of a residual add is read as a dense [rows][C] tensor: the output of a convolution, of an earlier
+    // residual, or a view that has been given a tensor; identity routes in between are looked through
+    auto as_tensor = [&](int a) -> int {
+        while (h->layers[a].op == OP_ROUTE && h->layers[a].nref == 1 && !h->need_mat[a]) a = h->layers[a].ref[0];
+        if (h->layers[a].materialized && h->layers[a].out_tensor == a) return a;
+        if (is_view_op(h->layers[a].op)) h->want_mat = a;       // lower() gives it a tensor and tries again
+        return -1;
+    };
     for (int i = 0; i < n; ++i) {
         Layer& l = h->layers[i];
         if (l.op != OP_RESIDUAL) continue;
         Layer& c = h->layers[l.prev];
-        // the epilogue reads the shortcut as a dense [rows][C] tensor: it must be a tensor of its own (the output of a
-        // convolution or of an earlier residual), possibly seen through identity routes -- not an upsample / stack /
-        // concat view, which exists only inside a loader
-        int a = l.ref[0];
-        while (h->layers[a].op == OP_ROUTE && h->layers[a].nref == 1) a = h->layers[a].ref[0];
-        if (!(h->layers[a].materialized && h->layers[a].out_tensor == a))
-            return fail(h, BYOLO_ERR_ARG, "byolo_finalize: residual layer %d: the shortcut must be the output of a convolution or residual layer", i);
+        const int a = as_tensor(l.ref[0]);
+        if (a < 0) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: residual layer %d: the shortcut is not a tensor", i);
         l.ref[0] = a;
-        if (c.op == OP_CONV && refs[l.prev] == 1 && c.fused_residual < 0 && l.ref[0] != l.prev) {
+        if (c.op == OP_CONV && refs[l.prev] == 1 && c.fused_residual < 0 && a != l.prev) {
             c.materialized = false; c.fused_residual = i; c.out_tensor = i; l.materialized = true; l.out_tensor = i;
-        } else {
-            return fail(h, BYOLO_ERR_ARG, "byolo_finalize: residual layer %d cannot be fused into a producing conv", i);
+        } else {                                            // its own element-wise step
+            const int left = as_tensor(l.prev);
+            if (left < 0) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: residual layer %d: the left operand is not a tensor", i);
+            l.standalone = true; l.add_a = left; l.materialized = true; l.out_tensor = i;
         }
     }
     h->steps.clear();
@@ -445,6 +464,28 @@ static int32_t lower(byolo_t* h) {
     { const char* e = getenv("BYOLO_NO_DEDUP"); h->dedup = !(e && atoi(e)); }
     for (int i = 0; i < n; ++i) {
         Layer& l = h->layers[i];
+        if (is_view_op(l.op) && h->need_mat[i]) {           // copy the view into its tensor
+            Step g; g.layer = i; g.mode = STEP_GATHER; g.out_tensor = i;
+            std::string why;
+            if (!resolve_view(h, i, g.in, why, true)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d: %s", i, why.c_str());
+            const int gi = (int)h->steps.size();
+            for (int k = 0; k < g.in.n; ++k) {
+                const Src& s = g.in.s[k];
+                if (s.layer >= 0) h->last_use[s.layer] = gi;
+                if (l.stacked && !(s.layer >= 0 && h->layers[s.layer].stacked) && !s.tile)
+                    return fail(h, BYOLO_ERR_ARG, "byolo_finalize: layer %d mixes stacked and unstacked inputs", i);
+            }
+            h->steps.push_back(g);
+            continue;
+        }
+        if (l.op == OP_RESIDUAL && l.standalone) {
+            Step a; a.layer = i; a.mode = STEP_ADD; a.out_tensor = i;
+            a.in.n = 2; a.in.s[0] = {l.add_a, l.C, 0, false}; a.in.s[1] = {l.ref[0], l.C, 0, false};
+            const int ai = (int)h->steps.size();
+            h->last_use[l.add_a] = ai; h->last_use[l.ref[0]] = ai;
+            h->steps.push_back(a);
+            continue;
+        }
         if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
         Step st; st.layer = i; st.out_tensor = l.out_tensor; st.c_lo = 0; st.c_hi = l.Cin;
         std::string why;
@@ -492,6 +533,7 @@ static int32_t lower(byolo_t* h) {
     }
     // launch geometry that depends on the graph only (byolo_workspace_bytes may plan before byolo_finalize)
     for (auto& st : h->steps) {
+        if (!st.is_conv()) continue;
         const Layer& l = h->layers[st.layer];
         const int N = l.filters;
         if (l.direct) { st.tile = -1; st.Npad = N; }
@@ -503,6 +545,22 @@ static int32_t lower(byolo_t* h) {
     for (const auto& l : h->layers) h->maxC = std::max(h->maxC, l.C);
     h->lowered = true;
     return BYOLO_OK;
+}
+
+// Lower the graph; where a view cannot be expressed inside a loader, give that view a tensor of its own and try again
+// (at most once per layer).
+static int32_t lower(byolo_t* h) {
+    const int n = (int)h->layers.size();
+    if (!n) return fail(h, BYOLO_ERR_STATE, "byolo_finalize: empty graph");
+    if (!h->n_det) return fail(h, BYOLO_ERR_STATE, "byolo_finalize: no detection layer (model.py:190: assert len(det_layers) > 0)");
+    h->need_mat.assign(n, 0);
+    for (int attempt = 0; ; ++attempt) {
+        h->want_mat = -1;
+        const int32_t rc = lower_once(h);
+        if (rc == BYOLO_OK) return rc;
+        if (h->want_mat < 0 || h->need_mat[h->want_mat] || attempt > n) return rc;
+        h->need_mat[h->want_mat] = 1;
+    }
 }
 
 static float* dptr(const byolo_t* h, size_t off) { return h->d_blob + off; }
@@ -538,6 +596,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
     // layout of the device blob
     size_t off = 0; const int maxC = h->maxC;
     for (auto& st : h->steps) {
+        if (!st.is_conv()) continue;
         Layer& l = h->layers[st.layer];
         const int Cs = st.c_hi - st.c_lo, K = l.ksize * l.ksize * Cs, N = l.filters;
         st.w_off = off; off += align_up((size_t)K * st.Npad, 64);      // tile / Npad / wino_ok: set by lower()
@@ -551,6 +610,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
     std::vector<float> blob(off, 0.f);
     std::vector<float> sc, sf;
     for (auto& st : h->steps) {
+        if (!st.is_conv()) continue;
         const Layer& l = h->layers[st.layer];
         const int Cs = st.c_hi - st.c_lo, taps = l.ksize * l.ksize, N = l.filters;
         const float* w = h->params[l.p_kernel].data.data();     // HWIO == [K][N], k = (ky*ks + kx)*Cin + c
@@ -676,7 +736,7 @@ static void make_plan(byolo_t* h, int B, int T) {
     for (size_t si = 0; si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
-        if (l.direct) continue;
+        if (!s.is_conv() || l.direct) continue;
         int M, KT; step_geometry(h, s, B, T, &M, &KT);
         // Grid fill: a 128x128 tiling of a small-M layer (deep backbone layers at small batch) leaves CUs
         // idle; the 128x64 tile doubles the block count (the packed weight layout [K/32][Npad][32] does not
@@ -837,6 +897,14 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.d_addT = make_fastdiv((uint32_t)p.addend_T);
 }
 
+// STEP_GATHER / STEP_ADD (fill_conv has resolved the sources, the output extent and the destination)
+static int32_t run_aux_step(byolo_t* h, const Step& s, const ConvParams& p, hipStream_t st) {
+    const Layer& l = h->layers[s.layer];
+    if (s.mode == STEP_GATHER) { HIPCHK(h, launch_view_gather(p, st)); }
+    else { HIPCHK(h, launch_tensor_add(p.src0, p.src1, p.dst, (int64_t)p.M * l.C, st)); }
+    return BYOLO_OK;
+}
+
 // profiling level 2: event + bookkeeping entry before a launch of the convolution stack
 static int32_t mark_launch(byolo_t* h, int layer, int variant, int64_t m, int64_t n, int64_t k, double algo, hipStream_t st) {
     while (h->step_ev.size() < h->launches.size() + 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->step_ev.push_back(e); }
@@ -976,6 +1044,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
             HIPCHK(h, hipEventRecord(h->ev[1], st)); backbone_marked = true;
         }
         ConvParams p; fill_conv(h, s, d_img, ws, B, T, p);
+        if (!s.is_conv()) { rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
         if (l.op == OP_CONV && s.mode != STEP_PARTIAL) {
             p.flags = EPI_LEAKY;
             if (l.drop_ordinal >= 0 && dropout_on) {
@@ -1098,6 +1167,7 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
     for (const Step& s : h->steps) {
         Layer& l = h->layers[s.layer];
         ConvParams p; fill_conv(h, s, d_img, ws, B, 1, p);
+        if (!s.is_conv()) { int32_t rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
         if (l.op == OP_DETECTION) { HIPCHK(h, launch_conv_igemm(p, s.tile, st)); continue; }
         p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = 0;             // raw conv output (+ addend for STEP_MAIN)
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, s.tile, st));

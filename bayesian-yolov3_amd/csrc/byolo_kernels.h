@@ -137,6 +137,9 @@ enum : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };
 int conv_tile_bn(int tile);           // BN of a tile config
 int conv_pick_tile(int N);            // tile config for cout = N
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st);
+// a route / upsample / stack view copied into a dense [M][C0 + C1] tensor (sources, extents and dst as in ConvParams)
+hipError_t launch_view_gather(const ConvParams& p, hipStream_t st);
+hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, hipStream_t st);   // dst = a + b
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st);   // small-cin (stem) direct conv
 
 // ---- calibration helpers -------------------------------------------------------------------

@@ -140,6 +140,38 @@ hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// A view as a tensor (STEP_GATHER of byolo_api.hip): dst[m][c] = the element the convolution loader would have read --
+// source 0 or 1 by channel, nearest x2 upsampling as (y >> 1, x >> 1), the T-fold sample tile as sample / T.
+// And the residual add that does not ride in a convolution's epilogue.  Neither is on the reference models' path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void view_gather_kernel(const ConvParams p) {
+    const int C = p.C0 + p.C1, hw = p.Hout * p.Wout;
+    const int64_t total = (int64_t)p.M * C;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = gid / C;
+        const int c = (int)(gid - m * C);
+        const int s = (int)(m / hw), rem = (int)(m - (int64_t)s * hw);
+        const int y = rem / p.Wout, x = rem - y * p.Wout;
+        float v;
+        if (c < p.C0) v = p.src0[(((size_t)(s / p.sdiv0) * p.Hs0 + (y >> p.sh0)) * p.Ws0 + (x >> p.sh0)) * p.C0 + c];
+        else v = p.src1[(((size_t)(s / p.sdiv1) * p.Hs1 + (y >> p.sh1)) * p.Ws1 + (x >> p.sh1)) * p.C1 + (c - p.C0)];
+        p.dst[gid] = v;
+    }
+}
+__global__ __launch_bounds__(256) void tensor_add_kernel(const float* a, const float* b, float* d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = a[i] + b[i];
+}
+static unsigned grid_for(int64_t n) { int64_t b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 256 * 32 ? 256 * 32 : b)); }
+hipError_t launch_view_gather(const ConvParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(view_gather_kernel, dim3(grid_for((int64_t)p.M * (p.C0 + p.C1))), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(tensor_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, b, dst, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // calibration helpers (byolo_calibrate_bn): per-channel batch statistics, device-side BN fold,
 // in-place BN + leaky [+ residual].  Not on the inference hot path.
 // ---------------------------------------------------------------------------------------------

@@ -67,15 +67,17 @@ BYOLO_API const char* byolo_version(void);
  * (model.py:40-41) or a negative error.  Layer references (`shortcut`, `routes`, `src`) follow
  * the reference: negative = relative to the end of the list, non-negative = absolute.
  *
- * Route / upsample / stack layers are VIEWS: they exist only inside the loader of the convolution that reads them.
- * What the reference's three models build is covered; a general ModelBuilder graph meets these limits, reported by
- * byolo_finalize / byolo_workspace_bytes (never at run time):
- *   - a convolution reads at most two concatenated sources, each upsampled at most once ("nested concat",
- *     "double upsample" need a convolution in between);
- *   - a residual add follows a convolution whose output nothing else reads, and its shortcut is the output of a
- *     convolution or residual layer (identity routes in between are resolved);
- *   - channel counts are free: input channels that are not a multiple of 32 (per concatenated source) take a general
- *     direct kernel instead of the matrix-pipe one -- correct, slow. ------------------------------------------ */
+ *
+ * Route / upsample / stack layers are VIEWS: they exist only inside the loader of the convolution that reads them
+ * (two concatenated sources, each upsampled at most once), and a residual add rides in the epilogue of the
+ * convolution in front of it.  That covers everything the reference's three models build at no cost.  A general
+ * ModelBuilder graph is accepted as well; what does not fit is lowered to plain steps of its own:
+ *   - the inner view of a nested concat / double upsample, or a view used as an operand of a residual add, is
+ *     copied into a tensor first;
+ *   - a residual add whose left operand is not a convolution, or whose convolution has other readers, runs as an
+ *     element-wise kernel;
+ *   - input channels that are not a multiple of 32 (per concatenated source) take a general direct convolution
+ *     instead of the matrix-pipe one -- correct, slow. ---------------------------------------------------------- */
 
 /* make_conv_layer / make_downsample_layer / make_darknet_conv_layer / make_darknet_downsample_layer
  * (model.py:52-81 -> layers.conv, lib_yolo/layers.py:545-575): conv(no bias) -> [dropout] -> BN

@@ -68,7 +68,7 @@ def one_case(rng, idx):
             k = int(rng.choice([1, 3]))
             stride = 2 if (k == 3 and rng.random() < 0.3 and last["h"] % 2 == 0 and last["w"] % 2 == 0 and min(last["h"], last["w"]) >= 4) else 1
             conv(last, int(rng.choice(FILTERS)), k, stride, BN | (DROP if rng.random() < 0.35 else 0))
-        elif op == "res" and last["op"] == "conv":
+        elif op == "res":
             cands = [j for j, r in enumerate(L[:-1]) if (r["h"], r["w"], r["c"], r["stacked"]) == (last["h"], last["w"], last["c"], last["stacked"])]
             if cands:
                 j = int(rng.choice(cands))
