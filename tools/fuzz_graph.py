@@ -153,6 +153,21 @@ def one_case(rng, idx):
         worst = max(worst, assert_close(got, want, "case %d layer %d (%s)" % (idx, i, "det" if i == det_idx else L[i]["op"]),
                                         rtol=3e-4, atol=3e-4))
         checked += 1
+    # the same batch in two calls (first_image tells the second where it sits in the logical batch): equal to
+    # the unsplit run -- what sub-batching and the one-shard-per-GPU mode rely on (dropout masks are indexed by position)
+    if B >= 2:
+        whole = eng.layer_output(det_idx).clone()
+        k = int(rng.integers(1, B))
+        S = run_T if stacked else 1
+        parts = []
+        for lo, hi in ((0, k), (k, B)):
+            eng.forward(torch.from_numpy(img[lo:hi]).cuda(), T=run_T, seed=seed, want_boxes=True, want_nms=False, first_image=lo)
+            parts.append(eng.layer_output(det_idx).clone())
+        torch.cuda.synchronize()
+        # (same masks; the launch plan -- tile shape, K slices -- may differ with the batch size, so the float32
+        # summation order may too: a wrong mask is an O(1) difference, this is 1e-4)
+        assert_close(torch.cat(parts, 0).cpu().numpy(), whole.cpu().numpy(), "case %d: split batch (%d + %d images) vs the whole" % (idx, k, B - k))
+        assert whole.shape[0] == B * S
     eng.close()
     assert checked >= 2
     return "| %d | %dx%d B=%d T=%d | %s | %d of %d layers compared, max abs err %.1e |" % (
