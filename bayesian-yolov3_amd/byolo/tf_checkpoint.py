@@ -145,6 +145,9 @@ def _masked_crc(data):
 
 
 def _read_block(f, offset, size, verify):
+    end = os.fstat(f.fileno()).st_size
+    if offset < 0 or size < 0 or offset + size + 5 > end:     # a corrupt handle must not become a giant read
+        raise IOError('table block handle outside the file')
     f.seek(offset)
     raw = f.read(size + 5)
     if len(raw) < size + 5:
@@ -174,7 +177,14 @@ def _block_entries(block):
 
 
 def read_index(prefix, verify=True):
-    """{name: entry dict} plus the header under key ''."""
+    """{name: entry dict} plus the header under key ''.  A malformed file raises IOError."""
+    try:
+        return _read_index(prefix, verify)
+    except (IndexError, struct.error, UnicodeDecodeError, TypeError, ValueError, OverflowError, MemoryError) as e:
+        raise IOError('corrupt checkpoint index %s.index: %s' % (prefix, e))
+
+
+def _read_index(prefix, verify):
     path = prefix + '.index'
     out = {}
     with open(path, 'rb') as f:
@@ -220,13 +230,18 @@ def read(prefix, names=None, verify=True):
             if sid not in files:
                 files[sid] = open('%s.data-%05d-of-%05d' % (prefix, sid, header['num_shards']), 'rb')
             f = files[sid]
+            if e['offset'] < 0 or e['size'] < 0 or e['offset'] + e['size'] > os.fstat(f.fileno()).st_size:
+                raise IOError('truncated data for %s' % name)
             f.seek(e['offset'])
             raw = f.read(e['size'])
             if len(raw) != e['size']:
                 raise IOError('truncated data for %s' % name)
             if verify and e['crc32c'] is not None and _masked_crc(raw) != e['crc32c']:
                 raise IOError('data CRC mismatch for %s' % name)
-            out[name] = np.frombuffer(raw, dtype=dt).reshape(e['shape']).copy()
+            try:
+                out[name] = np.frombuffer(raw, dtype=dt).reshape(e['shape']).copy()
+            except (ValueError, TypeError) as err:
+                raise IOError('corrupt entry for %s: %s' % (name, err))
     finally:
         for f in files.values():
             f.close()

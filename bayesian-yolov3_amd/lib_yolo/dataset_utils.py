@@ -13,6 +13,7 @@ batches and prefetches one batch; this iterator does the same in sorted file ord
 import ctypes
 import glob
 import io
+import os
 import struct
 
 import numpy as np
@@ -31,6 +32,7 @@ def _masked_crc(data):
 
 def read_tfrecords(path, verify_crc=True):
     """Yield the payload bytes of every record in a TFRecord file."""
+    size = os.path.getsize(path)
     with open(path, 'rb') as f:
         while True:
             head = f.read(12)
@@ -42,6 +44,8 @@ def read_tfrecords(path, verify_crc=True):
             len_crc, = struct.unpack('<I', head[8:])
             if verify_crc and _masked_crc(head[:8]) != len_crc:
                 raise IOError('corrupt TFRecord length CRC in {}'.format(path))
+            if length > size - f.tell():              # a corrupt length must not turn into a giant read
+                raise IOError('truncated TFRecord in {}'.format(path))
             data = f.read(length)
             tail = f.read(4)
             if len(data) < length or len(tail) < 4:
@@ -63,6 +67,8 @@ def write_tfrecords(path, payloads):
 def _varint(buf, pos):
     out = shift = 0
     while True:
+        if pos >= len(buf) or shift > 63:
+            raise ValueError('corrupt protobuf varint')
         b = buf[pos]
         pos += 1
         out |= (b & 0x7F) << shift
@@ -80,6 +86,8 @@ def _fields(buf):
             val, pos = _varint(buf, pos)
         elif wt == 2:
             ln, pos = _varint(buf, pos)
+            if ln > n - pos:
+                raise ValueError('corrupt protobuf length')
             val = buf[pos:pos + ln]
             pos += ln
         elif wt == 1:
@@ -94,7 +102,14 @@ def _fields(buf):
 
 
 def parse_example(data):
-    """tf.train.Example -> {feature name: list of bytes / int / float values}."""
+    """tf.train.Example -> {feature name: list of bytes / int / float values}.  Malformed input raises ValueError."""
+    try:
+        return _parse_example(data)
+    except (IndexError, TypeError, OverflowError, UnicodeDecodeError) as e:
+        raise ValueError('corrupt tf.train.Example: {}'.format(e))
+
+
+def _parse_example(data):
     out = {}
     for num, _, features in _fields(data):
         if num != 1:                                  # Example.features

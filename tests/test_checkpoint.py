@@ -138,3 +138,35 @@ def test_find_and_restore(tmp_path):
     m.engine.set_params(tc.read(os.path.splitext(path)[0]), strict=True)
     for k, v in params.items():
         assert np.array_equal(m.engine.get_param(k, v.shape), v)
+
+
+def test_corrupt_files_raise_io_errors(tmp_path):
+    """Random damage to either file of a checkpoint (byte flips, deletions, insertions; found by an ad-hoc fuzz: struct /
+    index / decode errors and a MemoryError from a corrupt length used to escape): the reader either returns the
+    tensors or raises IOError / NotImplementedError -- never another exception type, never a giant allocation."""
+    import glob
+    import random
+    prefix = str(tmp_path / "model.ckpt-1")
+    tc.write(prefix, _tensors())
+    files = {f: open(f, "rb").read() for f in glob.glob(prefix + "*")}
+    rnd = random.Random(3)
+    outcomes = set()
+    for i in range(400):
+        for f, good in files.items():
+            b = bytearray(good)
+            for _ in range(rnd.randint(0, 3)):
+                op = rnd.randint(0, 2)
+                if op == 0:
+                    b[rnd.randrange(len(b))] = rnd.randrange(256)
+                elif op == 1:
+                    del b[rnd.randrange(len(b)):][:rnd.randint(1, 40)]
+                else:
+                    at = rnd.randrange(len(b))
+                    b[at:at] = bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 16)))
+            open(f, "wb").write(bytes(b))
+        try:
+            tc.read(prefix, verify=bool(i % 2))
+            outcomes.add("ok")
+        except (IOError, NotImplementedError):
+            outcomes.add("refused")
+    assert outcomes == {"ok", "refused"}

@@ -195,3 +195,36 @@ def test_vis_uncertainty_do_it(tmp_path):
     assert "frame_prior0_epi_x.png" in files and "frame_prior8_obj_mutual_info.png" in files
     im = np.asarray(Image.open(tmp_path / "maps" / "frame_prior4_ale_w.png"))
     assert im.shape == (64, 96, 3) and im.dtype == np.uint8
+
+
+def test_corrupt_tfrecords_raise_cleanly(tmp_path):
+    """Damaged TFRecord files: IOError from the framing, ValueError from the Example parser -- no other exception type,
+    no giant read from a corrupt length (ad-hoc fuzz finding)."""
+    import random
+    from lib_yolo import dataset_utils as du
+    ex = du.make_example({"image/encoded": _png(np.zeros((8, 8, 3), np.uint8)), "image/filename": b"a.png",
+                          "image/height": 8, "image/width": 8})
+    path = str(tmp_path / "x.tfrecord")
+    du.write_tfrecords(path, [ex, ex])
+    good = open(path, "rb").read()
+    rnd = random.Random(4)
+    seen = set()
+    for i in range(600):
+        b = bytearray(good)
+        for _ in range(rnd.randint(1, 3)):
+            op = rnd.randint(0, 2)
+            if op == 0:
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+            elif op == 1:
+                del b[rnd.randrange(len(b)):][:rnd.randint(1, 30)]
+            else:
+                at = rnd.randrange(len(b))
+                b[at:at] = bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 12)))
+        open(path, "wb").write(bytes(b))
+        try:
+            for rec in du.read_tfrecords(path, verify_crc=bool(i % 2)):
+                du.parse_example(rec)
+            seen.add("ok")
+        except (IOError, ValueError):
+            seen.add("refused")
+    assert seen == {"ok", "refused"}
