@@ -23,12 +23,12 @@ BN, DROP = 1, 2
 FILTERS = [8, 16, 24, 32, 40, 48, 64, 96, 128, 192, 256]
 
 
-def one_case(rng, idx):
+def one_case(rng, idx, max_cells=5):
     import torch
     from byolo import Engine, ByoloError
     from conftest import assert_close
     from test_gpu_layers import _ref_conv, _random_params
-    H, W = int(rng.integers(1, 6)) * 32, int(rng.integers(1, 6)) * 32
+    H, W = int(rng.integers(1, max_cells + 1)) * 32, int(rng.integers(1, max_cells + 1)) * 32
     B, T = int(rng.integers(1, 4)), int(rng.integers(1, 5))
     prob = float(rng.choice([0.1, 0.25, 0.5]))
     for k in ("BYOLO_WINOGRAD", "BYOLO_WINO_FUSED", "BYOLO_KSPLIT"):
@@ -178,6 +178,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-cells", type=int, default=5, help="image sides up to 32 * this")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     print("| # | input | graph | result |\n|---|---|---|---|")
@@ -185,7 +186,7 @@ def main():
     t0 = time.time()
     for i in range(a.cases):
         try:
-            line, worst = one_case(rng, i)
+            line, worst = one_case(rng, i, a.max_cells)
             refused += worst is None
             print(line, flush=True)
         except Exception as e:
