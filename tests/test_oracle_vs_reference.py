@@ -1,0 +1,58 @@
+"""The CPU restatement against the REFERENCE'S OWN graph code, live: `lib_yolo/{yolov3,model,layers}.py` and the
+`inference_*` helpers imported from /root/reference and executed unmodified under oracle/tf1_shim.py -- on weights,
+images, image size, T and dropout seed that are NOT the ones the committed fixtures were generated with (the fixtures
+pin one configuration; this keeps the restatement from being fitted to it).
+
+Runs only where the reference is mounted (the build container); skipped on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (build container only)")
+
+VARIANTS = ("yolov3", "yolov3_aleatoric", "bayesian_yolov3_aleatoric")
+H, W, T, SEED_W, SEED_DROP = 32, 64, 2, 21, 77
+
+
+def _params(variant):
+    from oracle import cpu_ref
+    from byolo import synth
+    # BN statistics calibrated once with the restatement (oracle/make_golden.py:81-90 does the same for the fixtures)
+    shapes = cpu_ref.variable_shapes("yolov3_aleatoric", 2)
+    p = cpu_ref.to_torch_params(synth.base_params(shapes, "yolov3_aleatoric", 2, seed=SEED_W))
+    cpu_ref.forward(p, synth.synthetic_images(32, H, W, seed=5), "yolov3_aleatoric", calibrate=True)
+    stats = {k: v.numpy() for k, v in p.items() if k.endswith("moving_mean") or k.endswith("moving_variance")}
+    out = synth.base_params(cpu_ref.variable_shapes(variant, 2), variant, 2, seed=SEED_W)
+    for k, v in stats.items():
+        out[k] = v.astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_restatement_equals_reference_graph_code(variant, monkeypatch):
+    from oracle import cpu_ref, make_golden as mg
+    from byolo import synth
+    monkeypatch.setattr(mg, "H", H)
+    monkeypatch.setattr(mg, "W", W)
+    params = _params(variant)
+    B = 1 if variant.startswith("bayes") else 2            # the reference asserts batch 1 in epistemic mode
+    imgs = synth.synthetic_images(B, H, W, seed=31)
+    ref = mg.run_reference(variant, params, imgs, torch.float32, seed=SEED_DROP, T=T)
+    with torch.no_grad():
+        boxes, f = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params), imgs, variant, T=T, seed=SEED_DROP)
+    for k in range(3):
+        assert_close(f["raw"][k].numpy(), ref["raw"][k], "%s raw detection output %d" % (variant, k), rtol=1e-5, atol=1e-5)
+    rb = ref["bbox"] if ref["bbox"].ndim == 3 else ref["bbox"][None]
+    assert_close(boxes.numpy(), rb, "%s pre-NMS rows" % variant, rtol=1e-5, atol=1e-5)
+    # NMS of the reference's rows: the restated tail on the same rows keeps the same boxes
+    mine = cpu_ref.nms_batch(torch.from_numpy(rb), variant)
+    for b in range(rb.shape[0]):
+        assert np.array_equal(mine[b][0], ref["nms_rows"][b]), "%s image %d: NMS rows differ" % (variant, b)
+    # structure: variables in creation order, layer count, row layout
+    assert ref["var_names"] == list(cpu_ref.variable_shapes(variant, 2))
+    assert (ref["obj_idx"], ref["cls_start_idx"]) == cpu_ref.row_layout(variant, 2)[1:]
