@@ -10,9 +10,10 @@
 // xi = 15 the lanes hold finished pre-activation outputs: dropout mask, BN scale / shift, leaky, residual, 16-byte NHWC
 // stores -- the same epilogue as conv_igemm.hip / winograd.hip.
 //
-// Cost: the fold (72 vector-ALU instructions per xi on average + 32 to clear) and the epilogue run on the SIMDs that
-// multiply, where a vector-ALU instruction is paid in matrix-pipe time (tools/mfma_peak.hip): ~12 % at K = 128, ~3 % at
-// K = 512.  Gain: no M (write + read of 4x the output), no output-transform launch.
+// Cost: the fold (36 packed multiply-adds per xi on average; no clears: the first MFMA of a transform point takes a zero
+// C operand, the first fold into an output assigns) and the epilogue run on the SIMDs that multiply, where a vector-ALU
+// instruction is paid in matrix-pipe time (tools/mfma_peak.hip): ~10 % at K = 128, ~3 % at K = 512 (ablation table in
+// DESIGN.md section 3).  Gain: no M (write + read of 4x the output), no output-transform launch.
 // Block = 4 waves as 2 (rows) x 2 (columns), wave tile 64 tiles x 32 channels; LDS image, fragment scheme and
 // interleaving as in conv_igemm.hip; persistent grid and XCD placement as in gemm_stream.hip.
 #include <hip/hip_runtime.h>
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     const uint32_t r0 = slot * (uint32_t)p.q + (slot < (uint32_t)p.rem ? slot : (uint32_t)p.rem);   // first row tile
     const int cnt = p.q + (slot < (uint32_t)p.rem ? 1 : 0);
     if (cnt <= 0) return;
-    const int KT = p.KT, total = cnt * 16 * KT;
+    const int KT = p.KT;
     // The epilogue's per-channel constants live in LDS: read from global memory inside the epilogue, every group
     // of 4 channels waited on vmcnt -- which also counts the stores of the group before it -- and the epilogue ran at
     // memory latency (32 round trips per row tile).  (Visible after the pipeline's first barrier.)
@@ -150,26 +151,16 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
 
     f32x16 acc[TM];                               // M[xi] of this wave's 64 tiles x 32 channels (transposed: rows = channels)
     f32x16 Y[4][TM];                              // the four outputs (dy, dx) of every tile
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    };
-    auto zero_y = [&]() {
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Y[o][i][r] = 0.f;
-    };
-    zero_acc(); zero_y();
-    auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+    // Neither accumulator set is ever cleared with vector-ALU moves: the first MFMA of a transform point takes a zero C
+    // operand (an inline constant), and the first fold into each output assigns instead of adding.
+    auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[0][s], af[i][s], acc[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[0][s], af[i][s], (FIRST && s == 0) ? zero : acc[i], 0, 0, 0);
     };
 
     // Y[dy][dx] += A^T[dy][i] * A^T[dx][j] * M[xi = 4 i + j];   A^T = [1 1 1 0; 0 1 -1 -1]
@@ -184,13 +175,21 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
             for (int dx = 0; dx < 2; ++dx) {
                 const float c = cy[dy] * cx[dx];
                 if (c != 0.f) {                   // block-uniform
+                    // the first transform point that reaches output (dy, dx) is xi = 5 dy ... : (0,0) <- 0, (0,1) <- 1,
+                    // (1,0) <- 4, (1,1) <- 5
+                    if (xi == 4 * dy + dx) {
 #pragma unroll
-                    for (int t = 0; t < TM; ++t)
+                        for (int t = 0; t < TM; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) Y[dy * 2 + dx][t][r] += c * acc[t][r];
+                            for (int r = 0; r < 16; ++r) Y[dy * 2 + dx][t][r] = c * acc[t][r];
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < TM; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) Y[dy * 2 + dx][t][r] += c * acc[t][r];
+                    }
                 }
             }
-        zero_acc();
     };
 
     // ---- epilogue of one finished row tile (128 output tiles): lane = tile li (+32 per t), 4 x 4 consecutive channels ----
@@ -251,7 +250,6 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
                 }
             }
         }
-        zero_y();
     };
 
     // ---- the pipeline ---------------------------------------------------------------------------------------------
@@ -268,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     __syncthreads();
     read_frags(c0{}, c0{}, af0, bf0);
 
-    auto tile_body = [&](auto buf_tag, auto has_next_tag, auto load_tag) {
+    auto tile_body = [&](auto buf_tag, auto has_next_tag, auto load_tag, auto first_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         using cur = std::integral_constant<int, BUF>;
         using nxt = std::integral_constant<int, BUF ^ 1>;
@@ -279,49 +277,45 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LD) load_b(b_far);
         read_frags(cur{}, c1{}, af1, bf1);
-        mfma_group(af0, bf0);
+        mfma_group(af0, bf0, first_tag);
         wf_interleave<G, LD ? B_LD : 0, NFR, 0>();
         __builtin_amdgcn_sched_barrier(0);
 
         read_frags(cur{}, c2{}, af0, bf0);
-        mfma_group(af1, bf1);
+        mfma_group(af1, bf1, no{});
         wf_interleave<G, 0, NFR, 0>();
         __builtin_amdgcn_sched_barrier(0);
 
         read_frags(cur{}, c3{}, af1, bf1);
         if constexpr (HN) store_tile(nxt{}, b_near);
-        mfma_group(af0, bf0);
+        mfma_group(af0, bf0, no{});
         wf_interleave<G, 0, NFR, HN ? NLD : 0>();
         __builtin_amdgcn_sched_barrier(0);
 
         __syncthreads();
         if constexpr (LD) load_a();
         if constexpr (HN) read_frags(nxt{}, c0{}, af0, bf0);
-        mfma_group(af1, bf1);
+        mfma_group(af1, bf1, no{});
         wf_interleave<G, LD ? A_LD : 0, HN ? NFR : 0, 0>();
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // KT is even: a transform point ends after the second tile of a pair
-    const int half = KT >> 1;
-    int pair_in_xi = 0, xi = 0;
+    // One unit = one transform point of one row tile = KT K-tiles (KT is even: tiles go in pairs over the two LDS
+    // buffers).  Every tile prefetches the tile two ahead, also the last two of the stream: those loads run past the
+    // slot's rows (the next slot's first tile, or beyond the buffer where the bounds check returns 0) and are never used.
+    const int half = KT >> 1, units = cnt * 16;
+    int xi = 0;
     uint32_t row_tile = r0;
-    auto after_pair = [&]() {
-        if (++pair_in_xi == half) {
-            pair_in_xi = 0;
-            fold(xi);
-            if (++xi == 16) { xi = 0; epilogue(row_tile); ++row_tile; }
+    for (int u = 0; u < units; ++u) {
+        next_tile(); tile_body(c0{}, yes{}, yes{}, yes{});            // first MFMAs of the unit start from zero
+        next_tile(); tile_body(c1{}, yes{}, yes{}, no{});
+        for (int pr = 1; pr < half; ++pr) {
+            next_tile(); tile_body(c0{}, yes{}, yes{}, no{});
+            next_tile(); tile_body(c1{}, yes{}, yes{}, no{});
         }
-    };
-    int t = 0;
-    for (; t + 3 < total; t += 2) {
-        next_tile(); tile_body(c0{}, yes{}, yes{});
-        next_tile(); tile_body(c1{}, yes{}, yes{});
-        after_pair();
+        fold(xi);
+        if (++xi == 16) { xi = 0; epilogue(row_tile); ++row_tile; }
     }
-    tile_body(c0{}, yes{}, no{});
-    tile_body(c1{}, no{}, no{});
-    after_pair();
 }
 
 hipError_t launch_wino_fused(const WinoFusedParams& p, hipStream_t st) {
