@@ -513,7 +513,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                         }
                         float* d = dst_row[i] + dn;
                         if constexpr (VEC) {
-                            if (do_res) v += extra[j * 4 + g];
+                            // (a launch with BOTH an addend and a residual -- a de-duplicated concat convolution
+                            //  followed by a residual add: no reference model has one -- prefetched the addend)
+                            if (do_res) v += p.addend ? *reinterpret_cast<const f32x4*>(res_row[i] + dn) : extra[j * 4 + g];
                             *reinterpret_cast<f32x4*>(d) = v;
                         } else {
 #pragma unroll

@@ -152,3 +152,32 @@ def test_general_direct_convolution_and_view_shortcuts():
     for name, ref in (("a", a), ("b", b), ("res", c), ("d", d), ("e", e), ("det", det)):
         assert_close(eng.layer_output(L[name]).cpu().numpy(), ref.numpy(), "layer %s" % name)
 
+
+
+def test_deduplicated_concat_convolution_with_residual():
+    """Found by tools/fuzz_graph.py: a convolution over [stacked tensor, T-fold tile of an unstacked one] is split into a
+    once-per-image partial sum and a main launch that picks it up as an addend; when a residual add is fused into the
+    same launch the epilogue has BOTH an addend and a residual (it used to add the addend twice)."""
+    import torch
+    from byolo import Engine
+    H, W, B, T = 64, 96, 2, 3
+    eng = Engine((H, W, 3), 2, keep_all_outputs=True)
+    L = {}
+    L["a"] = eng.add_conv("a", 32, 3, 1, BN)
+    L["s"] = eng.add_stack(L["a"])
+    L["b"] = eng.add_conv("b", 64, 1, 1, BN)
+    L["cat"] = eng.add_route([L["b"], L["s"]])               # 64 stacked + 32 tiled channels
+    L["c"] = eng.add_conv("c", 64, 3, 1, BN)
+    L["res"] = eng.add_residual(L["b"])
+    L["det"] = eng.add_detection("h/detection", 2, [(0.1, 0.2), (0.3, 0.1), (0.5, 0.5)])
+    p = _random_params(eng, 13)
+    eng.set_params(p)
+    eng.finalize()
+    img = np.random.default_rng(2).random((B, H, W, 3)).astype(np.float32)
+    eng.forward(torch.from_numpy(img).cuda(), T=T, seed=1, want_boxes=True, want_nms=False)
+    torch.cuda.synchronize()
+    a = _ref_conv(torch.from_numpy(img), p, "a", 3, 1, BN)
+    s = a.repeat_interleave(T, dim=0)
+    b = _ref_conv(s, p, "b", 1, 1, BN)
+    c = _ref_conv(torch.cat([b, s], dim=3), p, "c", 3, 1, BN) + b
+    assert_close(eng.layer_output(L["res"]).cpu().numpy(), c.numpy(), "concat convolution + residual")

@@ -92,12 +92,14 @@ def one_case(rng, idx, max_cells=5):
                 assert eng.add_route([j]) == len(L)
                 add("route", L[j]["h"], L[j]["w"], L[j]["c"], last["stacked"], srcs=[j])
                 desc.append("id(%d)" % j)
-        elif op == "stack" and not stacked and T > 1:
-            j = len(L) - 1
+        elif op == "stack" and T > 1 and (not stacked or rng.random() < 0.3):
+            # the T-fold tile of ANY unstacked layer so far (the Bayesian YOLOv3 stacks three taps of its backbone)
+            cands = [j for j, r in enumerate(L) if not r["stacked"]]
+            j = len(L) - 1 if not stacked and rng.random() < 0.6 else int(rng.choice(cands))
             assert eng.add_stack(j) == len(L)
-            add("stack", last["h"], last["w"], last["c"], True, src=j)
+            add("stack", L[j]["h"], L[j]["w"], L[j]["c"], True, src=j)
             stacked = True
-            desc.append("S")
+            desc.append("S%d" % j)
     kind = 2 if stacked else int(rng.integers(0, 2))
     if L[-1]["op"] != "conv":                       # detection reads a convolution's output in every reference model
         conv(L[-1], int(rng.choice(FILTERS)), 1, 1, BN)
