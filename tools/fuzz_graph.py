@@ -61,15 +61,40 @@ def one_case(rng, idx, max_cells=5):
     img_rec = dict(h=H, w=W, c=3, stacked=False)
     conv(img_rec, int(rng.choice([8, 16, 32, 64])), 3, 1, BN)
     stacked = False
+    # several detection heads like the reference's models: all of one kind; the Bayesian kind sits on stacked layers
+    bayes = T > 1 and rng.random() < 0.6
+    kind = 2 if bayes else int(rng.integers(0, 2))
+    pri = [(0.1, 0.2), (0.3, 0.1), (0.5, 0.5)]
+    n_det = 0
+
+    def plain(j):                                   # layers other layers may read
+        return L[j]["op"] != "det"
+
     for _ in range(int(rng.integers(3, 14))):
         last = L[-1]
-        op = rng.choice(["conv", "conv", "conv", "res", "up", "route", "stack"])
+        op = rng.choice(["conv", "conv", "conv", "res", "up", "route", "stack", "det"])
+        if op == "stack" and not bayes:
+            op = "conv"
+        if op == "det":
+            if n_det < 2 and (stacked or not bayes) and len(L) >= 2:
+                if last["op"] != "conv":
+                    conv(last, int(rng.choice(FILTERS)), 1, 1, BN)
+                assert eng.add_detection("d%d/detection" % n_det, kind, pri) == len(L)
+                add("det", L[-1]["h"], L[-1]["w"], 3 * 7 * (1 if kind == 0 else 2), L[-1]["stacked"], scope="d%d/detection" % n_det, src=len(L) - 1)
+                desc.append("det%d" % kind)
+                n_det += 1
+                back = [j for j in range(len(L)) if plain(j) and L[j]["stacked"] == L[-1]["stacked"]]      # route back (yolov3.py:258-260)
+                j = int(rng.choice(back))
+                assert eng.add_route([j]) == len(L)
+                add("route", L[j]["h"], L[j]["w"], L[j]["c"], L[j]["stacked"], srcs=[j])
+                desc.append("id(%d)" % j)
+            continue
         if op == "conv":
             k = int(rng.choice([1, 3]))
             stride = 2 if (k == 3 and rng.random() < 0.3 and last["h"] % 2 == 0 and last["w"] % 2 == 0 and min(last["h"], last["w"]) >= 4) else 1
             conv(last, int(rng.choice(FILTERS)), k, stride, BN | (DROP if rng.random() < 0.35 else 0))
         elif op == "res":
-            cands = [j for j, r in enumerate(L[:-1]) if (r["h"], r["w"], r["c"], r["stacked"]) == (last["h"], last["w"], last["c"], last["stacked"])]
+            cands = [j for j, r in enumerate(L[:-1]) if plain(j) and (r["h"], r["w"], r["c"], r["stacked"]) == (last["h"], last["w"], last["c"], last["stacked"])]
             if cands:
                 j = int(rng.choice(cands))
                 assert eng.add_residual(j) == len(L)
@@ -80,7 +105,7 @@ def one_case(rng, idx, max_cells=5):
             add("up", 2 * last["h"], 2 * last["w"], last["c"], last["stacked"], src=len(L) - 1)
             desc.append("U")
         elif op == "route":
-            cands = [j for j, r in enumerate(L) if r["stacked"] == last["stacked"]]
+            cands = [j for j, r in enumerate(L) if plain(j) and r["stacked"] == last["stacked"]]
             j = int(rng.choice(cands))
             same = [q for q in cands if q != j and (L[q]["h"], L[q]["w"]) == (L[j]["h"], L[j]["w"])]
             if same and rng.random() < 0.7:
@@ -94,16 +119,21 @@ def one_case(rng, idx, max_cells=5):
                 desc.append("id(%d)" % j)
         elif op == "stack" and T > 1 and (not stacked or rng.random() < 0.3):
             # the T-fold tile of ANY unstacked layer so far (the Bayesian YOLOv3 stacks three taps of its backbone)
-            cands = [j for j, r in enumerate(L) if not r["stacked"]]
+            cands = [j for j, r in enumerate(L) if plain(j) and not r["stacked"]]
             j = len(L) - 1 if not stacked and rng.random() < 0.6 else int(rng.choice(cands))
             assert eng.add_stack(j) == len(L)
             add("stack", L[j]["h"], L[j]["w"], L[j]["c"], True, src=j)
             stacked = True
             desc.append("S%d" % j)
-    kind = 2 if stacked else int(rng.integers(0, 2))
+    if bayes and not stacked:                       # the Bayesian detection reduces over T samples
+        j = len(L) - 1
+        assert eng.add_stack(j) == len(L)
+        add("stack", L[j]["h"], L[j]["w"], L[j]["c"], True, src=j)
+        stacked = True
+        desc.append("S%d" % j)
     if L[-1]["op"] != "conv":                       # detection reads a convolution's output in every reference model
         conv(L[-1], int(rng.choice(FILTERS)), 1, 1, BN)
-    det_idx = eng.add_detection("d/detection", kind, [(0.1, 0.2), (0.3, 0.1), (0.5, 0.5)])
+    det_idx = eng.add_detection("d/detection", kind, pri)
     desc.append("det%d" % kind)
     run_T = T if stacked else 1
     print("case %d: %dx%d B=%d T=%d %s  env %s" % (idx, H, W, B, run_T, " ".join(desc), {k: os.environ.get(k) for k in (
@@ -140,6 +170,9 @@ def one_case(rng, idx, max_cells=5):
             ref.append(torch.cat([ref[j] for j in r["srcs"]], dim=3) if len(r["srcs"]) == 2 else ref[r["srcs"][0]])
         elif r["op"] == "stack":
             ref.append(ref[r["src"]].repeat_interleave(run_T, dim=0))
+        elif r["op"] == "det":
+            wd = torch.from_numpy(p[r["scope"] + "/conv2d/kernel"]).permute(3, 2, 0, 1)
+            ref.append(torch.nn.functional.conv2d(ref[r["src"]].permute(0, 3, 1, 2), wd).permute(0, 2, 3, 1) + torch.from_numpy(p[r["scope"] + "/conv2d/bias"]))
     wdet = torch.from_numpy(p["d/detection/conv2d/kernel"]).permute(3, 2, 0, 1)
     det = torch.nn.functional.conv2d(ref[-1].permute(0, 3, 1, 2), wdet).permute(0, 2, 3, 1) + torch.from_numpy(p["d/detection/conv2d/bias"])
     checked = 0
