@@ -148,7 +148,7 @@ def one_case(rng, idx, max_cells=5):
     eng.finalize()
     img = rng.random((B, H, W, 3)).astype(np.float32)
     seed = int(rng.integers(0, 1 << 30))
-    eng.forward(torch.from_numpy(img).cuda(), T=run_T, seed=seed, want_boxes=True, want_nms=False)
+    out = eng.forward(torch.from_numpy(img).cuda(), T=run_T, seed=seed, want_boxes=True, want_nms=False)
     torch.cuda.synchronize()
     # reference interpretation
     ref = []
@@ -188,6 +188,31 @@ def one_case(rng, idx, max_cells=5):
         worst = max(worst, assert_close(got, want, "case %d layer %d (%s)" % (idx, i, "det" if i == det_idx else L[i]["op"]),
                                         rtol=3e-4, atol=3e-4))
         checked += 1
+    # decode + concat of the heads: the oracle's decode applied to the DEVICE's raw head outputs (so that this checks the
+    # decode and the concat offsets of 1 .. 3 heads of arbitrary grids, not error propagation), corners / objectness /
+    # layer and prior ids of every row, in concat_bbox order (head after head, prior-major inside a head)
+    from oracle import cpu_ref
+    heads = [i for i, r in enumerate(L) if r["op"] == "det"] + [det_idx]
+    rows = []
+    for lid, i in enumerate(heads):
+        raw = eng.layer_output(i).cpu()
+        if kind == 0:
+            rows.append(cpu_ref.decode_standard(raw, pri, 2))
+        elif kind == 1:
+            rows.append(cpu_ref.decode_aleatoric(raw, pri, 2, lid))
+        else:
+            rows.append([cpu_ref.decode_epistemic(raw[b * run_T:(b + 1) * run_T], pri, 2, lid) for b in range(B)])
+    if kind == 2:
+        want_boxes = torch.stack([cpu_ref.concat_bbox([rows[k][b] for k in range(len(heads))], False) for b in range(B)]).numpy()
+    else:
+        want_boxes = cpu_ref.concat_bbox(rows, True).numpy()
+    got_boxes = out["boxes"].cpu().numpy()
+    assert got_boxes.shape == want_boxes.shape, "case %d: boxes %s vs %s" % (idx, got_boxes.shape, want_boxes.shape)
+    obj_col = {0: 4, 1: 9, 2: 14}[kind]
+    cols = [0, 1, 2, 3, obj_col] + ([] if kind == 0 else [got_boxes.shape[-1] - 2, got_boxes.shape[-1] - 1])
+    with np.errstate(all="ignore"):
+        sane = np.isfinite(want_boxes[..., :4]).all(-1) & (np.abs(want_boxes[..., :4]).max(-1) < 1e3)   # exp(t) of a wild logit
+    assert_close(got_boxes[..., cols][sane], want_boxes[..., cols][sane], "case %d: decoded rows of %d head(s)" % (idx, len(heads)))
     # the same batch in two calls (first_image tells the second where it sits in the logical batch): equal to
     # the unsplit run -- what sub-batching and the one-shard-per-GPU mode rely on (dropout masks are indexed by position)
     if B >= 2:
