@@ -37,7 +37,8 @@ def one_case(rng, idx, max_cells=5):
             os.environ[k] = v
         else:
             os.environ.pop(k, None)
-    eng = Engine((H, W, 3), 2, drop_prob=prob, keep_all_outputs=True)
+    IC = int(rng.choice([3, 3, 3, 1, 4]))          # image channels (the reference feeds RGB)
+    eng = Engine((H, W, IC), 2, drop_prob=prob, keep_all_outputs=True)
     # python-side model of the graph: one record per layer
     L = []          # dict(op, h, w, c, stacked, args)
     desc = []
@@ -58,7 +59,7 @@ def one_case(rng, idx, max_cells=5):
             flags=flags, src=len(L) - 1 if L else -1)
         desc.append("%s%dx%d/%d->%d%s" % ("C", k, k, stride, filters, "d" if flags & DROP else ""))
 
-    img_rec = dict(h=H, w=W, c=3, stacked=False)
+    img_rec = dict(h=H, w=W, c=IC, stacked=False)
     conv(img_rec, int(rng.choice([8, 16, 32, 64])), 3, 1, BN)
     stacked = False
     # several detection heads like the reference's models: all of one kind; the Bayesian kind sits on stacked layers
@@ -146,7 +147,7 @@ def one_case(rng, idx, max_cells=5):
     p = _random_params(eng, int(rng.integers(0, 1 << 30)))
     eng.set_params(p)
     eng.finalize()
-    img = rng.random((B, H, W, 3)).astype(np.float32)
+    img = rng.random((B, H, W, IC)).astype(np.float32)
     seed = int(rng.integers(0, 1 << 30))
     out = eng.forward(torch.from_numpy(img).cuda(), T=run_T, seed=seed, want_boxes=True, want_nms=False)
     torch.cuda.synchronize()
