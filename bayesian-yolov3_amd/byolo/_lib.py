@@ -63,6 +63,7 @@ PROTOTYPES = {
     "byolo_stage_ms": (_i32, [_vp, _P(_f32)]),
     "byolo_num_steps": (_i32, [_vp]),
     "byolo_step_profile": (_i32, [_vp, _i32, _P(_i32), _P(_i32), _P(_i64), _P(_f32), _P(ctypes.c_double)]),
+    "byolo_step_split": (_i32, [_vp, _i32, _P(_i32), _P(_i32)]),
     "byolo_flops": (_i32, [_vp, _i32, _i32, _P(ctypes.c_double)]),
     "byolo_crc32c": (ctypes.c_uint32, [_vp, _sz]),
 }

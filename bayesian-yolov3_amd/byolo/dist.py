@@ -63,3 +63,25 @@ def allgather_boxes(rows, kept, count, world=None):
     g_kept = recv[:, n_r:n_r + n_k].contiguous().view(torch.int32).reshape(world * Bl, cap)
     g_count = recv[:, n_r + n_k:].contiguous().view(torch.int32).reshape(world * Bl, 2)
     return g_rows, g_kept, g_count
+
+
+def padded_block(n_global, world):
+    """Images per rank in the gathered buffer: every rank contributes the same number (the collective needs equal
+    shapes), ranks whose block of the global batch is shorter pad with empty images (count 0)."""
+    return (n_global + world - 1) // world
+
+
+def unpack_global(g_rows, g_kept, g_count, n_global, world):
+    """The gathered, rank-major, padded buffers of allgather_boxes -> ([rows_0, ..., rows_{n_global-1}], [kept_0, ...])
+    in GLOBAL image order, image g trimmed to its kept count: the final box list of the batch.  Reads the counts on
+    the host (one small copy): call it on the rank that consumes the list (rank 0 of the entry points)."""
+    bl = padded_block(n_global, world)
+    assert g_rows.shape[0] == world * bl, "every rank pads its block to padded_block(n_global, world) images"
+    counts = g_count[:, 0].cpu().tolist()
+    out_rows, out_kept = [], []
+    for r in range(world):
+        lo, hi = shard_range(n_global, r, world)
+        for j in range(hi - lo):
+            out_rows.append(g_rows[r * bl + j, :counts[r * bl + j]])
+            out_kept.append(g_kept[r * bl + j, :counts[r * bl + j]])
+    return out_rows, out_kept

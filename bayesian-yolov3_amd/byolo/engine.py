@@ -180,6 +180,9 @@ class Engine:
         self._check_img(img)
         B = int(img.shape[0])
         cap_b = self.max_images(T)
+        if cap_b < 1:
+            raise ValueError("T=%d at %dx%d: one image's stacked activation exceeds the 3 GiB a convolution source may "
+                             "span (32-bit buffer offsets); lower T or the image size" % (T, self.cfg.img_h, self.cfg.img_w))
         if B > cap_b:
             N, D = self.num_boxes()
             res = dict(out) if out is not None else {}
@@ -197,6 +200,7 @@ class Engine:
             return dict(boxes=res.get("boxes"), rows=res.get("rows"), kept=res.get("kept"), count=res.get("count"))
         check(self._h, lib.byolo_set_first_image(self._h, int(first_image)))
         ws = self._workspace(B, T, slot)
+        self._last_ws = ws                                # byolo_layer_output points into the last forward's workspace
         N, D = self.num_boxes()
         dev = img.device
         res = out if out is not None else {}
@@ -226,17 +230,20 @@ class Engine:
         shp = (ctypes.c_int64 * 4)()
         check(self._h, lib.byolo_layer_output(self._h, int(idx), ctypes.byref(ptr), shp))
         shape = tuple(int(s) for s in shp)
-        base = self._ws.data_ptr()
-        off = ptr.value - base
+        ws = getattr(self, "_last_ws", None)
         n = int(np.prod(shape))
+        off = ptr.value - ws.data_ptr() if ws is not None else -1
+        if ws is None or off < 0 or off + 4 * n > ws.numel():
+            raise RuntimeError("layer_output: the workspace of the last forward is gone")
         torch.cuda.synchronize(self.device)
-        return self._ws[off:off + 4 * n].view(torch.float32).reshape(shape).clone()
+        return ws[off:off + 4 * n].view(torch.float32).reshape(shape).clone()
 
     def calibrate_bn(self, img):
         self._check_img(img)
         torch = _torch()
         B = int(img.shape[0])
         ws = self._workspace(B, 1)
+        self._last_ws = ws
         stream = torch.cuda.current_stream(img.device).cuda_stream
         check(self._h, lib.byolo_calibrate_bn(self._h, ctypes.c_void_p(img.data_ptr()), B,
                                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(stream)))
@@ -252,11 +259,14 @@ class Engine:
         out = []
         layer, var, ms, algo = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_float(), ctypes.c_double()
         mnk = (ctypes.c_int64 * 3)()
+        ks, stl = ctypes.c_int32(), ctypes.c_int32()
         for i in range(n):
             check(self._h, lib.byolo_step_profile(self._h, i, ctypes.byref(layer), ctypes.byref(var), mnk, ctypes.byref(ms),
                                                   ctypes.byref(algo)))
+            check(self._h, lib.byolo_step_split(self._h, i, ctypes.byref(ks), ctypes.byref(stl)))
             out.append(dict(layer=layer.value, variant=var.value, M=int(mnk[0]), N=int(mnk[1]), K=int(mnk[2]),
-                            ms=float(ms.value), flops=float(algo.value), flops_executed=2.0 * mnk[0] * mnk[1] * mnk[2]))
+                            ms=float(ms.value), flops=float(algo.value), flops_executed=2.0 * mnk[0] * mnk[1] * mnk[2],
+                            ksplit=ks.value, split_tiles=stl.value))
         return out
 
     def stage_ms(self):

@@ -143,10 +143,18 @@ def step_of(checkpoint):
 class InferenceLoop:
     """`Inference` of the three scripts: dataset -> model.run -> one-deep asynchronous ECP-JSON writer.
     Build extensions (all optional config keys): `weights='synthetic'` (random-init + device BN
-    calibration instead of a checkpoint), `seed`, `nms_mode`, multi-GPU sharding via torchrun."""
+    calibration instead of a checkpoint), `seed`, `nms_mode`.
+
+    Multi-GPU (`torchrun --nproc-per-node N inference_epistemic.py`, one process per GPU; the reference pins one
+    device, `inference_epistemic.py:57`): `batch_size` stays the GLOBAL batch.  Rank r builds its engine on
+    cuda:LOCAL_RANK, decodes and runs its contiguous block of every global batch with `first_image` = the block's
+    position (the N-GPU job draws the dropout masks one GPU would draw on the whole batch), ONE all-gather
+    (byolo.dist.allgather_boxes: RCCL over xGMI) assembles the final box list, and rank 0 alone creates the output
+    directory and writes the JSON files.  Ranks other than 0 never copy results to the host."""
 
     def __init__(self, yolo, config, variant, to_ecp, batched):
         from lib_yolo import dataset_utils
+        from byolo import dist as bdist
         self.batch_size = config['batch_size']
         self.variant = variant
         self.to_ecp = to_ecp
@@ -154,15 +162,20 @@ class InferenceLoop:
         self.config = config
         self.img_size = config['full_img_size']
         assert not config['crop']
+        self.rank, self.local_rank, self.world = bdist.env_rank()
+        if self.world > 1:                                # one engine per process, on this process's GPU
+            yolo.set_engine_option('device', self.local_rank)
 
         self.dataset = dataset_utils.TestingDataset(config)
         self.model = yolo.init_model(inputs=self.dataset.placeholder, training=False).get_model()
+        self.device = self.model.engine.device
         if config.get('weights') == 'synthetic':
             self.checkpoint = 'synthetic-0'
         else:
             self.checkpoint = find_checkpoint(config)
         self.out_path = '{}_{}'.format(config['out_path'], step_of(self.checkpoint))
-        os.makedirs(self.out_path)
+        if self.rank == 0:
+            os.makedirs(self.out_path)                    # like the reference: refuses to overwrite an existing run
         self.worker_thread = None
 
     def _load_weights(self):
@@ -173,31 +186,50 @@ class InferenceLoop:
             eng.set_params(synth.base_params(eng.param_shapes(), self.variant, self.model.cls_cnt, seed=7))
             eng.finalize()
             h, w, c = self.img_size
-            eng.calibrate_bn(torch.from_numpy(synth.synthetic_images(2, h, w, c, seed=999)).cuda())
+            # the same calibration frames on every rank -> identical weights
+            eng.calibrate_bn(torch.from_numpy(synth.synthetic_images(2, h, w, c, seed=999)).to('cuda:%d' % self.device))
         else:
             restore(self.model, self.checkpoint)
 
     def run(self):
         import torch
+        from byolo import dist as bdist
+        rank, _, world = bdist.init()
+        pg = torch.distributed.is_initialized()           # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
         self._load_weights()
+        eng = self.model.engine
+        dev = 'cuda:%d' % self.device
+        _, D = eng.num_boxes()
+        cap = eng.out_cap
         step = 0
         seed = int(self.config.get('seed', 0))
-        for imgs, files in self.dataset:                      # ends like tf.errors.OutOfRangeError
+        for imgs, files, lo in self.dataset.iter_shards(rank, world):     # ends like tf.errors.OutOfRangeError
             step += 1
-            x = torch.from_numpy(imgs).cuda()
-            out = self.model.run(x, seed=seed + step, want_boxes=False)
-            counts = out['count'][:, 0].cpu().numpy()
-            rows = out['rows'].cpu().numpy()
-            boxes = [rows[i, :counts[i]] for i in range(len(files))]
-            if self.worker_thread:
-                self.worker_thread.join()
-            self.worker_thread = threading.Thread(target=self.write_to_disc, args=(boxes, files))
-            self.worker_thread.start()
+            n_glob, n_loc = len(files), int(imgs.shape[0])
+            bl = bdist.padded_block(n_glob, world)        # images per rank in the gathered buffer
+            out = {'rows': torch.zeros((bl, cap, D), dtype=torch.float32, device=dev),
+                   'kept': torch.full((bl, cap), -1, dtype=torch.int32, device=dev),
+                   'count': torch.zeros((bl, 2), dtype=torch.int32, device=dev)}
+            if n_loc:
+                x = torch.from_numpy(imgs).to(dev)
+                self.model.run(x, seed=seed + step, want_boxes=False, first_image=lo,
+                               out={k: v[:n_loc] for k, v in out.items()})
+            g = (out['rows'], out['kept'], out['count'])
+            if pg:                                        # ONE collective per global batch
+                g = bdist.allgather_boxes(*g, world)
+            if rank == 0:                                 # only the writer copies anything to the host
+                boxes = [r.cpu().numpy() for r in bdist.unpack_global(*g, n_glob, world)[0]]
+                if self.worker_thread:
+                    self.worker_thread.join()
+                self.worker_thread = threading.Thread(target=self.write_to_disc, args=(boxes, files))
+                self.worker_thread.start()
             if step % 15 == 0:
                 logging.info('Processed {} images.'.format(step * self.batch_size))
         logging.info('Processed {} batches.'.format(step))
         if self.worker_thread:
             self.worker_thread.join()
+        if pg:
+            torch.distributed.barrier()                   # the files exist when any rank returns
 
     def write_to_disc(self, boxes, files):
         for bxs, filename in zip(boxes, files):

@@ -144,7 +144,7 @@ struct byolo {
     bool ev_valid = false;
     // level 2: one entry per kernel launch of the convolution stack in the last forward (a Winograd layer
     // contributes input transform / GEMM / output transform per chunk); event k is recorded before launch k
-    struct Launch { int layer, variant; int64_t m, n, k; double algo_flops; };
+    struct Launch { int layer, variant; int64_t m, n, k; double algo_flops; int ksplit, split_tiles; };
     std::vector<Launch> launches;
     std::vector<hipEvent_t> step_ev;   // pool, launches.size() + 1 in use
     bool step_valid = false;
@@ -906,10 +906,11 @@ static int32_t run_aux_step(byolo_t* h, const Step& s, const ConvParams& p, hipS
 }
 
 // profiling level 2: event + bookkeeping entry before a launch of the convolution stack
-static int32_t mark_launch(byolo_t* h, int layer, int variant, int64_t m, int64_t n, int64_t k, double algo, hipStream_t st) {
+static int32_t mark_launch(byolo_t* h, int layer, int variant, int64_t m, int64_t n, int64_t k, double algo, hipStream_t st,
+                           int ksplit = 1, int split_tiles = 0) {
     while (h->step_ev.size() < h->launches.size() + 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->step_ev.push_back(e); }
     HIPCHK(h, hipEventRecord(h->step_ev[h->launches.size()], st));
-    h->launches.push_back({layer, variant, m, n, k, algo});
+    h->launches.push_back({layer, variant, m, n, k, algo, ksplit, split_tiles});
     return BYOLO_OK;
 }
 
@@ -990,7 +991,7 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
             g.full_tiles = sp.full_tiles; g.split_tiles = sp.split_tiles; g.split_blocks = sp.split_blocks; g.ksplit = sp.ksplit;
             g.slabs = c.slabs; g.slab_bytes = (uint32_t)conv_split_slab_bytes(sp, tile); g.counters = c.counters;
         }
-        if (prof && (rc = mark_launch(h, s.layer, conv_tile_bn(tile), rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
+        if (prof && (rc = mark_launch(h, s.layer, conv_tile_bn(tile), rows, c.N, c.C0, algo_flops * ns / S, st, g.ksplit > 1 ? g.ksplit : 1, g.split_tiles))) return rc;
         HIPCHK(h, launch_conv_igemm(g, tile, st));
         if (prof && (rc = mark_launch(h, s.layer, -3, w.P, c.N, 0, 0.0, st))) return rc;
         HIPCHK(h, launch_wino_output(w, st));
@@ -1072,7 +1073,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         const int64_t S_all = l.stacked ? (int64_t)B * T : B;
         const double algo = s.mode == STEP_PARTIAL ? 0.0 : 2.0 * (double)(S_all * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);
         if (h->plan.wino[si].chunk > 0) { rc = run_winograd(h, s, l, p, h->plan.wino[si], tile, algo, ws, st); if (rc) return rc; continue; }
-        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st); if (rc) return rc; }
+        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st, l.direct ? 1 : sp.ksplit, l.direct ? 0 : sp.split_tiles); if (rc) return rc; }
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, tile, st));
     }
     if (per_step) {
@@ -1247,6 +1248,15 @@ extern "C" int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int
         HIPCHK(h, hipEventSynchronize(h->step_ev[i + 1]));
         HIPCHK(h, hipEventElapsedTime(ms, h->step_ev[i], h->step_ev[i + 1]));
     }
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_step_split(byolo_t* h, int32_t i, int32_t* ksplit, int32_t* split_tiles) {
+    if (!h) return BYOLO_ERR_ARG;
+    if (!h->step_valid) return fail(h, BYOLO_ERR_STATE, "byolo_step_split: no forward with profiling level 2");
+    if (i < 0 || i >= (int)h->launches.size()) return fail(h, BYOLO_ERR_ARG, "byolo_step_split: bad index");
+    if (ksplit) *ksplit = h->launches[i].ksplit;
+    if (split_tiles) *split_tiles = h->launches[i].split_tiles;
     return BYOLO_OK;
 }
 

@@ -193,8 +193,10 @@ def decode_img(encoded, shape):
 
 class TestingDataset:
     """Iterable of (images [B,H,W,C] float32, [filenames]) batches; `placeholder` is what the model is
-    built on.  Multi-GPU (torchrun): every rank reads the same record stream and keeps its block of each
-    global batch (images sharded on the batch axis)."""
+    built on.  `batch_size` is the GLOBAL batch, as in the reference (`lib_yolo/dataset_utils.py:188-219`).
+    Multi-GPU (torchrun, one process per GPU): `iter_shards(rank, world)` -- every rank reads the same record stream,
+    parses the (cheap) Example protos of a global batch for the file names and decodes only the PNGs of ITS
+    contiguous block of the batch axis (byolo.dist.shard_range)."""
     __test__ = False
 
     def __init__(self, config, config_key='data'):
@@ -219,21 +221,36 @@ class TestingDataset:
                 except StopIteration:
                     active.remove(it)
 
+    def _global_batches(self):
+        recs = []
+        for rec in self._records():
+            recs.append(rec)
+            if len(recs) == self.batch_size:
+                yield recs
+                recs = []
+        if recs:                                       # last, smaller batch (tf.data batch keeps the remainder)
+            yield recs
+
+    @staticmethod
+    def _filename(feats):
+        names = feats.get('image/filename', [])
+        return names[0].decode('utf-8') if names else ''
+
     def parse_example(self, example):
         feats = parse_example(example)
-        img = decode_img(feats['image/encoded'][0], self.shape)
-        names = feats.get('image/filename', [])
-        filename = names[0].decode('utf-8') if names else ''
-        return img, filename
+        return decode_img(feats['image/encoded'][0], self.shape), self._filename(feats)
 
     def __iter__(self):
-        imgs, names = [], []
-        for rec in self._records():
-            img, name = self.parse_example(rec)
-            imgs.append(img)
-            names.append(name)
-            if len(imgs) == self.batch_size:
-                yield np.stack(imgs), names
-                imgs, names = [], []
-        if imgs:                                       # last, smaller batch (tf.data batch keeps the remainder)
-            yield np.stack(imgs), names
+        for imgs, names, _ in self.iter_shards(0, 1):
+            yield imgs, names
+
+    def iter_shards(self, rank, world):
+        """Yields (images of this rank's block [n_local,H,W,C], ALL filenames of the global batch, lo): the block is
+        images [lo, lo + n_local) of the global batch; n_local may be 0 for a last, short batch."""
+        from byolo.dist import shard_range
+        for recs in self._global_batches():
+            lo, hi = shard_range(len(recs), rank, world)
+            feats = [parse_example(r) for r in recs]
+            imgs = [decode_img(f['image/encoded'][0], self.shape) for f in feats[lo:hi]]
+            x = np.stack(imgs) if imgs else np.empty((0,) + self.shape, dtype=np.float32)
+            yield x, [self._filename(f) for f in feats], lo

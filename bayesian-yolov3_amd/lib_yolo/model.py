@@ -248,13 +248,14 @@ class Model:
         self.engine.finalize()
         return self
 
-    def run(self, img, seed=0, dropout_on=True, want_boxes=True, want_nms=True):
+    def run(self, img, seed=0, dropout_on=True, want_boxes=True, want_nms=True, first_image=0, out=None):
         """img: float32 CUDA tensor [B,H,W,C] in [0,1).  Returns the dict of Engine.forward and keeps
-        it as `self.last`, which the DetLayer accessors read."""
+        it as `self.last`, which the DetLayer accessors read.  `first_image`: position of img[0] in the logical
+        (multi-GPU / split) batch; `out`: preallocated rows / kept / count tensors."""
         if not self.engine.finalized:
             self.engine.finalize()
         self.last = self.engine.forward(img, T=self.T, seed=seed, dropout_on=dropout_on, want_boxes=want_boxes,
-                                        want_nms=want_nms)
+                                        want_nms=want_nms, first_image=first_image, out=out)
         return self.last
 
     def matches_blueprint(self, blueprint):

@@ -77,6 +77,11 @@ class _Yolo:
             assert config['crop_img_size'][0] % 32 == 0
             assert config['crop_img_size'][1] % 32 == 0
 
+    def set_engine_option(self, key, value):
+        """Build-specific: an engine option (e.g. the device of this process under torchrun) set before init_model."""
+        assert self._model is None, 'engine options are fixed once the model is built'
+        self._engine_options[key] = value
+
     def get_model(self):
         """
         call init_model first!

@@ -179,6 +179,9 @@ BYOLO_API int32_t byolo_stage_ms(byolo_t* h, float ms[4]);
 BYOLO_API int32_t byolo_num_steps(const byolo_t* h);
 BYOLO_API int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms,
                                      double* algo_flops);
+/* the same launch's split-K plan: K slices per tile of its last partial round of tiles (1 = not split) and how many
+ * tiles were cut (conv_igemm.hip; decided per (B, T) shape, deterministic) */
+BYOLO_API int32_t byolo_step_split(byolo_t* h, int32_t i, int32_t* ksplit, int32_t* split_tiles);
 /* analytic cost of one forward: conv FLOPs (2*MAC, graph as written) for B images x T samples */
 BYOLO_API int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops);
 

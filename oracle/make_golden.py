@@ -55,9 +55,32 @@ def _purge_reference_modules():
             del sys.modules[k]
 
 
+_SAVED_PATH = None        # sys.path before the first import_reference()
+
+
+def restore_environment():
+    """Undo import_reference() / shim.install(): the caller's sys.path is back, the reference's `lib_yolo`,
+    `inference_*`, `detect`, `vis_uncertainty` and the stand-in `tensorflow` / `cv2` leave sys.modules, so a later
+    `import lib_yolo` finds the build's own package again (tests/test_oracle_vs_reference.py tears down with this)."""
+    global _SAVED_PATH
+    if _SAVED_PATH is not None:
+        sys.path[:] = _SAVED_PATH
+        _SAVED_PATH = None
+    _purge_reference_modules()
+    if getattr(sys.modules.get("tensorflow"), "__version__", "") == "1.12-shim":
+        del sys.modules["tensorflow"]
+    cv2 = sys.modules.get("cv2")
+    if cv2 is not None and not hasattr(cv2, "__file__"):          # the bare stub of shim.install()
+        del sys.modules["cv2"]
+
+
 def import_reference():
-    """Import the reference modules under the shim (module level only defines functions/tables)."""
+    """Import the reference modules under the shim (module level only defines functions/tables).
+    Changes sys.path / sys.modules for the process; restore_environment() undoes it."""
+    global _SAVED_PATH
     os.environ.setdefault("MPLBACKEND", "Agg")
+    if _SAVED_PATH is None:
+        _SAVED_PATH = list(sys.path)
     _purge_reference_modules()
     if REF not in sys.path:
         sys.path.insert(0, REF)

@@ -19,6 +19,15 @@ VARIANTS = ("yolov3", "yolov3_aleatoric", "bayesian_yolov3_aleatoric")
 H, W, T, SEED_W, SEED_DROP = 32, 64, 2, 21, 77
 
 
+@pytest.fixture(autouse=True)
+def _leave_no_reference_modules_behind():
+    """oracle.make_golden.import_reference() points `lib_yolo` at the reference and installs stand-in `tensorflow` /
+    `cv2` modules; undo that after every test so the rest of the session imports the build's own package."""
+    yield
+    from oracle import make_golden as mg
+    mg.restore_environment()
+
+
 def _params(variant):
     from oracle import cpu_ref
     from byolo import synth
