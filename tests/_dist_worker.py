@@ -20,8 +20,22 @@ def main(rank, world, port, out_dir):
     kept = torch.randint(-1, 22743, (Bl, cap), generator=g, dtype=torch.int32)
     count = torch.randint(0, cap, (Bl, 2), generator=g, dtype=torch.int32)
     g_rows, g_kept, g_count = bdist.allgather_boxes(rows, kept, count, world)
+    # a short global batch of 3 images over 2 ranks (blocks of 2 and 1): every rank pads its block to
+    # padded_block(3, 2) = 2 images, the final box list comes back in GLOBAL image order, trimmed to the kept counts
+    n_glob = 3
+    lo, hi = bdist.shard_range(n_glob, rank, world)
+    bl = bdist.padded_block(n_glob, world)
+    p_rows = torch.zeros((bl, cap, D)); p_kept = torch.full((bl, cap), -1, dtype=torch.int32)
+    p_count = torch.zeros((bl, 2), dtype=torch.int32)
+    for j in range(hi - lo):
+        k = 1 + (lo + j) % cap                       # image g keeps 1 + g boxes, all valued 100 * g + column index
+        p_rows[j, :k] = 100.0 * (lo + j) + torch.arange(D, dtype=torch.float32)
+        p_kept[j, :k] = torch.arange(k, dtype=torch.int32) + 1000 * (lo + j)
+        p_count[j] = k
+    u_rows, u_kept = bdist.unpack_global(*bdist.allgather_boxes(p_rows, p_kept, p_count, world), n_glob, world)
     torch.save({"rows": rows, "kept": kept, "count": count, "g_rows": g_rows, "g_kept": g_kept, "g_count": g_count,
-                "shard": bdist.shard_range(7, rank, world)}, os.path.join(out_dir, "rank%d.pt" % rank))
+                "shard": bdist.shard_range(7, rank, world), "u_rows": u_rows, "u_kept": u_kept},
+               os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -113,12 +113,12 @@ def assert_close(a, b, what, rtol=RTOL, atol=ATOL):
 
 def column_groups(variant, C=2):
     """Columns of a pre-NMS row by meaning (lib_yolo/layers.py:250-258, :330-346, :480-499).
-    `exp`: the column is (a sum / product of) exp() of a logit -- unbounded, so its bound is relative beyond 1."""
+    `(exp)`: exp(logvar) of network outputs (layers.py:309-313, :465-468) -- unbounded, the only columns beyond 1."""
     if variant == "yolov3":
         return {"coords": list(range(0, 4)), "scores": list(range(4, 5 + C))}
     if variant == "yolov3_aleatoric":
-        return {"coords": list(range(0, 4)), "sigma_ale(exp)": list(range(4, 9)), "scores": [9] + list(range(11, 11 + C)),
-                "entropy": [10, 11 + C], "ids": [12 + C, 13 + C]}
+        return {"coords": list(range(0, 4)), "sigma_ale(exp)": [4, 5, 6, 7, 8],
+                "scores": [9] + list(range(11, 11 + C)), "entropy": [10, 11 + C], "ids": [12 + C, 13 + C]}
     return {"coords": list(range(0, 4)), "sigma_epi": [4, 5, 6, 7, 12], "sigma_ale(exp)": [8, 9, 10, 11, 13],
             "scores": [14] + list(range(17, 17 + C)), "mutual_info/entropy": [15, 16, 17 + C, 18 + C],
             "ids": [19 + C, 20 + C]}
@@ -126,31 +126,36 @@ def column_groups(variant, C=2):
 
 def rows_report(got, ref, variant, C=2):
     """Per column group: max |err|, max |ref|, max relative err over |ref| > 1, and the worst error in units of the
-    literal bound 1e-4 * max(1, |ref|)."""
+    north_star's bound taken literally, 1e-4 * max(1, |ref|)."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     rep = {}
     for name, cols in column_groups(variant, C).items():
         g, r = got[..., cols], ref[..., cols]
         ok = np.isfinite(r) & np.isfinite(g)
+        r0 = np.where(ok, r, 0)
         err = np.where(ok, np.abs(g - r), 0.0)
         big = ok & (np.abs(r) > 1)
-        rep[name] = dict(max_abs_err=float(err.max()), max_ref=float(np.abs(np.where(ok, r, 0)).max()),
+        units = err / _literal_tol(r0, ATOL, RTOL)
+        rep[name] = dict(max_abs_err=float(err.max()), max_ref=float(np.abs(r0).max()),
                          max_rel_err_over_1=float((err[big] / np.abs(r[big])).max()) if big.any() else 0.0,
-                         worst_in_bounds=float((err / _literal_tol(np.where(ok, r, 0), ATOL, RTOL)).max()),
+                         worst_in_bounds=float(units.max()), ref_at_worst=float(r0.reshape(-1)[int(units.argmax())]),
                          nonfinite=int((~ok).sum()))
     return rep
 
 
 def format_report(rep):
-    return "; ".join("%s: |err| %.2e (|ref| <= %.3g, rel>1 %.1e, %.2f of bound)"
-                     % (k, v["max_abs_err"], v["max_ref"], v["max_rel_err_over_1"], v["worst_in_bounds"]) for k, v in rep.items())
+    return "; ".join("%s: |err| %.2e (|ref| <= %.3g, rel>1 %.1e, %.2f of bound at ref %.3g)"
+                     % (k, v["max_abs_err"], v["max_ref"], v["max_rel_err_over_1"], v["worst_in_bounds"], v["ref_at_worst"])
+                     for k, v in rep.items())
 
 
-def assert_rows_close(got, ref, variant, what, C=2):
+def assert_rows_close(got, ref, variant, what, C=2, floor=None):
     """Pre-NMS rows against the oracle, per column group, at the north_star's literal bound: ids exact, everything
     else |err| <= 1e-4 * max(1, |ref|); NaN / inf patterns equal (entropies are NaN exactly at saturated
-    probabilities, layers.py:349-358).  Returns the per-group report (printed by the callers)."""
+    probabilities, layers.py:349-358).  `floor`: a rows_report of the float32 CPU restatement against the SAME
+    (float64) reference -- where float32 arithmetic itself does not reach the bound on a group, the device must be
+    no further from the reference than that float32 evaluation (x 1.1).  Returns the per-group report."""
     got = np.asarray(got)
     ref = np.asarray(ref)
     assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, got.shape, ref.shape)
@@ -159,6 +164,7 @@ def assert_rows_close(got, ref, variant, what, C=2):
     rep = rows_report(got, ref, variant, C)
     if "ids" in rep:
         assert rep["ids"]["max_abs_err"] == 0.0, "%s: layer / prior ids differ" % what
-    bad = {k: v for k, v in rep.items() if v["worst_in_bounds"] > 1.0}
-    assert not bad, "%s: beyond 1e-4 * max(1, |ref|): %s" % (what, format_report(bad))
+    allowed = {k: max(1.0, 1.1 * floor[k]["worst_in_bounds"]) if floor else 1.0 for k in rep}
+    bad = {k: v for k, v in rep.items() if v["worst_in_bounds"] > allowed[k]}
+    assert not bad, "%s: beyond 1e-4 * max(1, |ref|)%s: %s" % (what, " and beyond the float32 floor" if floor else "", format_report(bad))
     return rep

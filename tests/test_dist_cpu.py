@@ -4,6 +4,7 @@ import socket
 import subprocess
 import sys
 
+import pytest
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,6 +32,56 @@ def test_allgather_world2(tmp_path):
             want = torch.cat([res[0][k], res[1][k]], 0)
             assert torch.equal(res[r][gk], want), (r, k)
     assert res[0]["shard"] == (0, 4) and res[1]["shard"] == (4, 7)
+    for r in range(2):                               # the short batch: global order, trimmed, identical on both ranks
+        assert [t.shape[0] for t in res[r]["u_rows"]] == [1, 2, 3]
+        for g in range(3):
+            assert torch.equal(res[r]["u_rows"][g], (100.0 * g + torch.arange(23.0)).expand(g + 1, 23))
+            assert res[r]["u_kept"][g].tolist() == [1000 * g + i for i in range(g + 1)]
+
+
+def _records(tmp_path, n, H=32, W=32):
+    import io
+    import numpy as np
+    from PIL import Image
+    from lib_yolo import dataset_utils as du
+    rng = np.random.default_rng(5)
+    exs, imgs = [], []
+    for i in range(n):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        b = io.BytesIO(); Image.fromarray(img).save(b, format="PNG")
+        exs.append(du.make_example({"image/encoded": b.getvalue(), "image/filename": "f%02d.png" % i, "image/height": H, "image/width": W}))
+        imgs.append(img.astype(np.float32) * np.float32(1 / 255.))
+    du.write_tfrecords(str(tmp_path / "val-00000-of-00001"), exs)
+    return imgs
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_dataset_shards_cover_every_global_batch(tmp_path, world):
+    """TestingDataset.iter_shards: batch_size is the GLOBAL batch (as in the reference); rank r gets the contiguous
+    block shard_range(len(batch), r, world) of every global batch, its offset `lo` (-> first_image: the dropout stream
+    position) and ALL file names; the blocks of the ranks tile the batch, also the last short one (blocks may be empty)."""
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "bayesian-yolov3_amd"))
+    from lib_yolo import dataset_utils as du
+    from byolo import dist as bdist
+    imgs = _records(tmp_path, 11)
+    cfg = {"batch_size": 4, "full_img_size": [32, 32, 3], "data": {"file_pattern": str(tmp_path / "val-*")}}
+    per_rank = [list(du.TestingDataset(cfg).iter_shards(r, world)) for r in range(world)]
+    plain = list(du.TestingDataset(cfg))
+    assert [len(n) for _, n in plain] == [4, 4, 3]
+    for step in range(3):
+        names = per_rank[0][step][1]
+        assert names == plain[step][1] == ["f%02d.png" % (4 * step + i) for i in range(len(names))]
+        pos = 0
+        for r in range(world):
+            x, n_r, lo = per_rank[r][step]
+            assert n_r == names and lo == pos == bdist.shard_range(len(names), r, world)[0]
+            assert x.dtype == np.float32 and x.shape[1:] == (32, 32, 3)
+            for j in range(x.shape[0]):
+                assert np.array_equal(x[j], imgs[4 * step + lo + j])
+            pos += x.shape[0]
+        assert pos == len(names)
 
 
 def test_shard_range_covers_batch():
@@ -40,9 +91,6 @@ def test_shard_range_covers_batch():
             spans = [bdist.shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
-
-
-import pytest
 
 
 @pytest.mark.gpu

@@ -146,6 +146,37 @@ def test_inference_driver_end_to_end(variant, tmp_path):
 
 
 @pytest.mark.gpu
+def test_inference_epistemic_as_a_torchrun_rank(tmp_path):
+    """`torchrun inference_epistemic.py`: the entry point as the driver would launch it, on the only GPU of the box as a
+    forced one-rank RCCL group (BYOLO_DIST_FORCE=1) -- sharded dataset, first_image, the all-gather of the padded
+    box lists, rank-0 writer -- must write byte-identical JSON files to the plain single-process run."""
+    import socket
+    import subprocess
+    import sys
+    import inference_epistemic as mod
+    imgs, names = _make_records(tmp_path, 5)
+    ck = tmp_path / "checkpoints" / "run"
+    ck.mkdir(parents=True)
+    np.savez(str(ck / "model-77.npz"), **golden_params("bayesian_yolov3_aleatoric"))
+    pattern = str(tmp_path / "ecp-day-val-*-of-*")
+    cfg = make_config("bayesian_yolov3_aleatoric", 64, 96, T=3, batch_size=2, checkpoint_path=str(tmp_path / "checkpoints"),
+                      run_id="run", step="last", seed=10, data={"file_pattern": pattern}, out_path=str(tmp_path / "plain" / "run"))
+    mod.inference(cfg)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BYOLO_DIST_FORCE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(here, "_inference_worker.py"), pattern, str(tmp_path / "checkpoints"),
+           str(tmp_path / "dist" / "run"), "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    a, b = str(tmp_path / "plain" / "run_77"), str(tmp_path / "dist" / "run_77")
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == sorted(n.replace(".png", ".json") for n in names)
+    for f in os.listdir(a):
+        assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+
+
+@pytest.mark.gpu
 def test_detect_do_it(tmp_path):
     import detect
     from lib_yolo import yolov3

@@ -84,9 +84,11 @@ def test_config4_as_benched():
 
 def test_config2_as_benched():
     """BASELINE configs[1]: aleatoric head, 416x416, 8 images -- every image against the oracle (no MC samples).
-    The oracle runs in float64 here: with T = 1 the sigma columns are exp(logvar) of ONE sample (up to ~17), and two
-    float32 evaluations of a 75-layer network differ by ~1e-4 relative on the worst of 1.3 M values -- the float32 CPU
-    restatement's own distance from the float64 result is printed next to the device's."""
+    The oracle runs in float64 here.  With T = 1 the sigma columns are exp(logvar) of ONE forward pass, and float32
+    arithmetic itself does not reach 1e-4 relative on the worst of the 1.3 M values of this 75-layer network: the
+    float32 CPU restatement sits at ~1.4 bounds from its own float64 run on that group (every other group: <= 0.25).
+    So: every group within the literal bound, or -- where the float32 CPU evaluation is not -- no further from the
+    float64 result than that evaluation."""
     import torch
     from oracle import cpu_ref
     cfg, eng, imgs, out, launches = _step(2)
@@ -99,9 +101,11 @@ def test_config2_as_benched():
         ref32, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params), imgs, cfg["variant"], T=1, seed=1000)
     boxes = out["boxes"].cpu().numpy()
     assert boxes.shape == (8, 10647, 16)
-    print("config 2, float32 CPU restatement vs float64:", format_report(rows_report(ref32.numpy(), ref64.numpy(), cfg["variant"])))
-    rep = assert_rows_close(boxes, ref64.numpy(), cfg["variant"], "config 2 (416x416 aleatoric B=8) vs float64 oracle")
+    floor = rows_report(ref32.numpy(), ref64.numpy(), cfg["variant"])
+    print("config 2, float32 CPU restatement vs float64:", format_report(floor))
+    rep = assert_rows_close(boxes, ref64.numpy(), cfg["variant"], "config 2 (416x416 aleatoric B=8) vs float64 oracle", floor=floor)
     print("config 2, device vs float64:", format_report(rep))
+    assert all(v["worst_in_bounds"] <= 1.0 for k, v in rep.items() if "(exp)" not in k)      # literal everywhere else
     _check_nms_against_oracle(boxes, out, cfg["variant"])
 
 
