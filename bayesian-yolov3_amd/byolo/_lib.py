@@ -56,11 +56,14 @@ PROTOTYPES = {
     "byolo_max_images": (_i32, [_vp, _i32, _P(_i32)]),
     "byolo_layer_output": (_i32, [_vp, _i32, _P(_vp), _P(_i64)]),
     "byolo_decode": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _P(_f32), _i32, _vp, _i64, _i64, _vp]),
+    "byolo_epistemic_stats": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "byolo_nms_workspace_bytes": (_sz, [_i32, _i64]),
     "byolo_sort_nms": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _sz, _vp, _vp, _vp, _vp]),
     "byolo_calibrate_bn": (_i32, [_vp, _vp, _i32, _vp, _sz, _vp]),
     "byolo_set_profiling": (_i32, [_vp, _i32]),
     "byolo_stage_ms": (_i32, [_vp, _P(_f32)]),
+    "byolo_set_profile_depth": (_i32, [_vp, _i32]),
+    "byolo_select_profile": (_i32, [_vp, _i32]),
     "byolo_num_steps": (_i32, [_vp]),
     "byolo_step_profile": (_i32, [_vp, _i32, _P(_i32), _P(_i32), _P(_i64), _P(_f32), _P(ctypes.c_double)]),
     "byolo_step_split": (_i32, [_vp, _i32, _P(_i32), _P(_i32)]),

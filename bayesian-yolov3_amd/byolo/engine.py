@@ -252,6 +252,14 @@ class Engine:
         """0 off, 1 per-stage hipEvents, 2 additionally one hipEvent per conv launch."""
         check(self._h, lib.byolo_set_profiling(self._h, int(level)))
 
+    def set_profile_depth(self, depth):
+        """Keep the profile records of the last `depth` forwards (read them with select_profile(age))."""
+        check(self._h, lib.byolo_set_profile_depth(self._h, int(depth)))
+
+    def select_profile(self, age):
+        """Which profiled forward step_profile() / stage_ms() read: 0 = the last one, 1 = the one before, ..."""
+        check(self._h, lib.byolo_select_profile(self._h, int(age)))
+
     def step_profile(self):
         """Per conv launch of the last forward (profiling level 2): list of dicts
         {layer, variant (tile BN or -1 = direct), M, N, K, ms, flops}."""
@@ -284,6 +292,23 @@ class Engine:
         check(self._h, lib.byolo_decode(self._h, int(kind), ctypes.c_void_p(raw.data_ptr()), int(B), int(T), int(lh),
                                         int(lw), arr, int(layer_id), ctypes.c_void_p(boxes.data_ptr()),
                                         int(boxes.shape[1]), int(box_base), ctypes.c_void_p(stream)))
+
+    def epistemic_stats(self, raw, B, T):
+        """decode_epistemic's dict entries outside the box row from a raw epistemic detection output [B*T,lh,lw,F]:
+        dict(ev_loc [B,lh,lw,3,4], epi_covar_loc [B,lh,lw,3,4,4], obj_samples [B*T,lh,lw,3], cls_samples [B*T,lh,lw,3,C])."""
+        torch = _torch()
+        S, lh, lw, F = raw.shape
+        C = self.cfg.cls_cnt
+        assert S == B * T and F == 3 * 2 * (5 + C) and raw.is_cuda and raw.dtype == torch.float32 and raw.is_contiguous()
+        dev = raw.device
+        out = dict(ev_loc=torch.empty((B, lh, lw, 3, 4), device=dev), epi_covar_loc=torch.empty((B, lh, lw, 3, 4, 4), device=dev),
+                   obj_samples=torch.empty((S, lh, lw, 3), device=dev), cls_samples=torch.empty((S, lh, lw, 3, C), device=dev))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        check(self._h, lib.byolo_epistemic_stats(self._h, p(raw), int(B), int(T), int(lh), int(lw), p(out["ev_loc"]),
+                                                 p(out["epi_covar_loc"]), p(out["obj_samples"]), p(out["cls_samples"]),
+                                                 ctypes.c_void_p(stream)))
+        return out
 
     def sort_nms(self, boxes, obj_idx, cls_start_idx, nms_mode=None, max_out=None, iou_thresh=None):
         """tf.image.non_max_suppression + tf.gather per image on boxes [B,N,D] (device tensor)."""

@@ -109,6 +109,7 @@ struct Plan {
     std::vector<ConvSplit> split;  // per step
     std::vector<int> tile;         // per step: tile configuration of the launch
     std::vector<WinoPlan> wino;    // per step
+    std::vector<int> stream1x1;    // per step: tile width of the row-streaming 1x1 launch (gemm_stream.hip), 0 = conv_igemm
     size_t wino_off = 0;           // scratch for V and M of one chunk (shared by all steps)
 };
 static constexpr int CNT_PER_STEP = 1024;      // >= resident workgroups of any tile configuration
@@ -140,14 +141,23 @@ struct byolo {
     void* last_ws = nullptr;
     int64_t first_image = 0;       // position of a call's first image in the logical batch (dropout stream)
     int profiling = 0;             // 0 off, 1 stage events, 2 + one event per conv launch
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
-    // level 2: one entry per kernel launch of the convolution stack in the last forward (a Winograd layer
+    // level 2: one entry per kernel launch of the convolution stack in a forward (a Winograd layer
     // contributes input transform / GEMM / output transform per chunk); event k is recorded before launch k
     struct Launch { int layer, variant; int64_t m, n, k; double algo_flops; int ksplit, split_tiles; };
-    std::vector<Launch> launches;
-    std::vector<hipEvent_t> step_ev;   // pool, launches.size() + 1 in use
-    bool step_valid = false;
+    // The records of the last `depth` profiled forwards (byolo_set_profile_depth; 1 by default): a caller that times a
+    // run of back-to-back forwards reads all of them AFTER the run instead of synchronising with every step.
+    struct ProfSlot {
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        bool ev_valid = false;
+        std::vector<Launch> launches;
+        std::vector<hipEvent_t> step_ev;   // pool, launches.size() + 1 in use
+        bool step_valid = false;
+    };
+    std::vector<ProfSlot> prof = std::vector<ProfSlot>(1);
+    int prof_w = 0;                    // slot of the most recent profiled forward
+    int prof_age = 0;                  // which forward the read calls refer to: 0 = the last, 1 = the one before, ...
+    ProfSlot& wslot() { return prof[prof_w]; }
+    ProfSlot& rslot() { const int d = (int)prof.size(); return prof[((prof_w - prof_age) % d + d) % d]; }
 };
 
 static thread_local std::string g_err;
@@ -189,13 +199,17 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
 
 extern "C" int32_t byolo_destroy(byolo_t* h) {
     if (!h) return BYOLO_OK;
-    if (h->d_blob || h->d_ones || h->ev[0] || !h->step_ev.empty()) {
+    bool on_device = h->d_blob || h->d_ones;
+    for (auto& ps : h->prof) on_device = on_device || ps.ev[0] || !ps.step_ev.empty();
+    if (on_device) {                               // a handle that never ran (builder-only use, no GPU) touches no HIP call
         (void)hipSetDevice(h->device);
         if (h->d_blob) (void)hipFree(h->d_blob);
         if (h->d_ones) (void)hipFree(h->d_ones);
         if (h->d_zeros) (void)hipFree(h->d_zeros);
-        for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
-        for (auto& e : h->step_ev) (void)hipEventDestroy(e);
+        for (auto& ps : h->prof) {
+            for (auto& e : ps.ev) if (e) (void)hipEventDestroy(e);
+            for (auto& e : ps.step_ev) (void)hipEventDestroy(e);
+        }
     }
     delete h;
     return BYOLO_OK;
@@ -806,6 +820,24 @@ static void make_plan(byolo_t* h, int B, int T) {
         slab = std::max(slab, conv_split_slab_bytes(p.split[si], s.tile));
       }
     }
+    // Row-streaming launch for the 1x1 / stride-1 convolutions over one plain source (gemm_stream.hip): the 1x1
+    // convolutions of the heads, the concat convolutions' stacked half (STEP_MAIN) and the detection heads.
+    // BYOLO_STREAM1X1=0 keeps them on conv_igemm (A/B), =2 takes it for every shape the kernel can express (tests).
+    p.stream1x1.assign(h->steps.size(), 0);
+    { const char* e = getenv("BYOLO_STREAM1X1");
+      const bool on = !e || atoi(e) != 0, force = e && atoi(e) >= 2;
+      for (size_t si = 0; on && si < h->steps.size(); ++si) {
+        const Step& s = h->steps[si];
+        const Layer& l = h->layers[s.layer];
+        if (!s.is_conv() || l.direct || l.ksize != 1 || l.stride != 1) continue;
+        if (s.mode != STEP_NORMAL && s.mode != STEP_MAIN) continue;
+        if (s.in.n != 1 || s.in.s[0].sh || s.in.s[0].tile || s.in.s[0].layer < 0 || l.fused_residual >= 0) continue;
+        if (l.op == OP_CONV && (l.filters % 4)) continue;
+        int M, KT; step_geometry(h, s, B, T, &M, &KT);
+        const int bn = conv1x1_stream_tile(M, s.c_hi - s.c_lo, l.filters, force);
+        if (bn && (l.filters <= 64 ? s.Npad == 64 : s.Npad == l.filters)) p.stream1x1[si] = bn;
+      }
+    }
     p.wino_off = o; o += align_up(wino_scratch, 256);
     p.slab_off = o; p.slab_bytes = slab; o += align_up(slab, 256);
     p.cnt_bytes = h->steps.size() * CNT_PER_STEP * sizeof(unsigned);
@@ -908,9 +940,10 @@ static int32_t run_aux_step(byolo_t* h, const Step& s, const ConvParams& p, hipS
 // profiling level 2: event + bookkeeping entry before a launch of the convolution stack
 static int32_t mark_launch(byolo_t* h, int layer, int variant, int64_t m, int64_t n, int64_t k, double algo, hipStream_t st,
                            int ksplit = 1, int split_tiles = 0) {
-    while (h->step_ev.size() < h->launches.size() + 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->step_ev.push_back(e); }
-    HIPCHK(h, hipEventRecord(h->step_ev[h->launches.size()], st));
-    h->launches.push_back({layer, variant, m, n, k, algo, ksplit, split_tiles});
+    byolo::ProfSlot& ps = h->wslot();
+    while (ps.step_ev.size() < ps.launches.size() + 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); ps.step_ev.push_back(e); }
+    HIPCHK(h, hipEventRecord(ps.step_ev[ps.launches.size()], st));
+    ps.launches.push_back({layer, variant, m, n, k, algo, ksplit, split_tiles});
     return BYOLO_OK;
 }
 
@@ -966,7 +999,9 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
             q.RT = w.P_pad / 128;
             const int R = 16 * q.RT;
             q.slots = 512 / q.n_tiles; q.q = R / q.slots; q.rem = R % q.slots;
-            q.d_ntiles = make_fastdiv((uint32_t)q.n_tiles); q.d_RT = make_fastdiv((uint32_t)q.RT);            if (prof && (rc = mark_launch(h, s.layer, 129, rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
+            q.d_ntiles = make_fastdiv((uint32_t)q.n_tiles); q.d_RT = make_fastdiv((uint32_t)q.RT);
+            q.epi = 0; q.M = rows; q.Npad = c.N; q.ldc = c.N;
+            if (prof && (rc = mark_launch(h, s.layer, 129, rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
             HIPCHK(h, launch_gemm_stream(q, st));
             if (prof && (rc = mark_launch(h, s.layer, -3, w.P, c.N, 0, 0.0, st))) return rc;
             HIPCHK(h, launch_wino_output(w, st));
@@ -989,9 +1024,10 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
         const ConvSplit sp = conv_plan_split(rows, c.Npad, g.KT, tile);
         if (conv_split_slab_bytes(sp, tile) <= h->plan.slab_bytes) {
             g.full_tiles = sp.full_tiles; g.split_tiles = sp.split_tiles; g.split_blocks = sp.split_blocks; g.ksplit = sp.ksplit;
+            g.sk_grid = sp.sk_grid;
             g.slabs = c.slabs; g.slab_bytes = (uint32_t)conv_split_slab_bytes(sp, tile); g.counters = c.counters;
         }
-        if (prof && (rc = mark_launch(h, s.layer, conv_tile_bn(tile), rows, c.N, c.C0, algo_flops * ns / S, st, g.ksplit > 1 ? g.ksplit : 1, g.split_tiles))) return rc;
+        if (prof && (rc = mark_launch(h, s.layer, conv_tile_bn(tile), rows, c.N, c.C0, algo_flops * ns / S, st, g.sk_grid > 0 ? -g.sk_grid : (g.ksplit > 1 ? g.ksplit : 1), g.split_tiles))) return rc;
         HIPCHK(h, launch_conv_igemm(g, tile, st));
         if (prof && (rc = mark_launch(h, s.layer, -3, w.P, c.N, 0, 0.0, st))) return rc;
         HIPCHK(h, launch_wino_output(w, st));
@@ -1031,18 +1067,20 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
     char* ws = reinterpret_cast<char*>(d_workspace);
     h->last_ws = d_workspace;
     if (h->profiling) {
-        for (auto& e : h->ev) if (!e) HIPCHK(h, hipEventCreate(&e));
-        HIPCHK(h, hipEventRecord(h->ev[0], st));
+        h->prof_w = (h->prof_w + 1) % (int)h->prof.size();
+        byolo::ProfSlot& ps = h->wslot();
+        ps.ev_valid = false; ps.step_valid = false; ps.launches.clear();
+        for (auto& e : ps.ev) if (!e) HIPCHK(h, hipEventCreate(&e));
+        HIPCHK(h, hipEventRecord(ps.ev[0], st));
     }
     const bool per_step = h->profiling >= 2;
-    if (per_step) { h->launches.clear(); h->step_valid = false; }
     bool backbone_marked = false;
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     for (size_t si = 0; si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
         if (h->profiling && !backbone_marked && h->backbone_end >= 0 && s.layer >= h->backbone_end) {
-            HIPCHK(h, hipEventRecord(h->ev[1], st)); backbone_marked = true;
+            HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); backbone_marked = true;
         }
         ConvParams p; fill_conv(h, s, d_img, ws, B, T, p);
         if (!s.is_conv()) { rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
@@ -1065,6 +1103,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         const int tile = h->plan.tile[si];
         const ConvSplit& sp = h->plan.split[si];
         p.full_tiles = sp.full_tiles; p.split_tiles = sp.split_tiles; p.split_blocks = sp.split_blocks; p.ksplit = sp.ksplit;
+        p.sk_grid = sp.sk_grid;
         p.slabs = reinterpret_cast<float*>(ws + h->plan.slab_off);
         p.slab_bytes = (uint32_t)conv_split_slab_bytes(sp, tile);
         p.counters = reinterpret_cast<unsigned*>(ws + h->plan.cnt_off) + si * CNT_PER_STEP;
@@ -1073,17 +1112,36 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         const int64_t S_all = l.stacked ? (int64_t)B * T : B;
         const double algo = s.mode == STEP_PARTIAL ? 0.0 : 2.0 * (double)(S_all * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);
         if (h->plan.wino[si].chunk > 0) { rc = run_winograd(h, s, l, p, h->plan.wino[si], tile, algo, ws, st); if (rc) return rc; continue; }
-        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st, l.direct ? 1 : sp.ksplit, l.direct ? 0 : sp.split_tiles); if (rc) return rc; }
+        if (h->plan.stream1x1[si]) {                            // row-streaming 1x1 convolution / detection head
+            const int bn = h->plan.stream1x1[si];
+            GemmStreamParams q; memset(&q, 0, sizeof q);
+            q.a = p.src0; q.a_bytes = p.src0_bytes;
+            q.w = p.wpk; q.w_bytes = p.w_bytes; q.wstride = 0;
+            q.dst = p.dst; q.C = p.C0; q.N = p.N; q.KT = p.KT; q.n_tiles = bn == 64 ? 1 : p.N / 128;
+            const int R = (p.M + 127) / 128;
+            q.RT = R + 1;                                       // one weight matrix for all rows
+            q.slots = 512 / q.n_tiles; q.q = R / q.slots; q.rem = R % q.slots;
+            q.d_ntiles = make_fastdiv((uint32_t)q.n_tiles); q.d_RT = make_fastdiv((uint32_t)q.RT);
+            q.epi = l.op == OP_DETECTION ? 2 : 1; q.M = p.M; q.Npad = p.Npad; q.ldc = p.ldc;
+            q.scale = p.scale; q.shift = p.shift; q.addend = p.addend; q.hw = l.H * l.W;
+            q.flags = p.flags; q.k0 = p.k0; q.k1 = p.k1; q.thr = p.thr; q.idx_base = p.idx_base;
+            q.d_hw = p.d_hw; q.d_addT = p.d_addT;
+            if (per_step) { rc = mark_launch(h, s.layer, bn == 64 ? 132 : 131, p.M, l.filters, p.C0, algo, st); if (rc) return rc; }
+            HIPCHK(h, launch_gemm_stream(q, st));
+            continue;
+        }
+        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st, l.direct ? 1 : (sp.sk_grid > 0 ? -sp.sk_grid : sp.ksplit), l.direct ? 0 : sp.split_tiles); if (rc) return rc; }
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, tile, st));
     }
     if (per_step) {
-        while (h->step_ev.size() < h->launches.size() + 1) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->step_ev.push_back(e); }
-        HIPCHK(h, hipEventRecord(h->step_ev[h->launches.size()], st)); h->step_valid = true;
+        byolo::ProfSlot& ps = h->wslot();
+        while (ps.step_ev.size() < ps.launches.size() + 1) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); ps.step_ev.push_back(e); }
+        HIPCHK(h, hipEventRecord(ps.step_ev[ps.launches.size()], st)); ps.step_valid = true;
     }
-    if (h->profiling) { if (!backbone_marked) HIPCHK(h, hipEventRecord(h->ev[1], st)); HIPCHK(h, hipEventRecord(h->ev[2], st)); }
+    if (h->profiling) { if (!backbone_marked) HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); HIPCHK(h, hipEventRecord(h->wslot().ev[2], st)); }
     float* boxes = d_boxes ? d_boxes : reinterpret_cast<float*>(ws + h->plan.boxes_off);
     if (d_boxes || d_rows) { rc = run_decode(h, ws, boxes, B, T, st); if (rc) return rc; }
-    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[3], st));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->wslot().ev[3], st));
     if (d_rows) {
         NmsParams n; memset(&n, 0, sizeof n);
         n.boxes = boxes; n.B = B; n.N = h->n_boxes; n.D = h->row_len; n.obj_idx = h->obj_idx; n.cls_start = h->cls_start;
@@ -1093,16 +1151,18 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         if (n.two_class && h->cfg.cls_cnt != 2) return fail(h, BYOLO_ERR_ARG, "byolo_forward: 2-class NMS needs cls_cnt == 2");
         HIPCHK(h, launch_sort_nms(n, st));
     }
-    if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[4], st)); h->ev_valid = true; }
+    if (h->profiling) { HIPCHK(h, hipEventRecord(h->wslot().ev[4], st)); h->wslot().ev_valid = true; }
     return BYOLO_OK;
 }
 
 extern "C" int32_t byolo_layer_output(const byolo_t* h, int32_t idx, const float** d_ptr, int64_t shape[4]) {
     byolo_t* hh = const_cast<byolo_t*>(h);
     if (!h || idx < 0 || idx >= (int)h->layers.size()) return fail(hh, BYOLO_ERR_ARG, "byolo_layer_output: bad index");
-    if (!h->cfg.keep_all_outputs) return fail(hh, BYOLO_ERR_STATE, "byolo_layer_output: handle created without keep_all_outputs");
-    if (!h->last_ws || h->plan.B < 0) return fail(hh, BYOLO_ERR_STATE, "byolo_layer_output: no forward has run");
     const Layer& l = h->layers[idx];
+    // (the raw outputs of the detection layers are never overwritten by the planner: readable on any handle)
+    if (!h->cfg.keep_all_outputs && l.op != OP_DETECTION)
+        return fail(hh, BYOLO_ERR_STATE, "byolo_layer_output: handle created without keep_all_outputs");
+    if (!h->last_ws || h->plan.B < 0) return fail(hh, BYOLO_ERR_STATE, "byolo_layer_output: no forward has run");
     if (!l.materialized) return fail(hh, BYOLO_ERR_ARG, "byolo_layer_output: layer %d has no tensor of its own (fused or a view)", idx);
     if (d_ptr) *d_ptr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->last_ws) + h->plan.off[idx]);
     if (shape) { shape[0] = l.stacked ? (int64_t)h->plan.B * h->plan.T : h->plan.B; shape[1] = l.H; shape[2] = l.W; shape[3] = l.C; }
@@ -1126,6 +1186,19 @@ extern "C" int32_t byolo_decode(byolo_t* h, int32_t kind, const float* d_raw, in
     hipError_t e = launch_decode(kind, d, reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? BYOLO_ERR_ARG : BYOLO_ERR_HIP,
                                      "byolo_decode: %s (cls_cnt %d)", hipGetErrorString(e), d.C);
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_epistemic_stats(byolo_t* h, const float* d_raw, int32_t B, int32_t T, int32_t lh, int32_t lw,
+                                         float* d_ev_loc, float* d_epi_covar, float* d_obj_samples, float* d_cls_samples,
+                                         void* stream) {
+    if (!h || !d_raw) return fail(h, BYOLO_ERR_ARG, "byolo_epistemic_stats: null argument");
+    if (B < 1 || T < 1 || lh < 1 || lw < 1) return fail(h, BYOLO_ERR_ARG, "byolo_epistemic_stats: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    DecodeParams d; memset(&d, 0, sizeof d);
+    d.raw = d_raw; d.B = B; d.T = T; d.lh = lh; d.lw = lw; d.C = h->cfg.cls_cnt;
+    hipError_t e = launch_epi_stats(d, d_ev_loc, d_epi_covar, d_obj_samples, d_cls_samples, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, BYOLO_ERR_HIP, "byolo_epistemic_stats: %s", hipGetErrorString(e));
     return BYOLO_OK;
 }
 
@@ -1200,7 +1273,40 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
 // ------------------------------------------------------------------------------------------------
 extern "C" int32_t byolo_set_profiling(byolo_t* h, int32_t on) {
     if (!h) return BYOLO_ERR_ARG;
-    h->profiling = on < 0 ? 0 : (on > 2 ? 2 : on); h->ev_valid = false; h->step_valid = false;
+    h->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
+    for (auto& ps : h->prof) { ps.ev_valid = false; ps.step_valid = false; }
+    h->prof_age = 0;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_set_profile_depth(byolo_t* h, int32_t depth) {
+    if (!h) return BYOLO_ERR_ARG;
+    if (depth < 1 || depth > 4096) return fail(h, BYOLO_ERR_ARG, "byolo_set_profile_depth: depth out of [1, 4096]");
+    if ((int)h->prof.size() > depth) {
+        HIPCHK(h, hipSetDevice(h->device));
+        for (size_t i = depth; i < h->prof.size(); ++i) {
+            for (auto& e : h->prof[i].ev) if (e) (void)hipEventDestroy(e);
+            for (auto& e : h->prof[i].step_ev) (void)hipEventDestroy(e);
+        }
+    }
+    // new slots get event pools as large as the last profiled forward's, so that a run that follows creates none
+    const size_t pool = h->wslot().step_ev.size();
+    const bool staged = h->wslot().ev[0] != nullptr;
+    if (pool || staged) HIPCHK(h, hipSetDevice(h->device));
+    h->prof.resize((size_t)depth);
+    for (auto& ps : h->prof) {
+        ps.ev_valid = false; ps.step_valid = false;
+        while (ps.step_ev.size() < pool) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); ps.step_ev.push_back(e); }
+        if (staged) for (auto& e : ps.ev) if (!e) HIPCHK(h, hipEventCreate(&e));
+    }
+    h->prof_w = 0; h->prof_age = 0;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_select_profile(byolo_t* h, int32_t age) {
+    if (!h) return BYOLO_ERR_ARG;
+    if (age < 0 || age >= (int)h->prof.size()) return fail(h, BYOLO_ERR_ARG, "byolo_select_profile: age outside the profile depth");
+    h->prof_age = age;
     return BYOLO_OK;
 }
 
@@ -1229,43 +1335,47 @@ extern "C" int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images) 
 
 extern "C" int32_t byolo_num_steps(const byolo_t* h) {
     if (!h) return BYOLO_ERR_ARG;
-    if (!h->step_valid) return fail(const_cast<byolo_t*>(h), BYOLO_ERR_STATE, "byolo_num_steps: no forward with profiling level 2");
-    return (int32_t)h->launches.size();
+    byolo_t* hh = const_cast<byolo_t*>(h);
+    if (!hh->rslot().step_valid) return fail(hh, BYOLO_ERR_STATE, "byolo_num_steps: no forward with profiling level 2");
+    return (int32_t)hh->rslot().launches.size();
 }
 
 extern "C" int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms,
                                       double* algo_flops) {
     if (!h) return BYOLO_ERR_ARG;
-    if (!h->step_valid) return fail(h, BYOLO_ERR_STATE, "byolo_step_profile: no forward with profiling level 2");
-    if (i < 0 || i >= (int)h->launches.size()) return fail(h, BYOLO_ERR_ARG, "byolo_step_profile: bad index");
-    const byolo::Launch& e = h->launches[i];
+    byolo::ProfSlot& ps = h->rslot();
+    if (!ps.step_valid) return fail(h, BYOLO_ERR_STATE, "byolo_step_profile: no forward with profiling level 2");
+    if (i < 0 || i >= (int)ps.launches.size()) return fail(h, BYOLO_ERR_ARG, "byolo_step_profile: bad index");
+    const byolo::Launch& e = ps.launches[i];
     if (layer) *layer = e.layer;
     if (variant) *variant = e.variant;
     if (mnk) { mnk[0] = e.m; mnk[1] = e.n; mnk[2] = e.k; }       // EXECUTED extents of this launch
     if (algo_flops) *algo_flops = e.algo_flops;
     if (ms) {
         HIPCHK(h, hipSetDevice(h->device));
-        HIPCHK(h, hipEventSynchronize(h->step_ev[i + 1]));
-        HIPCHK(h, hipEventElapsedTime(ms, h->step_ev[i], h->step_ev[i + 1]));
+        HIPCHK(h, hipEventSynchronize(ps.step_ev[i + 1]));
+        HIPCHK(h, hipEventElapsedTime(ms, ps.step_ev[i], ps.step_ev[i + 1]));
     }
     return BYOLO_OK;
 }
 
 extern "C" int32_t byolo_step_split(byolo_t* h, int32_t i, int32_t* ksplit, int32_t* split_tiles) {
     if (!h) return BYOLO_ERR_ARG;
-    if (!h->step_valid) return fail(h, BYOLO_ERR_STATE, "byolo_step_split: no forward with profiling level 2");
-    if (i < 0 || i >= (int)h->launches.size()) return fail(h, BYOLO_ERR_ARG, "byolo_step_split: bad index");
-    if (ksplit) *ksplit = h->launches[i].ksplit;
-    if (split_tiles) *split_tiles = h->launches[i].split_tiles;
+    byolo::ProfSlot& ps = h->rslot();
+    if (!ps.step_valid) return fail(h, BYOLO_ERR_STATE, "byolo_step_split: no forward with profiling level 2");
+    if (i < 0 || i >= (int)ps.launches.size()) return fail(h, BYOLO_ERR_ARG, "byolo_step_split: bad index");
+    if (ksplit) *ksplit = ps.launches[i].ksplit;
+    if (split_tiles) *split_tiles = ps.launches[i].split_tiles;
     return BYOLO_OK;
 }
 
 extern "C" int32_t byolo_stage_ms(byolo_t* h, float ms[4]) {
     if (!h || !ms) return BYOLO_ERR_ARG;
-    if (!h->ev_valid) return fail(h, BYOLO_ERR_STATE, "byolo_stage_ms: no profiled forward");
+    byolo::ProfSlot& ps = h->rslot();
+    if (!ps.ev_valid) return fail(h, BYOLO_ERR_STATE, "byolo_stage_ms: no profiled forward");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipEventSynchronize(h->ev[4]));
-    for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    HIPCHK(h, hipEventSynchronize(ps.ev[4]));
+    for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventElapsedTime(&ms[i], ps.ev[i], ps.ev[i + 1]));
     return BYOLO_OK;
 }
 

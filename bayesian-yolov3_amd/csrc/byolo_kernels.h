@@ -73,7 +73,12 @@ struct ConvParams {
     // split-K of the last partial round of tiles (conv_plan_split): blocks [0, full_tiles) compute whole
     // tiles, the remaining split_tiles tiles are computed by ksplit K-slice blocks each
     int full_tiles, split_tiles, split_blocks, ksplit;
-    float* slabs;                     // [split_tiles][ksplit][128*BN] raw accumulators
+    // stream-K (small launches: fewer tiles than a few rounds of resident workgroups): sk_grid > 0 workgroups share
+    // the launch's tiles * KT K-tile units evenly -- workgroup g owns units [g*sk_q + min(g, sk_r), ...) -- a tile
+    // that straddles workgroups is reduced through slabs by the last arriver, like a split-K tile
+    int sk_grid, sk_q, sk_r;
+    FastDiv d_skq, d_skq1, d_kt;      // sk_q, sk_q + 1, KT
+    float* slabs;                     // [split_tiles][ksplit][128*BN] raw accumulators  (stream-K: [2 * sk_grid][128*BN])
     uint32_t slab_bytes;
     unsigned* counters;               // [split_tiles] arrival tickets, zero at launch
     // Winograd-domain batched GEMM (winograd.hip): the rows are 16 blocks of wino_rows (a multiple of 128) rows, block
@@ -96,17 +101,25 @@ struct WinoParams {
     int flags; uint32_t k0, k1, thr; uint64_t idx_base;
     FastDiv d_tt, d_tw, d_c4, d_n4;   // th*tw, tw, C/4, N/4
 };
-// The Winograd-domain GEMM as one persistent launch that streams row tiles (gemm_stream.hip)
+// Row-streaming persistent GEMM (gemm_stream.hip): the Winograd-domain GEMM (epi 0: 16 row blocks of RT row tiles, one
+// weight matrix each, raw accumulators out), a 1x1 / stride-1 convolution with its fused epilogue (epi 1), or a
+// detection head (epi 2: + bias, any cout)
 struct GemmStreamParams {
-    const float* a; uint32_t a_bytes;     // V: [16 * RT * 128 rows][C]
-    const float* w; uint32_t w_bytes;     // 16 matrices, each packed [C/32][N][32], wstride bytes apart
-    float* dst;                           // M: [rows][N]
-    int C, N, KT, n_tiles;                // KT = C / 32 (even), n_tiles = N / 128
-    int RT;                               // row tiles per transform point xi
+    const float* a; uint32_t a_bytes;     // A: [rows][C] (rows beyond a_bytes read 0)
+    const float* w; uint32_t w_bytes;     // weight matrices, each packed [C/32][Npad][32], wstride bytes apart
+    float* dst;                           // [rows][ldc]
+    int C, N, KT, n_tiles;                // KT = C / 32 (even), n_tiles = column tiles (128 wide; 64 for cout <= 64)
+    int RT;                               // row tiles per weight matrix (one matrix: > all row tiles)
     int slots, q, rem;                    // 512 / n_tiles row ranges of q (+1 for the first rem) row tiles
     uint32_t wstride;
     FastDiv d_ntiles, d_RT;
+    int epi, M, Npad, ldc;                // epilogue kind; valid rows (epi != 0); weight rows per K-tile; dst row stride
+    const float* scale; const float* shift;
+    const float* addend; int hw;          // epi 1: raw partial sums [images*hw][N] joined before scale, or null; h*w
+    int flags; uint32_t k0, k1, thr; uint64_t idx_base;      // EPI_LEAKY / EPI_DROPOUT; dropout keys (byolo_rng.h)
+    FastDiv d_hw, d_addT;                 // hw, samples per image of the rows (addend)
 };
+int conv1x1_stream_tile(int M, int C, int N, bool force = false);    // tile width (128 | 64) if a 1x1 convolution of M rows fits the streaming launch, else 0
 // The same GEMM with the output transform and the convolution's epilogue fused in (wino_fused.hip): no M
 struct WinoFusedParams {
     const float* v; uint32_t v_bytes;     // V: [16][P_pad][C]
@@ -128,7 +141,7 @@ hipError_t launch_wino_input(const WinoParams& p, hipStream_t st);
 hipError_t launch_wino_output(const WinoParams& p, hipStream_t st);
 void wino_weight_transform(const float g[9], float u[16]);   // host: U = G g G^T
 
-struct ConvSplit { int full_tiles, split_tiles, split_blocks, ksplit; };
+struct ConvSplit { int full_tiles, split_tiles, split_blocks, ksplit; int sk_grid = 0; };
 ConvSplit conv_plan_split(int M, int Npad, int KT, int tile);      // decision (shape-only, deterministic)
 size_t conv_split_slab_bytes(const ConvSplit& sp, int tile);
 
@@ -164,6 +177,8 @@ struct DecodeParams {
     int layer_id;
 };
 hipError_t launch_decode(int kind, const DecodeParams& p, hipStream_t st);
+// decode_epistemic's dict entries outside the box row: ev_loc [B,lh,lw,3,4], covar [B,lh,lw,3,4,4], obj / cls samples
+hipError_t launch_epi_stats(const DecodeParams& p, float* ev_loc, float* covar, float* obj_s, float* cls_s, hipStream_t st);
 
 size_t nms_workspace_bytes(int B, int64_t N);
 struct NmsParams {

@@ -27,6 +27,8 @@
 //     double-buffer index is a compile-time constant);
 //   * the K-tile sequencing (tap, channel chunk, weight offset) lives in SGPRs.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
 #include <type_traits>
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
@@ -86,9 +88,15 @@ __device__ __forceinline__ void sched_interleave() {
 // computes K-tiles [kt_begin, kt_end) of tile `logical`, writes its raw accumulators to slab
 // (slice_tile, slice) and draws a ticket; the block that draws the last ticket of the tile sums the slabs
 // in slice order (deterministic) and runs the epilogue.
+// How a partial tile (K-tiles [kt_begin, kt_end) of a tile) is handed over: the block writes its raw accumulators
+// to slab `my_slab` and draws a ticket from counters[counter]; the block that draws ticket nseg - 1 sums the slabs
+// of segments k = 0 .. nseg-1 -- slab index base + k * stride (+ first_add for k = 0) -- in that order and runs
+// the epilogue.  counter < 0: the block computes the whole tile.
+struct TileShare { int counter, my_slab, nseg, base, stride, first_add; };
+
 template <int BM, int BN, int WM, int WN, bool FAST>
 __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical, const int kt_begin,
-                                          const int kt_end, const int slice_tile, const int slice) {
+                                          const int kt_end, const TileShare sh) {
     constexpr int NT = 64 * WM * WN;            // threads per block
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_LD = BM * 8 / NT;           // 16-byte loads per thread per A tile
@@ -330,12 +338,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     // No release/acquire fence (an agent-scope release = buffer_wbl2 writes back the whole L2; hundreds of
     // slice blocks doing that at the end of a launch cost more than the split saved).  Correct for any
     // placement of a tile's slices on XCDs / CUs.
-    if (slice_tile >= 0) {
+    if (sh.counter >= 0) {
         constexpr uint32_t SLAB_B = BM * BN * 4;     // bytes; lane-linear image: float4 q of thread t at (q * NT + t) * 16
         constexpr int SC1 = 16;
         const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.slabs, 0, p.slab_bytes, RSRC_FLAGS);
-        const uint32_t tile_off = (uint32_t)slice_tile * (uint32_t)p.ksplit * SLAB_B;
-        const uint32_t my_off = tile_off + (uint32_t)slice * SLAB_B;
+        const uint32_t my_off = (uint32_t)sh.my_slab * SLAB_B;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -352,11 +359,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         __syncthreads();                         // also: every wave is done with the LDS tiles
         int* flag = reinterpret_cast<int*>(smem);
         if (tid == 0) {
-            const unsigned ticket = __hip_atomic_fetch_add(p.counters + slice_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool is_last = ticket == (unsigned)p.ksplit - 1u;
+            const unsigned ticket = __hip_atomic_fetch_add(p.counters + sh.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool is_last = ticket == (unsigned)sh.nseg - 1u;
             *flag = is_last;
             // leave the counter at zero for the next launch that uses it (several launches of one step share them)
-            if (is_last) __hip_atomic_store(p.counters + slice_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (is_last) __hip_atomic_store(p.counters + sh.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         const int last = *flag;
@@ -368,8 +375,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int sl = 0; sl < p.ksplit; ++sl) {      // slice order: the sum does not depend on arrival order
-            const uint32_t off = tile_off + (uint32_t)sl * SLAB_B;
+        for (int sl = 0; sl < sh.nseg; ++sl) {       // segment order: the sum does not depend on arrival order
+            const uint32_t off = (uint32_t)(sh.base + sl * sh.stride + (sl == 0 ? sh.first_add : 0)) * SLAB_B;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -542,23 +549,55 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
 template <int BM, int BN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // blocks [0, full_tiles): whole tiles, each XCD a contiguous range of them;
-    // blocks beyond: K slices of the remaining tiles -- slices of one tile on one XCD (block id % 8),
-    // neighbours in dispatch order: id = full_tiles + ((tile_local / 8) * ksplit + slice) * 8 + tile_local % 8
+    // One loop, one inlined conv_tile: the work items of this workgroup are either
+    //  (stream-K, p.sk_grid > 0) the tiles its share of the launch's tiles * KT units overlaps.  Workgroup order =
+    //    unit order per XCD (xcd_remap), so the tiles in flight on an XCD are neighbours and most split tiles stay on
+    //    one XCD; a straddling tile's slabs are indexed by the workgroup that wrote them (2 per workgroup: the head and
+    //    the tail of its range), its ticket counter by the workgroup that owns its first unit; or
+    //  (otherwise) blocks [0, full_tiles): whole tiles, each XCD a contiguous range of them; blocks beyond: K slices of
+    //    the remaining tiles -- slices of one tile on one XCD (block id % 8), neighbours in dispatch order:
+    //    id = full_tiles + ((tile_local / 8) * ksplit + slice) * 8 + tile_local % 8
+    const bool sk = p.sk_grid > 0;
+    const uint32_t q = (uint32_t)p.sk_q, r = (uint32_t)p.sk_r, KT = (uint32_t)p.KT;
+    auto start = [&](uint32_t w) { return w * q + (w < r ? w : r); };
+    auto owner = [&](uint32_t u) { return u < r * (q + 1) ? fdiv(u, p.d_skq1) : r + fdiv(u - r * (q + 1), p.d_skq); };
+    const uint32_t g = sk ? (uint32_t)xcd_remap(blockIdx.x, p.sk_grid) : 0u;
+    uint32_t u = sk ? start(g) : 0u;
+    const uint32_t u_end = sk ? start(g + 1) : 0u;
     const int total = p.full_tiles + p.split_blocks;
-    for (int v = blockIdx.x; v < total; v += gridDim.x) {
-        int logical = xcd_remap(v, p.full_tiles), kb = 0, ke = p.KT, tile_local = -1, slice = 0;
-        if (v >= p.full_tiles) {
-            const uint32_t id = (uint32_t)(v - p.full_tiles), i = id >> 3, x = id & 7u;
-            const uint32_t grp = fdiv(i, p.d_ksplit);
-            slice = (int)(i - grp * (uint32_t)p.ksplit);
-            tile_local = (int)(grp * 8u + x);
-            if (tile_local >= p.split_tiles) continue;
-            logical = p.full_tiles + tile_local;
-            kb = (int)fdiv((uint32_t)slice * (uint32_t)p.KT, p.d_ksplit);
-            ke = (int)fdiv((uint32_t)(slice + 1) * (uint32_t)p.KT, p.d_ksplit);
+    int v = blockIdx.x;
+    for (;;) {
+        int logical, kb, ke;
+        TileShare sh{-1, 0, 1, 0, 0, 0};
+        if (sk) {
+            if (u >= u_end) break;
+            const uint32_t t = fdiv(u, p.d_kt), t0 = t * KT;
+            logical = (int)t; kb = (int)(u - t0); ke = (int)((u_end - t0 < KT) ? u_end - t0 : KT);
+            if (kb != 0 || ke != (int)KT) {                      // this tile straddles workgroups
+                const uint32_t g_first = owner(t0), g_last = owner(t0 + KT - 1);
+                const int first_add = start(g_first) != t0;     // g_first's segment is the tail of ITS range
+                sh.counter = (int)g_first; sh.nseg = (int)(g_last - g_first + 1);
+                sh.base = 2 * (int)g_first; sh.stride = 2; sh.first_add = first_add;
+                sh.my_slab = 2 * (int)g + ((g == g_first && first_add) ? 1 : 0);
+            }
+            u = t0 + (uint32_t)ke;
+        } else {
+            if (v >= total) break;
+            const int cur = v;
+            v += gridDim.x;
+            logical = xcd_remap(cur, p.full_tiles); kb = 0; ke = p.KT;
+            if (cur >= p.full_tiles) {
+                const uint32_t id = (uint32_t)(cur - p.full_tiles), i = id >> 3, x = id & 7u;
+                const uint32_t grp = fdiv(i, p.d_ksplit);
+                const int slice = (int)(i - grp * (uint32_t)p.ksplit), tile_local = (int)(grp * 8u + x);
+                if (tile_local >= p.split_tiles) continue;
+                logical = p.full_tiles + tile_local;
+                kb = (int)fdiv((uint32_t)slice * (uint32_t)p.KT, p.d_ksplit);
+                ke = (int)fdiv((uint32_t)(slice + 1) * (uint32_t)p.KT, p.d_ksplit);
+                sh = TileShare{tile_local, tile_local * p.ksplit + slice, p.ksplit, tile_local * p.ksplit, 1, 0};
+            }
         }
-        conv_tile<BM, BN, WM, WN, FAST>(p, smem, logical, kb, ke, tile_local, slice);
+        conv_tile<BM, BN, WM, WN, FAST>(p, smem, logical, kb, ke, sh);
     }
 }
 
@@ -592,16 +631,35 @@ static int tile_slots(int tile) { return 256 * (tile == TILE_128x32 ? 3 : 2); }
 ConvSplit conv_plan_split(int M, int Npad, int KT, int tile) {
     const int BN = conv_tile_bn(tile), slots = tile_slots(tile);
     const int tiles = ((M + 127) / 128) * (Npad / BN);
-    ConvSplit r; r.full_tiles = tiles; r.split_tiles = 0; r.ksplit = 1; r.split_blocks = 0;
+    ConvSplit r; r.full_tiles = tiles; r.split_tiles = 0; r.ksplit = 1; r.split_blocks = 0; r.sk_grid = 0;
     // BYOLO_KSPLIT: 0 = never split, n > 1 = always n slices (tests, A/B); read when a handle plans a (B, T)
     const char* env = getenv("BYOLO_KSPLIT");
     const int knob = env ? atoi(env) : -1;
-    const int rem = tiles % slots;
-    if (knob == 0 || rem == 0) return r;
     // microseconds: K-tile and tile overhead of a whole tile, overhead of a slice (prologue, sc1 slab
     // round trip, ticket; measured on the 19x19 .. 76x76 head shapes and the small backbone launches)
     const double t_k = 1.8 * BN / 128.0, t_o = 3.3, t_slice = 16.0;
     const double whole = KT * t_k + t_o;
+    // ---- stream-K for small launches --------------------------------------------------------------------------
+    // Fewer tiles than a few rounds of resident workgroups: a whole-tile schedule either leaves CUs idle (tiles <
+    // CUs: a tile runs on ONE CU, however long its K loop) or pays a nearly empty last round (676 tiles on 512 slots
+    // = 2 rounds for 1.32 rounds of work).  Here every resident workgroup takes an equal share of the launch's
+    // tiles * KT K-tile units; cost in tile-times = share + hand-off of the (at most two) partial tiles of a workgroup.
+    // BYOLO_STREAMK: 0 never, 1 when the model predicts a gain (default), 2 whenever admissible (tests).
+    const char* se = getenv("BYOLO_STREAMK");
+    const int sk_knob = se ? atoi(se) : 1;
+    if (sk_knob && knob < 0 && KT >= 2) {
+        const int64_t U = (int64_t)tiles * KT;
+        int G = (int)std::min<int64_t>(slots, U / (sk_knob >= 2 ? 1 : 6)) & ~7;       // >= 6 K-tiles per workgroup
+        if (G >= 8 && U * G < ((int64_t)1 << 31) && U > G) {
+            const double rounds = (double)tiles / slots;
+            const double plain = tiles * 2 <= slots ? 0.95 : std::ceil(rounds);       // <= one workgroup per CU: a lone tile-time
+            // a workgroup's share in tile-times (two workgroups share a CU's matrix pipe unless G <= CUs) + the hand-off
+            const double sk = (double)tiles / G * (G * 2 <= slots ? 0.6 : 1.0) + t_slice / whole;
+            if (sk_knob >= 2 || (rounds < 4.0 && sk < 0.93 * plain)) { r.sk_grid = G; return r; }
+        }
+    }
+    const int rem = tiles % slots;
+    if (knob == 0 || rem == 0) return r;
     // a round that leaves at most one workgroup per CU runs faster than a full one (a lone workgroup owns
     // the matrix pipe), IF the dispatcher spreads it -- it does not always: 0.8 / 0.7 are averages
     // (measured: bimodal 0.58 / 1.0 for the 128x128 tile, always spread for the 128x64 tile)
@@ -622,6 +680,7 @@ ConvSplit conv_plan_split(int M, int Npad, int KT, int tile) {
     return r;
 }
 size_t conv_split_slab_bytes(const ConvSplit& sp, int tile) {
+    if (sp.sk_grid > 0) return (size_t)2 * sp.sk_grid * 128 * conv_tile_bn(tile) * sizeof(float);
     return sp.ksplit > 1 ? (size_t)sp.split_tiles * sp.ksplit * 128 * conv_tile_bn(tile) * sizeof(float) : 0;
 }
 
@@ -633,11 +692,18 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     q.d_ks = make_fastdiv((uint32_t)p.ksize);
     const int tiles = ((p.M + BM - 1) / BM) * (p.Npad / BN);
     if (p.ksplit <= 1 || !p.slabs || !p.counters) { q.full_tiles = tiles; q.split_tiles = 0; q.split_blocks = 0; q.ksplit = 1; }
+    if (!p.slabs || !p.counters || p.sk_grid <= 0 || (int64_t)tiles * p.KT <= p.sk_grid) q.sk_grid = 0;
     q.d_ksplit = make_fastdiv((uint32_t)q.ksplit);
     int grid = q.full_tiles + q.split_blocks;
+    if (q.sk_grid > 0) {
+        const uint32_t U = (uint32_t)tiles * (uint32_t)p.KT;
+        q.sk_q = (int)(U / (uint32_t)q.sk_grid); q.sk_r = (int)(U % (uint32_t)q.sk_grid);
+        q.d_skq = make_fastdiv((uint32_t)q.sk_q); q.d_skq1 = make_fastdiv((uint32_t)q.sk_q + 1u); q.d_kt = make_fastdiv((uint32_t)p.KT);
+        grid = q.sk_grid;
+    }
     // BYOLO_PERSIST = workgroups per CU of a persistent grid (0 = one workgroup per tile; tuning knob)
     static const int persist = [] { const char* e = getenv("BYOLO_PERSIST"); return e ? atoi(e) : 0; }();
-    if (persist > 0 && grid > 256 * persist) grid = 256 * persist;
+    if (persist > 0 && q.sk_grid == 0 && grid > 256 * persist) grid = 256 * persist;
     const bool fast = p.C1 == 0 && p.sh0 == 0 && p.ksize <= 3;
     return fast ? launch_one<BM, BN, WM, WN, true>(q, grid, st) : launch_one<BM, BN, WM, WN, false>(q, grid, st);
 }

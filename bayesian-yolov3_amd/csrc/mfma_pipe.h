@@ -1,0 +1,170 @@
+// mfma_pipe.h -- the ONE definition of the fp32 matrix-pipe software pipeline every GEMM-shaped kernel of this library
+// runs (conv_igemm.hip, gemm_stream.hip, wino_fused.hip): block tile BM x BN x 32 staged in LDS, fragment scheme,
+// MFMA group, and the per-K-tile schedule that places every auxiliary instruction between two MFMAs.
+//
+// Design rule (measured, tools/mfma_peak.hip): fp32 MFMA (v_mfma_f32_32x32x2_f32) and the vector ALU share the SIMD's
+// FP32 lanes -- a vector-ALU instruction is NOT hidden under an MFMA, global loads / LDS traffic / scalar ALU / waits
+// are.  So the steady-state K loop carries no vector-ALU instruction: operands come through buffer loads whose
+// addresses are a loop-invariant VGPR + an SGPR offset, every LDS address is a loop-invariant VGPR + an immediate
+// (the loop is unrolled x2 so that the double-buffer index is a compile-time constant).
+//
+// LDS image (bytes): A[2][BM][LD] then B[2][BN][LD], LD = 36 floats per staged row (32 + 4 pad: the ds_write_b128
+// staging stores and the ds_read_b128 fragment reads are bank-conflict free).  The K order inside a 32-slice is
+// permuted: lane-half h of MFMA step j of quarter q consumes k = 8q + 4h + j, so ONE ds_read_b128 per operand feeds four
+// MFMA steps.  The MFMAs compute the TRANSPOSED tile (srcA = B operand, srcB = A operand): in the 32x32 C/D map
+//   col = lane & 31 -> A row (pixel),   row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -> B row (channel)
+// so a lane owns one pixel and 4 groups of 4 CONSECUTIVE channels -- NHWC stores are 16-byte vectors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "byolo_kernels.h"
+
+namespace byk {
+namespace pipe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BK = 32;
+static constexpr int LD = 36;                     // floats per staged row
+static constexpr int RSRC_FLAGS = 0x00020000;     // raw buffer, 32-bit data format (gfx9 family)
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shr; }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, RSRC_FLAGS);
+}
+template <int AUX = 0>                                 // AUX: cache-policy bits of the instruction (16 = sc1)
+__device__ __forceinline__ f32x4 buffer_load_x4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
+
+// Scheduling pattern for one MFMA group: after every MFMA place ceil(aux / N_MFMA) auxiliary instructions, in the
+// order global loads -> LDS reads -> LDS writes (LLVM SchedGroupMask: MFMA 0x8, VMEM_READ 0x20, DS_READ 0x100,
+// DS_WRITE 0x200).
+template <int N_MFMA, int N_VMEM, int N_DSR, int N_DSW>
+__device__ __forceinline__ void sched_interleave() {
+    constexpr int AUX = N_VMEM + N_DSR + N_DSW;
+    constexpr int PER = (AUX + N_MFMA - 1) / N_MFMA;
+#pragma unroll
+    for (int k = 0; k < N_MFMA; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int q = k * PER + u;
+            if (q < N_VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            else if (q < N_VMEM + N_DSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (q < AUX) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    }
+}
+
+// Geometry of a block tile and the per-thread LDS addresses.  Block = WM x WN waves; a wave owns TM x TN accumulators
+// of 32 x 32; every thread stages the same A_LD rows of A and B_LD rows of B of every K-tile (16 bytes each).
+template <int BM_, int BN_, int WM_, int WN_>
+struct BlockTile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int NT = 64 * WM * WN;
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static constexpr int A_LD = BM * 8 / NT, B_LD = BN * 8 / NT;
+    static constexpr int ROWB = LD * 4, A_BUF = BM * ROWB, B_BUF = BN * ROWB, B_BASE = 2 * A_BUF;
+    static constexpr int JSTEP = (NT / 8) * ROWB;            // staging rows of one thread are NT/8 apart
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * ROWB;
+    static constexpr int G = 4 * TM * TN;                    // MFMAs per group (a quarter K-tile) per wave
+    static constexpr int NFR = TM + TN;                      // fragment reads per group
+    static constexpr int NLD = A_LD + B_LD;                  // 16-byte loads / LDS stores per K-tile per thread
+    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile config");
+
+    char* lds;
+    int tid, wm, wn, li, lh;          // wave row / column in the block; lane & 31, lane >> 5
+    int a_q, a_r;                     // staging: 16-byte column tid % 8, row tid / 8 (+ NT/8 per j)
+    int st_off, fa_off, fb_off;
+
+    __device__ __forceinline__ explicit BlockTile(float* smem) {
+        lds = reinterpret_cast<char*>(smem);
+        tid = threadIdx.x;
+        const int wave = tid >> 6, lane = tid & 63;
+        wm = wave / WN; wn = wave % WN;
+        li = lane & 31; lh = lane >> 5;
+        a_q = tid & 7; a_r = tid >> 3;
+        st_off = (a_r * LD + a_q * 4) * 4;
+        fa_off = ((wm * TM * 32 + li) * LD + lh * 4) * 4;
+        fb_off = ((wn * TN * 32 + li) * LD + lh * 4) * 4;
+    }
+    template <int BUF> __device__ __forceinline__ void store_a(const f32x4 (&a)[A_LD]) const {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (BUF * A_BUF + j * JSTEP)) = a[j];
+    }
+    template <int BUF> __device__ __forceinline__ void store_b(const f32x4 (&b)[B_LD]) const {
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (B_BASE + BUF * B_BUF + j * JSTEP)) = b[j];
+    }
+    template <int BUF, int KQ> __device__ __forceinline__ void read_frags(f32x4 (&af)[TM], f32x4 (&bf)[TN]) const {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(lds + fa_off + (BUF * A_BUF + KQ * 32 + i * 32 * ROWB));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(lds + fb_off + (B_BASE + BUF * B_BUF + KQ * 32 + j * 32 * ROWB));
+    }
+};
+
+// 4 k-steps x TM x TN MFMAs on one fragment set.  FIRST: the very first MFMA into each accumulator takes an inline-zero
+// C operand instead of the accumulator (no vector-ALU clears).
+template <int TM, int TN, bool FIRST = false>
+__device__ __forceinline__ void mfma_group(f32x16 (&acc)[TM][TN], const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], (FIRST && s == 0) ? zero : acc[i][j], 0, 0, 0);
+}
+
+// One K-tile t of the software pipeline; tile t lives in LDS buffer BUF = t & 1, its first fragments already in
+// (af0, bf0).  An fp32 MFMA occupies the matrix pipe for 64 cycles and a wave issues in order, so any RUN of non-MFMA
+// instructions longer than that lets the pipe drain: the body is branch-free and every auxiliary instruction sits
+// BETWEEN two MFMAs.  Per K-tile, 4 groups of G MFMAs per wave:
+//   group 0 | [loads0: early global loads, N_LD0 instructions]  LDS fragment reads of group 1
+//   group 1 | fragment reads of group 2
+//   group 2 | fragment reads of group 3, then (HN) the LDS writes of tile t+1 into the other buffer (N_ST instructions)
+//   barrier   (every read of the current buffer is in registers, tile t+1 is visible afterwards)
+//   group 3 | [loads3: global loads of tile t+2 into the staging registers just freed, N_LD3 instructions],
+//           | (HN) fragment reads of group 0 of tile t+1  -> barrier + LDS latency hide under group 3
+// mfma(af, bf, group) issues one group; ABL = timing-ablation bits of the conv build (1: handled by the caller's
+// loads, 2: by its store, 4 no barrier, 8 no fragment reads).
+template <int BUF, bool HN, int N_LD0, int N_LD3, int N_ST, int ABL = 0, class BT, class Mfma, class L0, class L3, class St>
+__device__ __forceinline__ void tile_body(const BT& t, f32x4 (&af0)[BT::TM], f32x4 (&bf0)[BT::TN], f32x4 (&af1)[BT::TM],
+                                          f32x4 (&bf1)[BT::TN], Mfma&& mfma, L0&& loads0, L3&& loads3, St&& store_next) {
+    constexpr int G = BT::G;
+    constexpr bool FR = !(ABL & 8);
+    constexpr int NFR = FR ? BT::NFR : 0;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (N_LD0 > 0) loads0();
+    if constexpr (FR) t.template read_frags<BUF, 1>(af1, bf1);
+    mfma(af0, bf0, 0);
+    sched_interleave<G, N_LD0, NFR, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+
+    if constexpr (FR) t.template read_frags<BUF, 2>(af0, bf0);
+    mfma(af1, bf1, 1);
+    sched_interleave<G, 0, NFR, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+
+    if constexpr (FR) t.template read_frags<BUF, 3>(af1, bf1);
+    if constexpr (HN) store_next();
+    mfma(af0, bf0, 2);
+    sched_interleave<G, 0, NFR, HN ? N_ST : 0>();
+    __builtin_amdgcn_sched_barrier(0);
+
+    if constexpr (!(ABL & 4)) __syncthreads();
+    if constexpr (N_LD3 > 0) loads3();
+    if constexpr (HN && FR) t.template read_frags<BUF ^ 1, 0>(af0, bf0);
+    mfma(af1, bf1, 3);
+    sched_interleave<G, N_LD3, HN ? NFR : 0, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+}  // namespace pipe
+}  // namespace byk

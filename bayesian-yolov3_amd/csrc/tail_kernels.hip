@@ -9,6 +9,7 @@
 //                             (inference_epistemic.py:99-128 incl. the commented 2-class variant)
 // HBM-bound / dependency-bound byte work: no MFMA here.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <float.h>
 #include "byolo_kernels.h"
 
@@ -226,6 +227,84 @@ __global__ void decode_epi_kernel(const DecodeParams p) {
         o[19 + C] = (float)p.layer_id;
         o[20 + C] = (float)pr;
     }
+}
+
+// The entries of decode_epistemic's dict (lib_yolo/layers.py:397-411) that are not columns of the box row: the mean
+// raw location logits `ev_loc`, the full 4x4 `epi_covar_loc` (same one-pass sums as decode_epi_kernel: its diagonal
+// equals the row's columns 4..7 bit for bit) and the per-sample `obj_samples` / `cls_samples`.  One lane per
+// (image, cell, prior); any output may be null.
+template <int CM, bool EXACT>
+__global__ void epi_stats_kernel(const DecodeParams p, float* ev_loc, float* covar, float* obj_s, float* cls_s) {
+    const int C = EXACT ? CM : p.C;
+    const int BLK = 2 * (5 + C);
+    const int cells = p.lh * p.lw;
+    const int64_t total = (int64_t)p.B * cells * 3;
+    const size_t sample_stride = (size_t)cells * 3 * BLK;
+    const float invT = 1.0f / (float)p.T;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int pr = (int)(gid % 3);
+        const int64_t bc = gid / 3;
+        const int cell = (int)(bc % cells), b = (int)(bc / cells);
+        const float* d0 = p.raw + ((size_t)b * p.T) * sample_stride + (size_t)cell * (3 * BLK) + pr * BLK;
+        float s_loc[4] = {0, 0, 0, 0}, s_ll[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < p.T; ++t) {
+            const float* d = d0 + (size_t)t * sample_stride;
+            float v[10 + CM];
+#pragma unroll
+            for (int i = 0; i < 10 + CM; ++i) if (EXACT || i < 10 + C) v[i] = d[i];
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s_loc[i] += v[i];
+#pragma unroll
+                for (int j = i; j < 4; ++j) s_ll[q++] += v[i] * v[j];
+            }
+            const size_t so = (((size_t)b * p.T + t) * cells + cell) * 3 + pr;       // [S, lh, lw, 3]
+            if (obj_s) obj_s[so] = sigmoidf_(v[8]);
+            if (cls_s) {
+                float pc[CM];
+                softmax_<CM, EXACT>(v + 10, pc, C);
+#pragma unroll
+                for (int c = 0; c < CM; ++c) if (EXACT || c < C) cls_s[so * C + c] = pc[c];
+            }
+        }
+        float ev[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ev[i] = s_loc[i] * invT;
+        const size_t o = ((size_t)b * cells + cell) * 3 + pr;                        // [B, lh, lw, 3]
+        if (ev_loc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ev_loc[o * 4 + i] = ev[i];
+        }
+        if (covar) {
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = i; j < 4; ++j) {
+                    const float c = s_ll[q++] * invT - ev[i] * ev[j];                // E[l l^T] - E[l]E[l]^T (layers.py:383)
+                    covar[o * 16 + i * 4 + j] = c; covar[o * 16 + j * 4 + i] = c;
+                }
+        }
+    }
+}
+
+template <int CM, bool EXACT>
+static hipError_t launch_epi_stats_c(const DecodeParams& p, float* ev, float* cov, float* os, float* cs, hipStream_t st) {
+    const int64_t total = (int64_t)p.B * p.lh * p.lw * 3;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(4096, (total + 255) / 256));
+    hipLaunchKernelGGL((epi_stats_kernel<CM, EXACT>), dim3((unsigned)blocks), dim3(256), 0, st, p, ev, cov, os, cs);
+    return hipGetLastError();
+}
+
+hipError_t launch_epi_stats(const DecodeParams& p, float* ev, float* cov, float* os, float* cs, hipStream_t st) {
+    if (p.C < 1 || p.C > BYOLO_MAX_CLASSES) return hipErrorInvalidValue;
+    if (p.C == 2) return launch_epi_stats_c<2, true>(p, ev, cov, os, cs, st);
+    if (p.C <= 8) return launch_epi_stats_c<8, false>(p, ev, cov, os, cs, st);
+    if (p.C <= 24) return launch_epi_stats_c<24, false>(p, ev, cov, os, cs, st);
+    if (p.C <= 48) return launch_epi_stats_c<48, false>(p, ev, cov, os, cs, st);
+    return launch_epi_stats_c<BYOLO_MAX_CLASSES, false>(p, ev, cov, os, cs, st);
 }
 
 template <int CM, bool EXACT>

@@ -303,22 +303,28 @@ class DetLayer:
 
     @property
     def det(self):
-        """The per-(cell, prior) statistics of `layers.decode_epistemic` (`lib_yolo/layers.py:397-411`) that
-        consumers such as `vis_uncertainty.py` read, as views/derivations of the last run's box rows
-        (epistemic detection layers only; image 0, like the reference's batch-1 tensors):
-        `epi_covar_loc` [lh,lw,3,4,4] (diagonal only -- the off-diagonal covariances are reduced to the
-        determinant on the device and are not exported), `ale_var_loc` [lh,lw,3,4], `obj_mean`,
-        `obj_mutual_info`, `obj_entropy`, `cls_mutual_info`, `cls_entropy` [lh,lw,3], `cls_mean` [lh,lw,3,C]."""
+        """The dict of `layers.decode_epistemic` (`lib_yolo/layers.py:397-411`) for the last run, image 0 (the
+        reference's tensors have no batch axis: it asserts batch 1) -- every key of the reference's dict with the
+        reference's shapes: `ev_loc` [lh,lw,3,4], `epi_covar_loc` [lh,lw,3,4,4] (full covariance), `ale_var_loc`
+        [lh,lw,3,4], `obj_samples` [T,lh,lw,3], `obj_mean`, `obj_mutual_info`, `obj_entropy` [lh,lw,3], `cls_samples`
+        [T,lh,lw,3,C], `cls_mean` [lh,lw,3,C], `cls_mutual_info`, `cls_entropy` [lh,lw,3].  The reduced statistics
+        are views of the decoded box rows; `ev_loc`, the off-diagonal covariances and the per-sample tensors come
+        from the layer's raw output through byolo_epistemic_stats (same one-pass sums as the decode kernel)."""
         import torch
         if self.kind != DET_EPISTEMIC:
             raise AttributeError('det statistics exist for epistemic detection layers only')
         per_prior = [b[0] for b in self.bbox]                          # 3 x [lh, lw, D]
         rows = torch.stack(per_prior, dim=2)                           # [lh, lw, 3, D]
         C = self._model.cls_cnt
+        T = self._model.T
+        raw = self.raw_output                                          # [B*T, lh, lw, F]
+        st = self._model.engine.epistemic_stats(raw[:T].contiguous(), 1, T)
         return {
-            'epi_covar_loc': torch.diag_embed(rows[..., 4:8]),
+            'ev_loc': st['ev_loc'][0], 'epi_covar_loc': st['epi_covar_loc'][0],
             'ale_var_loc': rows[..., 8:12],
+            'obj_samples': st['obj_samples'],
             'obj_mean': rows[..., 14], 'obj_mutual_info': rows[..., 15], 'obj_entropy': rows[..., 16],
+            'cls_samples': st['cls_samples'],
             'cls_mean': rows[..., 17:17 + C], 'cls_mutual_info': rows[..., 17 + C], 'cls_entropy': rows[..., 18 + C],
         }
 
@@ -328,7 +334,7 @@ class DetLayer:
 
     @property
     def raw_output(self):
-        """Raw detection-conv output [S,lh,lw,F] of the last run (engine built with keep_all_outputs)."""
+        """Raw detection-conv output [S,lh,lw,F] of the last run."""
         return self._model.engine.layer_output(self._raw_ref.index)
 
     def matches_blueprint(self, blueprint):

@@ -11,11 +11,23 @@ per-box T-reduction + decode, sort + NMS, and (N > 1) ONE RCCL all-gather of the
 Weights are random-init with BN statistics calibrated on the device (no checkpoints, no network).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel = the fp32-MFMA kernel with the most
-device time in the timed region (the fused Winograd-domain GEMM at this config; `by_kernel` lists all of them):
-EXECUTED matrix-pipe FLOPs (2*M*N*K of every launch) divided by their device time, measured with hipEvents
-recorded around every launch on the launch stream (byolo_step_profile).  The ALGORITHMIC view (direct-convolution
-FLOPs of the graph as written) is `all_conv_algorithmic` and `end_to_end_frac`; with Winograd
-F(2x2,3x3) on the large 3x3 layers these exceed what the matrix pipe executes.
+device time in the timed region (the fused Winograd-domain GEMM at this config; `by_kernel` lists all of them), its
+launches timed with hipEvents recorded around every launch on the launch stream (byolo_step_profile; the records of
+all K steps are read AFTER the timed region -- no host synchronisation inside it).  One definition:
+
+  achieved / frac        USEFUL matrix-pipe FLOP/s of those launches / the fp32 MFMA peak.  Useful = the multiplies the
+                         algorithm needs for the outputs it delivers: 2*M*N*K of a direct convolution launch; for a
+                         Winograd-domain GEMM launch the direct-convolution FLOPs of its samples / 2.25 (F(2x2,3x3):
+                         16 multiplies per 2x2 outputs instead of 36) -- tile padding (19x19 -> 20x20, rows to 128) is
+                         NOT counted as work;
+  frac_executed_padded   what the matrix pipe executed (2*M*N*K of the padded extents) / peak;
+  achieved_algorithmic   the same launches priced by the direct-convolution FLOPs they stand for (SURVEY.md 8d's
+                         per-image figure is made of these); `end_to_end_frac` = img/s * F(H,W,T) / peak is 8d's formula
+                         for the whole step.  Both exceed 1 where Winograd runs: they are not utilisations;
+  traffic                L2<->fabric bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes over
+                         this command (tools/pmc_traffic.py -> profiles/traffic_cfgN.json, stamped with the commit it
+                         was measured at: `traffic_measured_at`), `traffic_vs_algorithmic` = that / (V once + output
+                         once + weights once).
 `cpu_baseline` is the oracle's CPU restatement (PyTorch/oneDNN, NOT TensorFlow) on a bounded sample.
 """
 import argparse
@@ -86,6 +98,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=4, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the config's images per GPU on every GPU (default); strong: --global-batch images in total, "
+                         "global/N per GPU (SURVEY.md 8d: global B = 64 at config 4)")
+    ap.add_argument("--global-batch", type=int, default=64, help="strong scaling: images per step over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch hipEvents in the timed region")
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many concurrent HIP streams")
@@ -110,6 +126,9 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["B"] = args.batch
+    if args.scaling == "strong":
+        assert args.global_batch % world == 0, "--global-batch must divide by the number of GPUs"
+        cfg["B"] = args.global_batch // world
     m = build(cfg, device)
     eng = m.engine
     B, T = cfg["B"], cfg["T"]
@@ -162,10 +181,14 @@ def main():
         return r["rows"], r["kept"], r["count"]
 
     prof = not args.no_profile and nstreams == 1 and npipe == 1    # the handle's event set belongs to one forward at a time
+    eng.set_profiling(2 if prof else 0)          # on during the warm-up as well: the event pools exist before the timed region
     for i in range(args.warmup):
         step(i)
+    n_sub = -(-B // eng.max_images(T))           # byolo_forward calls per step (a batch beyond max_images runs as sub-batches)
+    if prof:
+        eng.set_profile_depth(args.steps * n_sub)   # every step's launch records stay readable until after the run
     eng.set_profiling(2 if prof else 0)
-    acc = {}                      # variant -> [flops, ms, launches]
+    acc = {}                      # variant -> [algorithmic flops, ms, launches, executed flops, useful flops, algorithmic bytes]
     per_launch = {}
     stage = {"backbone": 0.0, "heads": 0.0, "decode": 0.0, "sort_nms": 0.0}
     if pg:
@@ -174,15 +197,6 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-        if prof:
-            # reading the events waits for this step only; the timed region stays back-to-back
-            for j, s in enumerate(eng.step_profile()):
-                a = acc.setdefault(s["variant"], [0.0, 0.0, 0, 0.0])
-                a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1; a[3] += s["flops_executed"]
-                if args.dump_steps:
-                    per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / args.steps
-            for k, v in eng.stage_ms().items():
-                stage[k] += v
     torch.cuda.synchronize()
     if pg:
         dist.barrier()
@@ -192,13 +206,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if prof and rank == 0:
+        # the timed region is over: read the K steps' records (age K-1 = the first timed step)
+        WINO = (129, 130)
+        for age in range(args.steps * n_sub - 1, -1, -1):
+            eng.select_profile(age)
+            for j, s in enumerate(eng.step_profile()):
+                a = acc.setdefault(s["variant"], [0.0, 0.0, 0, 0.0, 0.0, 0.0])
+                wino = s["variant"] in WINO
+                a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1; a[3] += s["flops_executed"]
+                a[4] += s["flops"] / 2.25 if wino else s["flops"]
+                # algorithmic bytes of the launch: A operand once + result once + weights once
+                a[5] += 4.0 * ((s["M"] * s["K"] + (s["M"] // 4) * s["N"] + 16 * s["K"] * s["N"]) if s["variant"] == 130 else
+                               (s["M"] * s["K"] + s["M"] * s["N"] + (16 if wino else 1) * s["K"] * s["N"]))
+                if args.dump_steps:
+                    per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / args.steps
+            for k, v in eng.stage_ms().items():
+                stage[k] += v
+        eng.select_profile(0)
     if rank == 0:
         imgs = world * B * args.steps
         flops_img = eng.flops(1, T)
         line = {
             "metric": "img/s at T=%d MC-dropout, %dx%d" % (T, cfg["H"], cfg["W"]),
             "value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" [EXPERIMENT: dropout off, invalid]" if args.no_dropout else ""),
             "config": {"workload": "%s: %s %dx%d T=%d, %d images/GPU (global batch %d), "
                                    "class-%s NMS max_out=1000, random-init weights with device-calibrated BN"
@@ -209,7 +241,9 @@ def main():
                        "gflop_per_image": flops_img / 1e9},
         }
         KERNELS = {130: "wino_fused_kernel (Winograd-domain GEMM + output transform + epilogue, fp32 v_mfma_f32_32x32x2_f32)",
-                   129: "gemm_stream_kernel (Winograd-domain GEMM, fp32 v_mfma_f32_32x32x2_f32)",
+                   129: "gemm_stream_kernel<128,0> (Winograd-domain GEMM, fp32 v_mfma_f32_32x32x2_f32)",
+                   131: "gemm_stream_kernel<128,1> (row-streaming 1x1 convolution)",
+                   132: "gemm_stream_kernel<64,*> (row-streaming 1x1 convolution / detection head, 64-wide tile)",
                    128: "conv_igemm_kernel<128,128,2,2,*> (fp32 v_mfma_f32_32x32x2_f32)",
                    64: "conv_igemm_kernel<128,64,2,2,*>", 32: "conv_igemm_kernel<128,32,4,1,*>"}
         mm = [v for v in acc if v in KERNELS]
@@ -219,22 +253,29 @@ def main():
             # a Winograd-domain GEMM launch executes 1/2.25 of the direct-convolution FLOPs it stands for (x tile padding),
             # and its transforms are separate, HBM-bound launches.
             dom = max(mm, key=lambda v: acc[v][1])
-            f, ms, n, fx = acc[dom]
+            f, ms, n, fx, fu, ab = acc[dom]
             tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for a in acc.values())
-            ach = fx / (ms * 1e-3)
+            ach = fu / (ms * 1e-3)
             wino_ms = sum(acc[v][1] for v in (-2, -3) if v in acc)
             # HBM/fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
             # over this same command (tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent
-            traffic = None
+            traffic = measured_at = None
             tpath = os.path.join(REPO, "profiles", "traffic_cfg%d.json" % args.config)
-            if os.path.exists(tpath) and not args.batch:
+            if os.path.exists(tpath) and not args.batch and args.scaling == "weak":
                 tj = json.load(open(tpath))
                 if tj.get("kernel", "").split("<")[0].strip() in KERNELS[dom]:
                     traffic = tj.get("traffic_bytes_per_launch")
+                    measured_at = tj.get("measured_at")
             line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                                "frac": ach / PEAK_FP32_MFMA, "traffic": traffic,
+                                "frac": ach / PEAK_FP32_MFMA, "traffic": traffic, "traffic_measured_at": measured_at,
+                                "algorithmic_bytes_per_launch": ab / n,
+                                "traffic_vs_algorithmic": (traffic / (ab / n)) if traffic else None,
                                 "kernel": KERNELS[dom],
                                 "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
+                                "definition": "achieved = useful FLOPs (direct: 2MNK; Winograd-domain GEMM: direct-convolution "
+                                              "FLOPs of its samples / 2.25, tile padding not counted) / hipEvent time of the launches",
+                                "achieved_executed_padded": fx / (ms * 1e-3) / 1e12,
+                                "frac_executed_padded": fx / (ms * 1e-3) / PEAK_FP32_MFMA,
                                 # the same launches priced by the direct-convolution FLOPs they stand for (SURVEY 8d's
                                 # per-image figure is made of these): not a matrix-pipe utilisation where Winograd runs
                                 "achieved_algorithmic": f / (ms * 1e-3) / 1e12,
@@ -242,7 +283,9 @@ def main():
                                 # algorithmic (direct-convolution) FLOPs of the whole conv stack / its time, transforms
                                 # included: exceeds what the matrix pipe executes where Winograd F(2x2,3x3) is used
                                 "all_conv_algorithmic": tot_f / (tot_ms * 1e-3) / 1e12,
-                                "by_kernel": {KERNELS[v].split(" ")[0]: {"launches": acc[v][2], "ms": acc[v][1], "executed_tflops": acc[v][3] / (acc[v][1] * 1e-3) / 1e12}
+                                "by_kernel": {KERNELS[v].split(" ")[0]: {"launches": acc[v][2], "ms": acc[v][1],
+                                                                          "useful_tflops": acc[v][4] / (acc[v][1] * 1e-3) / 1e12,
+                                                                          "executed_tflops": acc[v][3] / (acc[v][1] * 1e-3) / 1e12}
                                               for v in sorted(mm, key=lambda v: -acc[v][1])},
                                 "end_to_end_frac": (imgs / dt) * flops_img / (world * PEAK_FP32_MFMA)}
             line["stage_ms_per_step"] = {k: v / args.steps for k, v in stage.items()}

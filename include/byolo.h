@@ -139,7 +139,7 @@ BYOLO_API int32_t byolo_set_first_image(byolo_t* h, int64_t first_image);
 BYOLO_API int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images);
 /* After a forward with keep_all_outputs: device pointer + NHWC shape of layer `idx`'s output
  * (the reference's model.layers[idx], model.py:191); for detection layers the raw conv output
- * (DetLayer.raw_output, model.py:241). */
+ * (DetLayer.raw_output, model.py:241) -- those are readable on any handle (they are never overwritten). */
 BYOLO_API int32_t byolo_layer_output(const byolo_t* h, int32_t idx, const float** d_ptr, int64_t shape[4]);
 
 /* ---- staged tail entry points (parity tests on oracle-provided inputs) ------------------------ */
@@ -149,6 +149,14 @@ BYOLO_API int32_t byolo_layer_output(const byolo_t* h, int32_t idx, const float*
 BYOLO_API int32_t byolo_decode(byolo_t* h, int32_t kind, const float* d_raw, int32_t B, int32_t T, int32_t lh, int32_t lw,
                      const float* priors_hw /*[3][2] host*/, int32_t layer_id, float* d_boxes,
                      int64_t n_total, int64_t box_base, void* stream);
+/* The entries of decode_epistemic's dict (lib_yolo/layers.py:397-411) that are not columns of the box row, from the
+ * raw output d_raw [B*T,lh,lw,3*2*(5+C)] of an epistemic detection layer (byolo_layer_output): ev_loc [B,lh,lw,3,4]
+ * (mean raw location logits), epi_covar_loc [B,lh,lw,3,4,4] (full covariance; its diagonal is columns 4..7 of the box
+ * row), obj_samples [B*T,lh,lw,3] = sigmoid(obj), cls_samples [B*T,lh,lw,3,C] = softmax(cls).  Any output may be NULL.
+ * (vis_uncertainty.py:49-163 and other consumers of DetLayer.det.) */
+BYOLO_API int32_t byolo_epistemic_stats(byolo_t* h, const float* d_raw, int32_t B, int32_t T, int32_t lh, int32_t lw,
+                                        float* d_ev_loc, float* d_epi_covar, float* d_obj_samples, float* d_cls_samples,
+                                        void* stream);
 /* tf.image.non_max_suppression + tf.gather per image on d_boxes [B,N,D] (scores = column obj_idx).
  * d_sort_ws: >= byolo_nms_workspace_bytes(B, N). */
 BYOLO_API size_t  byolo_nms_workspace_bytes(int32_t B, int64_t N);
@@ -168,10 +176,16 @@ BYOLO_API int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B, 
  * enable with byolo_set_profiling(h, 1).  stage: 0 backbone, 1 heads, 2 decode, 3 sort+nms. */
 BYOLO_API int32_t byolo_set_profiling(byolo_t* h, int32_t on);   /* 0 off, 1 per stage, 2 + per conv launch */
 BYOLO_API int32_t byolo_stage_ms(byolo_t* h, float ms[4]);
+/* Keep the records of the last `depth` profiled forwards (default 1) and choose which one byolo_stage_ms /
+ * byolo_num_steps / byolo_step_profile / byolo_step_split read: age 0 = the last forward, 1 = the one before, ...
+ * A caller timing K back-to-back forwards sets depth = K and reads every record after the run -- no host
+ * synchronisation inside the timed region (bench.py). */
+BYOLO_API int32_t byolo_set_profile_depth(byolo_t* h, int32_t depth);
+BYOLO_API int32_t byolo_select_profile(byolo_t* h, int32_t age);
 /* per kernel launch of the convolution stack in the LAST forward (profiling level 2): graph layer, kernel
  * variant (BN of the implicit-GEMM tile: 128 / 64 / 32; -1 the direct small-Cin kernels; -2 / -3 the Winograd
  * input / output transforms; 129 the row-streaming Winograd-domain GEMM; 130 the same with output transform and
- * epilogue fused in), the EXECUTED extents {M, N, K} (for a Winograd-domain GEMM: 16 * tiles rows, cout, cin), the launch's device time and the ALGORITHMIC FLOPs it stands for (2*M*N*K of the layer as
+ * epilogue fused in; 131 / 132 a 1x1 convolution / detection head as a row-streaming launch, 128- / 64-wide tile), the EXECUTED extents {M, N, K} (for a Winograd-domain GEMM: 16 * tiles rows, cout, cin), the launch's device time and the ALGORITHMIC FLOPs it stands for (2*M*N*K of the layer as
  * written; differs from the executed work for the T-invariant de-duplicated launches -- conv once per image +
  * T masked epilogues; the per-image partial sum of a concat's tiled half carries 0 -- and for Winograd, where
  * the GEMM launch carries the direct-convolution FLOPs of its samples and the transforms carry 0).
@@ -180,7 +194,8 @@ BYOLO_API int32_t byolo_num_steps(const byolo_t* h);
 BYOLO_API int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms,
                                      double* algo_flops);
 /* the same launch's split-K plan: K slices per tile of its last partial round of tiles (1 = not split) and how many
- * tiles were cut (conv_igemm.hip; decided per (B, T) shape, deterministic) */
+ * tiles were cut; a NEGATIVE ksplit -G = a stream-K launch: G workgroups share all tiles * K-tiles units evenly
+ * (conv_igemm.hip; decided per (B, T) shape, deterministic) */
 BYOLO_API int32_t byolo_step_split(byolo_t* h, int32_t i, int32_t* ksplit, int32_t* split_tiles);
 /* analytic cost of one forward: conv FLOPs (2*MAC, graph as written) for B images x T samples */
 BYOLO_API int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops);

@@ -116,6 +116,31 @@ def test_prefix_compressed_multiblock_snappy_index(tmp_path):
         assert np.array_equal(got[k], t[k]), k
 
 
+def test_hand_assembled_bundle_fixture():
+    """tests/golden/tf_bundle/: a checkpoint assembled byte by byte from the published formats by
+    tests/golden/make_bundle_fixture.py -- its own varint / CRC-32C / masking / block builder, nothing imported from
+    byolo -- laid out the way TensorFlow's BundleWriter and table builder do it: restart interval 16, prefix-compressed
+    keys over several data blocks, shortest-separator index keys, proto3 zero-field omission (offset 0, scalar shape),
+    optimizer slots and global_step beside the model variables.  (Not written by TensorFlow -- none here; this pins
+    the reader against a second implementation of the format.)"""
+    import importlib.util
+    from conftest import GOLDEN
+    spec = importlib.util.spec_from_file_location("make_bundle_fixture", os.path.join(GOLDEN, "make_bundle_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    want = mk.tensors()
+    prefix = os.path.join(GOLDEN, "tf_bundle", "model-4242")
+    got = tc.read(prefix)
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+    assert got["beta1_power"].shape == () and int(got["global_step"]) == 4242
+    header, entries = tc.read_index(prefix)
+    assert len(entries) == len(want)
+    sub = tc.read(prefix, names={k for k in want if "Adam" not in k and k not in ("global_step", "beta1_power")})
+    assert len(sub) == 6 * 5 + 2                                     # what a restore into the model asks for
+
+
 def test_find_and_restore(tmp_path):
     from byolo import inference as inf
     from conftest import build_model, golden_params

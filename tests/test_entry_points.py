@@ -228,6 +228,125 @@ def test_vis_uncertainty_do_it(tmp_path):
     assert im.shape == (64, 96, 3) and im.dtype == np.uint8
 
 
+@pytest.mark.gpu
+def test_weight_import_routes_reach_the_device(tmp_path):
+    """Row (f2) of SURVEY.md section 8: the same trained variables through every import route of the reference --
+    `tf.train.Saver.restore` of a tensor-bundle checkpoint (inference_epistemic.py:27-38, :58; found by
+    find_checkpoint, read by byolo.tf_checkpoint), the `.npz` by TF variable name, and `load_darknet53_weights` of a
+    Darknet `.weights` file for the backbone (lib_yolo/darknet.py:42-122: [beta, gamma, mean, var] then the kernel as
+    [cout, cin, kh, kw]) -- end in bit-identical device results, which equal the golden fixture of the reference's graph."""
+    import torch
+    from byolo import tf_checkpoint as tc, inference as inf
+    from conftest import build_model, golden_images
+    variant = "yolov3_aleatoric"
+    params = golden_params(variant)
+    x = torch.from_numpy(golden_images(2)).cuda()
+
+    def run(m):
+        out = m.run(x, seed=42)
+        torch.cuda.synchronize()
+        return out["boxes"].clone()
+
+    _, m0 = build_model(variant, 64, 96, params=params)
+    base = run(m0)
+    gold = golden("fwd_%s.npz" % variant)["bbox"]
+    assert_close(base.cpu().numpy(), gold, "npz-by-name route vs golden")
+    # (1) tensor-bundle checkpoint with the extras a training run leaves (global_step, an optimizer slot)
+    ck = tmp_path / "ckpts" / "run"
+    ck.mkdir(parents=True)
+    extra = dict(params, global_step=np.array(77, np.int64))
+    extra["darknet53/conv/conv2d/kernel/Adam"] = np.zeros_like(params["darknet53/conv/conv2d/kernel"])
+    tc.write(str(ck / "model-77"), extra)
+    path = inf.find_checkpoint({"checkpoint_path": str(tmp_path / "ckpts"), "run_id": "run", "step": "last"})
+    assert path.endswith("model-77.index")
+    _, m1 = build_model(variant, 64, 96)
+    inf.restore(m1, path)
+    assert torch.equal(run(m1), base)
+    # (2) Darknet .weights for the 52 backbone convolutions, the heads by name
+    yolo2, m2 = build_model(variant, 64, 96)
+    m2.engine.set_params({k: v for k, v in params.items() if not k.startswith("darknet53/")}, strict=False)
+    blob = [np.array([0, 2, 0, 0, 0], dtype=np.int32).tobytes()]
+    scopes = []
+    for n in m2.engine.param_shapes():
+        s_ = n.rsplit("/", 2)[0]
+        if n.startswith("darknet53/") and s_ not in scopes:
+            scopes.append(s_)
+    for s_ in scopes:
+        for v in ("beta", "gamma", "moving_mean", "moving_variance"):
+            blob.append(params["%s/batch_normalization/%s" % (s_, v)].tobytes())
+        blob.append(np.ascontiguousarray(params[s_ + "/conv2d/kernel"].transpose(3, 2, 0, 1)).tobytes())
+    wf = tmp_path / "darknet53.conv.74"
+    wf.write_bytes(b"".join(blob))
+    assert len(yolo2.load_darknet53_weights(str(wf))) == 52 * 5
+    assert torch.equal(run(m2), base)
+
+
+@pytest.mark.gpu
+def test_det_dict_and_uncertainty_maps_vs_oracle():
+    """Row (f3) of SURVEY.md section 8: `DetLayer.det` holds every key of the reference's decode_epistemic dict
+    (lib_yolo/layers.py:397-411) with the reference's shapes, each within 1e-4 of the oracle's
+    `decode_epistemic_stats` on the same image / weights / dropout stream -- and the 11 kinds x 9 (stride, prior)
+    heat maps built from the DEVICE statistics equal the maps built from the ORACLE statistics through the same
+    colour mapping (which tests/golden/vis_maps.npz pins to the reference's colorize / color_map)."""
+    import torch
+    import vis_uncertainty as vis
+    from lib_yolo import yolov3, model as _model
+    from oracle import cpu_ref
+    from byolo import synth
+    variant, H, W, T, seed = "bayesian_yolov3_aleatoric", 64, 96, 4, 21
+    params = golden_params(variant)
+    cfg = make_config(variant, H, W, T=T, batch_size=1)
+    yolo = yolov3.bayesian_yolov3_aleatoric(cfg)
+    m = yolo.init_model(inputs=_model.Placeholder((1, H, W, 3)), training=False).get_model()
+    m.engine.set_params(params)
+    m.finalize()
+    img = synth.synthetic_images(1, H, W, seed=77)
+    m.run(torch.from_numpy(img).cuda(), seed=seed, want_nms=False)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        f = cpu_ref.forward(cpu_ref.to_torch_params(params), img, variant, T=T, seed=seed)
+    keys = {"ev_loc", "epi_covar_loc", "ale_var_loc", "obj_samples", "obj_mean", "obj_mutual_info", "obj_entropy",
+            "cls_samples", "cls_mean", "cls_mutual_info", "cls_entropy"}
+    ref_stats = []
+    for k, dl in enumerate(m.det_layers):
+        got = dl.det
+        assert set(got) == keys
+        raw = f["raw"][k]
+        ref = cpu_ref.decode_epistemic_stats(raw, 2)
+        d = raw.reshape(T, dl.h, dl.w, 3, 14)
+        ref["obj_samples"] = torch.sigmoid(d[..., 8])
+        ref["cls_samples"] = torch.softmax(d[..., 10:12], dim=-1)
+        ref_stats.append(ref)
+        for key in sorted(keys):
+            assert tuple(got[key].shape) == tuple(ref[key].shape), (key, got[key].shape, ref[key].shape)
+            assert_close(got[key].cpu().numpy(), ref[key].numpy(), "det layer %d %s" % (k, key))
+        # the exported covariance is symmetric and its diagonal IS the row's columns (same sums, same bits)
+        cov = got["epi_covar_loc"]
+        assert torch.equal(cov, cov.transpose(-1, -2))
+        rows = torch.stack([b[0] for b in dl.bbox], dim=2)
+        assert torch.equal(torch.diagonal(cov, dim1=-2, dim2=-1), rows[..., 4:8])
+    # maps: device statistics vs oracle statistics through the same (reference-pinned) colour mapping
+    inf = vis.Inference.__new__(vis.Inference)
+    inf.model = m
+    n = 0
+    for key, idx, name in vis.UCTY_KINDS:
+        got_maps = inf.uncertainty_grids(img, key, idx)
+        want_maps = []
+        for dl, ref in zip(m.det_layers, ref_stats):
+            u = ref[key]
+            u = u if ("obj" in key or "cls" in key) else (u[..., idx, idx] if "epi" in key else u[..., idx])
+            u = u.numpy()
+            want_maps += [vis.color_map(img, u[..., p:p + 1], dl.downsample, 0, None) for p in range(3)]
+        assert len(got_maps) == len(want_maps) == 9
+        for g_, w_ in zip(got_maps, want_maps):
+            assert g_.shape == w_.shape == (H, W, 3) and g_.dtype == np.uint8
+            diff = np.abs(g_.astype(int) - w_.astype(int))
+            # a statistic within 1e-4 of the oracle's moves a colour index by at most one step of the 256-entry map
+            assert diff.max() <= 8 and (diff > 0).mean() < 0.02, "%s: max colour diff %d, %.3f of the pixels differ" % (name, diff.max(), (diff > 0).mean())
+            n += 1
+    assert n == 11 * 9
+
+
 def test_corrupt_tfrecords_raise_cleanly(tmp_path):
     """Damaged TFRecord files: IOError from the framing, ValueError from the Example parser -- no other exception type,
     no giant read from a corrupt length (ad-hoc fuzz finding)."""

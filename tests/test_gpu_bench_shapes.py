@@ -79,6 +79,9 @@ def test_config4_as_benched():
     split = [s for s in launches if s["ksplit"] > 1]
     assert split, "no split-K launch in the benchmark's plan"
     print("config 4: %d fused launches, %d split-K launches (ksplit %s)" % (len(fused), len(split), sorted({s["ksplit"] for s in split})))
+    streamed = [s for s in launches if s["variant"] in (131, 132)]
+    print("config 4: %d row-streaming 1x1 / detection launches" % len(streamed))
+    assert len(streamed) >= 6, "the 38x38 / 76x76 head 1x1 convolutions and detection heads run as row-streaming launches"
     _compare(cfg, eng, imgs, out, (0, cfg["B"] - 1), 1000, "config 4 (608x608 T=30 B=8)")
 
 
@@ -93,6 +96,9 @@ def test_config2_as_benched():
     from oracle import cpu_ref
     cfg, eng, imgs, out, launches = _step(2)
     print("config 2 launch variants:", _variants(launches))
+    sk = [s for s in launches if s["ksplit"] < 0]
+    print("config 2: %d of %d launches stream-K" % (len(sk), len(launches)))
+    assert len(sk) >= 20, "the small-M 3x3 convolutions (13x13 / 26x26 grids at 8 images) must take the stream-K schedule"
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     params = eng.get_params()
     with torch.no_grad():

@@ -334,6 +334,66 @@ def test_split_k_slices(ksplit, monkeypatch):
     assert not torch.equal(a["boxes"], ref["boxes"])        # the slices really ran (summation order differs)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_row_streaming_1x1_convolutions(variant, monkeypatch):
+    """gemm_stream.hip as a convolution: the 1x1 / stride-1 convolutions over one plain source (head 1x1s with dropout,
+    the concat convolutions' stacked half with its per-image addend, backbone 1x1s) and the detection heads (bias, 21 /
+    42 channels on a 64-wide tile) run as ONE persistent row-streaming launch each.  BYOLO_STREAM1X1=2 takes it for every
+    shape the kernel can express (the planner wants a few row tiles per slot): row counts far below one row tile per
+    slot, M not a multiple of 128.  Same rows as the fixtures of the reference's graph, close to the conv_igemm path."""
+    torch = _torch()
+    B = 1 if variant.startswith("bayes") else 2
+    monkeypatch.setenv("BYOLO_STREAM1X1", "0")
+    _, base, _, _ = _run(variant, B, keep_all=False)
+    monkeypatch.setenv("BYOLO_STREAM1X1", "2")
+    m, st, _, _ = _run(variant, B)
+    g = golden("fwd_%s.npz" % variant)
+    for i in TAPS:
+        assert_close(_sub(i, m.engine.layer_output(i).cpu().numpy()), g["layer_%d" % i], "%s layer %d (streamed 1x1)" % (variant, i))
+    for k, dl in enumerate(m.det_layers):
+        assert_close(dl.raw_output.cpu().numpy(), g["raw_%d" % k], "%s raw det output %d (streamed)" % (variant, k))
+    gb = g["bbox"] if g["bbox"].ndim == 3 else g["bbox"][None]
+    assert_close(st["boxes"].cpu().numpy(), gb, "%s pre-NMS rows (streamed 1x1)" % variant)
+    assert_close(st["boxes"].cpu().numpy(), base["boxes"].cpu().numpy(), "%s streamed vs conv_igemm" % variant)
+    m.engine.set_profiling(2)
+    m.engine.forward(torch.from_numpy(golden_images(B)).cuda(), T=m.T, seed=42)
+    torch.cuda.synchronize()
+    v = [s["variant"] for s in m.engine.step_profile()]
+    # the 1x1 convolutions; the detection heads (21 channels pack to a 32-wide tile, which stays on conv_igemm)
+    assert v.count(131) >= 20 and v.count(132) >= (2 if variant == "yolov3" else 3), (v.count(131), v.count(132))
+
+
+@pytest.mark.parametrize("winograd", ["0", "1"])
+def test_stream_k_on_every_launch(winograd, monkeypatch):
+    """Stream-K (conv_igemm.hip): the resident workgroups share a launch's tiles * K-tiles units evenly; tiles that
+    straddle workgroups are reduced through slabs by the last arriver, in segment order.  BYOLO_STREAMK=2 forces it on
+    EVERY matrix-pipe convolution launch (the planner takes it for small launches only): one to three segments per tile,
+    workgroups that hold a tail of one tile, whole tiles and a head of another, the two-source loader, K ranges that
+    start inside a filter tap.  Same rows as the golden fixture, twice the same bits, within fp32 re-association of
+    the whole-tile schedule."""
+    torch = _torch()
+    v = "bayesian_yolov3_aleatoric"
+    monkeypatch.setenv("BYOLO_WINOGRAD", winograd)
+    monkeypatch.setenv("BYOLO_STREAMK", "0")
+    _, ref, _, _ = _run(v, 2, keep_all=False)
+    monkeypatch.setenv("BYOLO_STREAMK", "2")
+    m, a, _, _ = _run(v, 2, keep_all=False)
+    m.engine.set_profiling(2)
+    x = torch.from_numpy(golden_images(2)).cuda()
+    b = m.engine.forward(x, T=m.T, seed=42, want_boxes=True)
+    torch.cuda.synchronize()
+    sk = [s for s in m.engine.step_profile() if s["ksplit"] < 0]
+    assert len(sk) >= 15, "stream-K launches: %d" % len(sk)
+    assert torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["kept"], b["kept"])      # deterministic
+    g = golden("fwd_bayesian_b2_loop.npz")
+    assert_close(a["boxes"].cpu().numpy(), g["bbox"], "stream-K rows vs golden")
+    assert_close(a["boxes"].cpu().numpy(), ref["boxes"].cpu().numpy(), "stream-K vs whole tiles")
+    assert not torch.equal(a["boxes"], ref["boxes"])        # segments really ran (summation order differs)
+    monkeypatch.setenv("BYOLO_NO_DEDUP", "1")               # two-source loader under stream-K
+    _, nd, _, _ = _run(v, 2, keep_all=False)
+    assert_close(nd["boxes"].cpu().numpy(), g["bbox"], "stream-K, no dedup, rows vs golden")
+
+
 @pytest.mark.parametrize("ksplit", ["0", "3"])
 def test_without_dedup_two_source_loader(ksplit, monkeypatch):
     """BYOLO_NO_DEDUP=1 lowers the graph as written: the convs after the concats read TWO sources (the stacked
