@@ -32,16 +32,12 @@
 #include <type_traits>
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
+#include "mfma_pipe.h"
 
 namespace byk {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using namespace pipe;                         // tile geometry, LDS image, fragment scheme, MFMA group, K-tile schedule: mfma_pipe.h
 
-static constexpr int BK = 32;
-static constexpr int LDS_LD = 36;            // floats per staged row (32 + 4 pad)
-static constexpr int RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data format (gfx9 family)
 // Timing ablations of the K loop (build.py --ablate N -> libbyolo_ablN.so, loaded with BYOLO_LIB=...; the
 // results are WRONG by construction): 1 no global loads, 2 no LDS staging writes (the loads are still
 // waited for), 4 no barrier, 8 no fragment reads.
@@ -50,33 +46,11 @@ static constexpr int RSRC_FLAGS = 0x00020000;   // raw buffer, 32-bit data forma
 #endif
 static constexpr int ABL = BYOLO_CONV_ABLATE;
 
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shr; }
-
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // Blocks are dispatched round-robin over the 8 XCDs (bid % 8); give each XCD a contiguous
     // range of logical tiles so neighbouring tiles (same A rows / same weights) share its L2.
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-}
-
-// Scheduling pattern for one MFMA group: after every MFMA place ceil(aux / N_MFMA) auxiliary
-// instructions, in the order global loads -> LDS reads -> LDS writes (LLVM SchedGroupMask: MFMA 0x8,
-// VMEM_READ 0x20, DS_READ 0x100, DS_WRITE 0x200).
-template <int N_MFMA, int N_VMEM, int N_DSR, int N_DSW>
-__device__ __forceinline__ void sched_interleave() {
-    constexpr int AUX = N_VMEM + N_DSR + N_DSW;
-    constexpr int PER = (AUX + N_MFMA - 1) / N_MFMA;
-#pragma unroll
-    for (int k = 0; k < N_MFMA; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int q = k * PER + u;
-            if (q < N_VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            else if (q < N_VMEM + N_DSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            else if (q < AUX) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-    }
 }
 
 // One BM x BN output tile (logical tile index -> (tile_m, tile_n)).
@@ -97,23 +71,16 @@ struct TileShare { int counter, my_slab, nseg, base, stride, first_add; };
 template <int BM, int BN, int WM, int WN, bool FAST>
 __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical, const int kt_begin,
                                           const int kt_end, const TileShare sh) {
-    constexpr int NT = 64 * WM * WN;            // threads per block
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_LD = BM * 8 / NT;           // 16-byte loads per thread per A tile
-    constexpr int B_LD = BN * 8 / NT;           // 16-byte loads per thread per B tile
-    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile config");
-    // LDS map (bytes): A[2][BM][LDS_LD] then B[2][BN][LDS_LD]
-    constexpr int ROWB = LDS_LD * 4, A_BUF = BM * ROWB, B_BUF = BN * ROWB, B_BASE = 2 * A_BUF;
-    constexpr int JSTEP = (NT / 8) * ROWB;      // staging rows of one thread are NT/8 apart
-    char* lds = reinterpret_cast<char*>(smem);
-
-    const int tid = threadIdx.x;
+    using BT = BlockTile<BM, BN, WM, WN>;
+    constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD, B_LD = BT::B_LD;
+    const BT bt(smem);
+    const int tid = bt.tid;
     const uint32_t n_tiles = (uint32_t)p.Npad / BN;
     const uint32_t tile_m = fdiv((uint32_t)logical, p.d_ntiles), tile_n = (uint32_t)logical - tile_m * n_tiles;
 
     // ---- per-thread A-row bookkeeping (4 rows at BM = 128, 256 threads) -----------------------------
     // Each thread stages the same A_LD rows of every K-tile.  Row state = output pixel (sample, oy, ox).
-    const int a_q = tid & 7, a_r = tid >> 3;
+    const int a_q = bt.a_q, a_r = bt.a_r;
     const uint32_t hw = (uint32_t)(p.Hout * p.Wout);
     uint32_t a_voff[A_LD];                       // byte offset of the row for the current (tap, source)
     uint32_t a_off00[A_LD], a_mask[A_LD];        // FAST: tap (0,0) offset, validity bit per tap
@@ -198,19 +165,16 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     };
 
     f32x4 a_reg[A_LD], b_reg[B_LD];              // staging registers, one K-tile
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, p.w_bytes, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wpk, p.w_bytes);
     auto issue_loads = [&]() {                   // A_LD + B_LD buffer_load_dwordx4 of the tile set up by next_tile()
-        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_base), 0, a_bytes, RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_bytes);
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j)
-            a_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[j], a_soff, 0));
+        for (int j = 0; j < A_LD; ++j) a_reg[j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j)
-            b_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff, w_soff + j * (NT * 16), 0));
+        for (int j = 0; j < B_LD; ++j) b_reg[j] = buffer_load_x4(w_rsrc, b_voff, w_soff + j * (NT * 16));
         w_soff += w_step;
     };
-    const int st_off = (a_r * LDS_LD + a_q * 4) * 4;         // A and B staging: row tid/8 (+ NT/8 per j), 16-byte column tid%8
-    auto store_tile = [&](auto buf_tag) {
+    auto store_tile = [&](auto buf_tag) {        // the staged K-tile -> LDS buffer BUF
         constexpr int BUF = decltype(buf_tag)::value;
         if constexpr ((ABL & 2) != 0) {
 #pragma unroll
@@ -219,25 +183,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
             for (int j = 0; j < B_LD; ++j) asm volatile("" : : "v"(b_reg[j]));
             return;
         }
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (BUF * A_BUF + j * JSTEP)) = a_reg[j];
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (B_BASE + BUF * B_BUF + j * JSTEP)) = b_reg[j];
+        bt.template store_a<BUF>(a_reg);
+        bt.template store_b<BUF>(b_reg);
     };
 
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lh = lane >> 5;
-    const int fa_off = ((wm * TM * 32 + li) * LDS_LD + lh * 4) * 4;
-    const int fb_off = ((wn * TN * 32 + li) * LDS_LD + lh * 4) * 4;
-
-    auto read_frags = [&](auto buf_tag, auto kq_tag, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
-        constexpr int BUF = decltype(buf_tag)::value, KQ = decltype(kq_tag)::value;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(lds + fa_off + (BUF * A_BUF + KQ * 32 + i * 32 * ROWB));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(lds + fb_off + (B_BASE + BUF * B_BUF + KQ * 32 + j * 32 * ROWB));
-    };
+    const int wm = bt.wm, wn = bt.wn, li = bt.li, lh = bt.lh;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -247,33 +197,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);   // D^T: rows = channels
-    };
-
-    // ---- software-pipelined K loop ---------------------------------------------------------------
-    // An fp32 MFMA occupies the matrix pipe for 64 cycles; the wave issues in order, so any RUN of
-    // non-MFMA instructions longer than that lets the pipe drain.  The loop body is branch-free (tail
-    // tiles peeled) and every auxiliary instruction is placed BETWEEN two MFMAs with
-    // sched_group_barrier patterns.  Per K-tile t, 4 groups of G = 4*TM*TN MFMAs per wave:
-    //   group 0 | LDS fragment reads of group 1
-    //   group 1 | fragment reads of group 2
-    //   group 2 | fragment reads of group 3, then the LDS writes of tile t+1 (other buffer)
-    //   barrier   (every read of the current buffer is in registers, tile t+1 is visible afterwards)
-    //   group 3 | buffer loads of tile t+2 into the staging registers just freed (three MFMA groups before the
-    //           | LDS write that waits for them; issuing them in group 0 of tile t+1 measured -0.3 %),
-    //           | fragment reads of group 0 of tile t+1  -> barrier + LDS latency hide under group 3
-    constexpr int G = 4 * TM * TN, NFR = TM + TN, NLD = A_LD + B_LD;
+    // ---- software-pipelined K loop (schedule: mfma_pipe.h tile_body) ----------------------------------------------
+    // The loop body is branch-free (tail tiles peeled).  The buffer loads of tile t+2 go into the staging registers
+    // just freed, in the last MFMA group of tile t: three MFMA groups before the LDS write that waits for them
+    // (issuing them in group 0 of tile t+1 measured -0.3 %).
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
-    using c2 = std::integral_constant<int, 2>;
-    using c3 = std::integral_constant<int, 3>;
     f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
     const int KT = kt_end - kt_begin;            // K-tiles of this block
     next_tile();
@@ -281,39 +210,18 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     store_tile(c0{});
     if (KT > 1) { next_tile(); issue_loads(); }   // tile 1 waits in the staging registers
     __syncthreads();
-    read_frags(c0{}, c0{}, af0, bf0);
+    bt.template read_frags<0, 0>(af0, bf0);
 
+    auto mf = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int) { mfma_group<TM, TN>(acc, af, bf); };
+    auto none = [] {};
     // tile t lives in LDS buffer BUF = t & 1.  HN: tile t+1 exists (stage it);  LD: tile t+2 exists (fetch it)
     auto tile_body = [&](auto buf_tag, auto has_next_tag, auto load_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
-        using cur = std::integral_constant<int, BUF>;
-        using nxt = std::integral_constant<int, BUF ^ 1>;
         constexpr bool HN = decltype(has_next_tag)::value;
         constexpr bool LD3 = decltype(load_tag)::value && !(ABL & 1);
-        constexpr bool FR = !(ABL & 8), ST = HN && !(ABL & 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (FR) read_frags(cur{}, c1{}, af1, bf1);
-        mfma_group(af0, bf0);
-        sched_interleave<G, 0, FR ? NFR : 0, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-
-        if constexpr (FR) read_frags(cur{}, c2{}, af0, bf0);
-        mfma_group(af1, bf1);
-        sched_interleave<G, 0, FR ? NFR : 0, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-
-        if constexpr (FR) read_frags(cur{}, c3{}, af1, bf1);
-        if constexpr (HN) store_tile(nxt{});
-        mfma_group(af0, bf0);
-        sched_interleave<G, 0, FR ? NFR : 0, ST ? NLD : 0>();
-        __builtin_amdgcn_sched_barrier(0);
-
-        if constexpr (!(ABL & 4)) __syncthreads();
-        if constexpr (LD3) issue_loads();
-        if constexpr (HN && FR) read_frags(nxt{}, c0{}, af0, bf0);
-        mfma_group(af1, bf1);
-        sched_interleave<G, LD3 ? NLD : 0, (HN && FR) ? NFR : 0, 0>();
-        __builtin_amdgcn_sched_barrier(0);
+        constexpr int N_ST = (ABL & 2) ? 0 : BT::NLD;
+        pipe::tile_body<BUF, HN, 0, LD3 ? BT::NLD : 0, N_ST, ABL>(
+            bt, af0, bf0, af1, bf1, mf, none, issue_loads, [&] { store_tile(std::integral_constant<int, BUF ^ 1>{}); });
     };
     using yes = std::true_type;
     using no = std::false_type;
@@ -341,7 +249,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     if (sh.counter >= 0) {
         constexpr uint32_t SLAB_B = BM * BN * 4;     // bytes; lane-linear image: float4 q of thread t at (q * NT + t) * 16
         constexpr int SC1 = 16;
-        const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.slabs, 0, p.slab_bytes, RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t s_rsrc = make_rsrc(p.slabs, p.slab_bytes);
         const uint32_t my_off = (uint32_t)sh.my_slab * SLAB_B;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -383,8 +291,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            s_rsrc, tid * 16, off + ((i * TN + j) * 4 + g) * (NT * 16), SC1));
+                        const f32x4 v = buffer_load_x4<SC1>(s_rsrc, tid * 16, off + ((i * TN + j) * 4 + g) * (NT * 16));
 #pragma unroll
                         for (int q = 0; q < 4; ++q) acc[i][j][4 * g + q] += v[q];
                     }
@@ -611,7 +518,7 @@ int conv_pick_tile(int N) {
 
 template <int BM, int BN, int WM, int WN, bool FAST>
 static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds = BlockTile<BM, BN, WM, WN>::LDS_BYTES;
     auto k = conv_igemm_kernel<BM, BN, WM, WN, FAST>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), lds, attr_done); e != hipSuccess) return e;

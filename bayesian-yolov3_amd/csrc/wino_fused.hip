@@ -20,12 +20,11 @@
 #include <type_traits>
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
+#include "mfma_pipe.h"
 
 namespace byk {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using namespace pipe;                             // tile geometry, LDS image, fragment scheme, K-tile schedule: mfma_pipe.h
 
 namespace {
 
@@ -37,41 +36,21 @@ namespace {
 #endif
 constexpr int WFA = BYOLO_WF_ABLATE;
 
-constexpr int WF_LD = 36;
-constexpr int WF_RSRC = 0x00020000;
-
-__device__ __forceinline__ uint32_t fdivw(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shr; }
-
-template <int N_MFMA, int N_VMEM, int N_DSR, int N_DSW>
-__device__ __forceinline__ void wf_interleave() {
-    constexpr int AUX = N_VMEM + N_DSR + N_DSW;
-    constexpr int PER = (AUX + N_MFMA - 1) / N_MFMA;
-#pragma unroll
-    for (int k = 0; k < N_MFMA; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int q = k * PER + u;
-            if (q < N_VMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            else if (q < N_VMEM + N_DSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            else if (q < AUX) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-    }
-}
-
 }  // namespace
 
 __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParams p) {
-    constexpr int BM = 128, BN = 64, NT = 256, TM = 2, TN = 1, A_LD = 4, B_LD = 2;
-    constexpr int ROWB = WF_LD * 4, A_BUF = BM * ROWB, B_BUF = BN * ROWB, B_BASE = 2 * A_BUF, JSTEP = (NT / 8) * ROWB;
-    constexpr int SS_BASE = 2 * (A_BUF + B_BUF);  // scale[64], shift[64] of this workgroup's channels
+    using BT = BlockTile<128, 64, 2, 2>;          // 4 waves of 64 tiles x 32 channels
+    constexpr int BM = BT::BM, BN = BT::BN, NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD, B_LD = BT::B_LD;
+    static_assert(TM == 2 && TN == 1 && A_LD == 4 && B_LD == 2, "wave tile 64 x 32");
+    constexpr int SS_BASE = BT::LDS_BYTES;        // scale[64], shift[64] of this workgroup's channels, after the tile buffers
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* lds = reinterpret_cast<char*>(smem);
-    const int tid = threadIdx.x;
+    const BT bt(smem);
+    char* lds = bt.lds;
+    const int tid = bt.tid;
 
     // ---- which tiles, which channels (placement as in gemm_stream.hip) ------------------------------------------
     const uint32_t b = blockIdx.x, x = b & 7u, i8 = b >> 3;
-    const uint32_t sl = fdivw(i8, p.d_ntiles), tile_n = i8 - sl * (uint32_t)p.n_tiles;
+    const uint32_t sl = fdiv(i8, p.d_ntiles), tile_n = i8 - sl * (uint32_t)p.n_tiles;
     const uint32_t slot = x * ((uint32_t)p.slots >> 3) + sl;
     if (slot >= (uint32_t)p.slots) return;
     const uint32_t r0 = slot * (uint32_t)p.q + (slot < (uint32_t)p.rem ? slot : (uint32_t)p.rem);   // first row tile
@@ -85,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
         reinterpret_cast<float*>(lds + SS_BASE)[tid] = tid < BN ? p.scale[tile_n * BN + tid] : p.shift[tile_n * BN + tid - BN];
 
     // ---- load stream: K-tile (row tile, xi, chunk), chunk fastest -----------------------------------------------------
-    const int a_q = tid & 7, a_r = tid >> 3;
+    const int a_q = bt.a_q, a_r = bt.a_r;
     uint32_t a_voff[A_LD];
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) a_voff[j] = (((r0 * BM + a_r + (NT / 8) * j) * (uint32_t)p.C) + a_q * 4) * 4u;
@@ -95,8 +74,8 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     uint32_t a_xi_off = 0, w_base = 0, a_soff = 0, w_soff = 0;      // xi part of the V and U offsets (scalar)
     int ld_chunk = 0, ld_xi = 0;
     bool ld_first = true;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v), 0, p.v_bytes, WF_RSRC);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, WF_RSRC);
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.v, p.v_bytes);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, p.w_bytes);
     // staging registers: the V rows of the next K-tile; the weight tiles of the next TWO (the 16 weight matrices of a
     // layer are 2 .. 32 MB per XCD and round -- they come from the Infinity Cache, not from L2, every time)
     f32x4 a_reg[A_LD], b_reg0[B_LD], b_reg1[B_LD];
@@ -119,49 +98,18 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     };
     auto load_a = [&]() {
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j)
-            a_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[j], a_soff, 0));
+        for (int j = 0; j < A_LD; ++j) a_reg[j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
     };
     auto load_b = [&](f32x4 (&b_reg)[B_LD]) {
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j)
-            b_reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff, w_soff + j * (NT * 16), 0));
+        for (int j = 0; j < B_LD; ++j) b_reg[j] = buffer_load_x4(w_rsrc, b_voff, w_soff + j * (NT * 16));
     };
-    const int st_off = (a_r * WF_LD + a_q * 4) * 4;
-    auto store_tile = [&](auto buf_tag, const f32x4 (&b_reg)[B_LD]) {
-        constexpr int BUF = decltype(buf_tag)::value;
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (BUF * A_BUF + j * JSTEP)) = a_reg[j];
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<f32x4*>(lds + st_off + (B_BASE + BUF * B_BUF + j * JSTEP)) = b_reg[j];
-    };
+    const int wm = bt.wm, wn = bt.wn, li = bt.li, lh = bt.lh;
 
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const int fa_off = ((wm * TM * 32 + li) * WF_LD + lh * 4) * 4;
-    const int fb_off = ((wn * TN * 32 + li) * WF_LD + lh * 4) * 4;
-    auto read_frags = [&](auto buf_tag, auto kq_tag, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
-        constexpr int BUF = decltype(buf_tag)::value, KQ = decltype(kq_tag)::value;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(lds + fa_off + (BUF * A_BUF + KQ * 32 + i * 32 * ROWB));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(lds + fb_off + (B_BASE + BUF * B_BUF + KQ * 32 + j * 32 * ROWB));
-    };
-
-    f32x16 acc[TM];                               // M[xi] of this wave's 64 tiles x 32 channels (transposed: rows = channels)
+    f32x16 acc[TM][TN];                           // M[xi] of this wave's 64 tiles x 32 channels (transposed: rows = channels)
     f32x16 Y[4][TM];                              // the four outputs (dy, dx) of every tile
     // Neither accumulator set is ever cleared with vector-ALU moves: the first MFMA of a transform point takes a zero C
-    // operand (an inline constant), and the first fold into each output assigns instead of adding.
-    auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[0][s], af[i][s], (FIRST && s == 0) ? zero : acc[i], 0, 0, 0);
-    };
+    // operand (mfma_group<.., FIRST>), and the first fold into each output assigns instead of adding.
 
     // Y[dy][dx] += A^T[dy][i] * A^T[dx][j] * M[xi = 4 i + j];   A^T = [1 1 1 0; 0 1 -1 -1]
     auto fold = [&](const int xi) {
@@ -181,12 +129,12 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
 #pragma unroll
                         for (int t = 0; t < TM; ++t)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) Y[dy * 2 + dx][t][r] = c * acc[t][r];
+                            for (int r = 0; r < 16; ++r) Y[dy * 2 + dx][t][r] = c * acc[t][0][r];
                     } else {
 #pragma unroll
                         for (int t = 0; t < TM; ++t)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) Y[dy * 2 + dx][t][r] += c * acc[t][r];
+                            for (int r = 0; r < 16; ++r) Y[dy * 2 + dx][t][r] += c * acc[t][0][r];
                     }
                 }
             }
@@ -203,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
         for (int t = 0; t < TM; ++t) {
             const uint32_t tile = row_tile * BM + wm * TM * 32 + t * 32 + li;
             if (tile < (uint32_t)p.P) {
-                const uint32_t s = fdivw(tile, p.d_tt), r = tile - s * tt;
-                const uint32_t ty = fdivw(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
+                const uint32_t s = fdiv(tile, p.d_tt), r = tile - s * tt;
+                const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const uint32_t oy = 2 * ty + (o >> 1), ox = 2 * tx + (o & 1);
@@ -224,7 +172,6 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
                             *reinterpret_cast<f32x4*>(p.y + off + 8 * g) = raw;
                             continue;
                         }
-                        const int n0 = nb + 8 * g;
                         // scale (x 1 / (1 - p) with the masks on: host) and shift of channels n0 .. n0 + 3
                         const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + SS_BASE + (wn * 32 + 4 * lh + 8 * g) * 4);
                         const f32x4 sf = *reinterpret_cast<const f32x4*>(lds + SS_BASE + (BN + wn * 32 + 4 * lh + 8 * g) * 4);
@@ -252,52 +199,32 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
         }
     };
 
-    // ---- the pipeline ---------------------------------------------------------------------------------------------
-    constexpr int G = 4 * TM * TN, NFR = TM + TN, NLD = A_LD + B_LD;
+    // ---- the pipeline (mfma_pipe.h) ---------------------------------------------------------------------------------
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
-    using c2 = std::integral_constant<int, 2>;
-    using c3 = std::integral_constant<int, 3>;
     using yes = std::true_type;
     using no = std::false_type;
     f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
-    next_tile(); load_a(); load_b(b_reg0); store_tile(c0{}, b_reg0);
+    next_tile(); load_a(); load_b(b_reg0); bt.template store_a<0>(a_reg); bt.template store_b<0>(b_reg0);
     next_tile(); load_a(); load_b(b_reg1);        // total >= 16 * KT >= 32
     __syncthreads();
-    read_frags(c0{}, c0{}, af0, bf0);
+    bt.template read_frags<0, 0>(af0, bf0);
 
-    auto tile_body = [&](auto buf_tag, auto has_next_tag, auto load_tag, auto first_tag) {
+    // tile t+1's weights wait in set (t+1) & 1; tile t+2's are fetched into set t & 1 in group 0 already, its V rows in
+    // group 3 (into the staging registers the LDS write of group 2 has just freed)
+    auto tile_body = [&](auto buf_tag, auto first_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
-        using cur = std::integral_constant<int, BUF>;
-        using nxt = std::integral_constant<int, BUF ^ 1>;
-        constexpr bool HN = decltype(has_next_tag)::value, LD = decltype(load_tag)::value && !(WFA & 32);
-        // tile t+1's weights wait in set (t+1) & 1; tile t+2's are fetched into set t & 1 in group 0 already
+        constexpr bool FIRST = decltype(first_tag)::value, LD = !(WFA & 32);
         f32x4 (&b_far)[B_LD] = BUF == 0 ? b_reg0 : b_reg1;
         f32x4 (&b_near)[B_LD] = BUF == 0 ? b_reg1 : b_reg0;
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (LD) load_b(b_far);
-        read_frags(cur{}, c1{}, af1, bf1);
-        mfma_group(af0, bf0, first_tag);
-        wf_interleave<G, LD ? B_LD : 0, NFR, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-
-        read_frags(cur{}, c2{}, af0, bf0);
-        mfma_group(af1, bf1, no{});
-        wf_interleave<G, 0, NFR, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-
-        read_frags(cur{}, c3{}, af1, bf1);
-        if constexpr (HN) store_tile(nxt{}, b_near);
-        mfma_group(af0, bf0, no{});
-        wf_interleave<G, 0, NFR, HN ? NLD : 0>();
-        __builtin_amdgcn_sched_barrier(0);
-
-        __syncthreads();
-        if constexpr (LD) load_a();
-        if constexpr (HN) read_frags(nxt{}, c0{}, af0, bf0);
-        mfma_group(af1, bf1, no{});
-        wf_interleave<G, LD ? A_LD : 0, HN ? NFR : 0, 0>();
-        __builtin_amdgcn_sched_barrier(0);
+        pipe::tile_body<BUF, true, LD ? B_LD : 0, LD ? A_LD : 0, BT::NLD>(
+            bt, af0, bf0, af1, bf1,
+            [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int group) {
+                if (FIRST && group == 0) mfma_group<TM, TN, true>(acc, af, bf);      // first MFMAs of a unit start from zero
+                else mfma_group<TM, TN, false>(acc, af, bf);
+            },
+            [&] { load_b(b_far); }, load_a,
+            [&] { bt.template store_a<BUF ^ 1>(a_reg); bt.template store_b<BUF ^ 1>(b_near); });
     };
 
     // One unit = one transform point of one row tile = KT K-tiles (KT is even: tiles go in pairs over the two LDS
@@ -307,11 +234,11 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
     int xi = 0;
     uint32_t row_tile = r0;
     for (int u = 0; u < units; ++u) {
-        next_tile(); tile_body(c0{}, yes{}, yes{}, yes{});            // first MFMAs of the unit start from zero
-        next_tile(); tile_body(c1{}, yes{}, yes{}, no{});
+        next_tile(); tile_body(c0{}, yes{});                          // first MFMAs of the unit start from zero
+        next_tile(); tile_body(c1{}, no{});
         for (int pr = 1; pr < half; ++pr) {
-            next_tile(); tile_body(c0{}, yes{}, yes{}, no{});
-            next_tile(); tile_body(c1{}, yes{}, yes{}, no{});
+            next_tile(); tile_body(c0{}, no{});
+            next_tile(); tile_body(c1{}, no{});
         }
         fold(xi);
         if (++xi == 16) { xi = 0; epilogue(row_tile); ++row_tile; }
@@ -319,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
 }
 
 hipError_t launch_wino_fused(const WinoFusedParams& p, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (128 + 64) * WF_LD * sizeof(float) + 2 * 64 * sizeof(float);
+    constexpr size_t lds = BlockTile<128, 64, 2, 2>::LDS_BYTES + 2 * 64 * sizeof(float);
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(wino_fused_kernel), lds, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(wino_fused_kernel, dim3(512), dim3(256), lds, st, p);

@@ -181,3 +181,16 @@ def test_deduplicated_concat_convolution_with_residual():
     b = _ref_conv(s, p, "b", 1, 1, BN)
     c = _ref_conv(torch.cat([b, s], dim=3), p, "c", 3, 1, BN) + b
     assert_close(eng.layer_output(L["res"]).cpu().numpy(), c.numpy(), "concat convolution + residual")
+
+
+def test_slab_handoff_stress_on_three_streams():
+    """tools/stress_handoff.py: split-K slices, stream-K segments and the planner's own plan on three concurrent HIP
+    streams, 150 iterations here (1000 in the tool's default run, logged under profiles/): every result bit-identical to
+    the handle's first run -- the ordered reduce of the last arriver never sees a stale slab or a left-over ticket."""
+    import importlib.util
+    import os
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("stress_handoff", os.path.join(REPO, "tools", "stress_handoff.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(150, verbose=True)
