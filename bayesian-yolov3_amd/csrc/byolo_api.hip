@@ -98,7 +98,7 @@ struct Step {
     size_t wino_off = 0;           // the 16 transformed weight matrices U[xi], each packed [Cin/32][Npad][32]
 };
 // per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
-struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; bool overlap = false; };
+struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; };
 struct AuxTensor { int H, W, C; };
 
 struct Plan {
@@ -143,7 +143,7 @@ struct byolo {
     int profiling = 0;             // 0 off, 1 stage events, 2 + one event per conv launch
     // level 2: one entry per kernel launch of the convolution stack in a forward (a Winograd layer
     // contributes input transform / GEMM / output transform per chunk); event k is recorded before launch k
-    // ev_begin / ev_end: indices into the slot's event pool, both recorded on the stream the launch ran on
+    // ev_begin / ev_end: indices into the slot's event pool (the end of a launch is the begin of the next one)
     struct Launch { int layer, variant; int64_t m, n, k; double algo_flops; int ksplit, split_tiles; int ev_begin, ev_end; };
     // The records of the last `depth` profiled forwards (byolo_set_profile_depth; 1 by default): a caller that times a
     // run of back-to-back forwards reads all of them AFTER the run instead of synchronising with every step.
@@ -152,13 +152,9 @@ struct byolo {
         bool ev_valid = false;
         std::vector<Launch> launches;
         std::vector<hipEvent_t> step_ev;   // pool; n_ev in use
-        int n_ev = 0, last_main = -1;      // events used by this forward; the last launch on the caller's stream (its end = the next one's begin)
+        int n_ev = 0, last_main = -1;      // events used by this forward; the last launch marked (its end = the next one's begin)
         bool step_valid = false;
     };
-    // Second stream of a handle (created on first use): the Winograd input transform of chunk k+1 runs there while the
-    // fused GEMM of chunk k multiplies on the caller's stream; fork / join by events, nothing else ever runs on it.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     std::vector<ProfSlot> prof = std::vector<ProfSlot>(1);
     int prof_w = 0;                    // slot of the most recent profiled forward
     int prof_age = 0;                  // which forward the read calls refer to: 0 = the last, 1 = the one before, ...
@@ -205,7 +201,7 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
 
 extern "C" int32_t byolo_destroy(byolo_t* h) {
     if (!h) return BYOLO_OK;
-    bool on_device = h->d_blob || h->d_ones || h->side;
+    bool on_device = h->d_blob || h->d_ones;
     for (auto& ps : h->prof) on_device = on_device || ps.ev[0] || !ps.step_ev.empty();
     if (on_device) {                               // a handle that never ran (builder-only use, no GPU) touches no HIP call
         (void)hipSetDevice(h->device);
@@ -215,11 +211,6 @@ extern "C" int32_t byolo_destroy(byolo_t* h) {
         for (auto& ps : h->prof) {
             for (auto& e : ps.ev) if (e) (void)hipEventDestroy(e);
             for (auto& e : ps.step_ev) (void)hipEventDestroy(e);
-        }
-        if (h->side) {
-            (void)hipStreamSynchronize(h->side);
-            (void)hipStreamDestroy(h->side);
-            for (hipEvent_t e : {h->ev_fork, h->ev_ready[0], h->ev_ready[1], h->ev_free[0], h->ev_free[1]}) if (e) (void)hipEventDestroy(e);
         }
     }
     delete h;
@@ -824,11 +815,7 @@ static void make_plan(byolo_t* h, int B, int T) {
         const size_t P_pad = align_up((size_t)w.chunk * w.th * w.tw, 128);
         w.v_bytes = align_up((size_t)16 * P_pad * l.Cin * 4, 256);
         w.m_bytes = w.fused ? 0 : align_up((size_t)16 * P_pad * l.filters * 4, 256);
-        // fused + several chunks: the input transform of chunk k+1 overlaps the GEMM of chunk k (second stream, second
-        // V buffer; run_winograd).  BYOLO_WINO_OVERLAP=0 keeps the chunks strictly sequential (A/B).
-        static const bool overlap_on = [] { const char* e = getenv("BYOLO_WINO_OVERLAP"); return !e || atoi(e) != 0; }();
-        w.overlap = overlap_on && w.fused && w.chunk < S && (l.Cin % 2) == 0;
-        wino_scratch = std::max(wino_scratch, (w.overlap ? 2 : 1) * w.v_bytes + w.m_bytes);
+        wino_scratch = std::max(wino_scratch, w.v_bytes + w.m_bytes);
         const int rows = (int)(16 * P_pad);
         p.split[si] = conv_plan_split(rows, s.Npad, l.Cin / 32, s.tile);
         p.tile[si] = s.tile;
@@ -961,30 +948,14 @@ static int32_t next_event(byolo_t* h, hipStream_t st, int* idx) {
     return BYOLO_OK;
 }
 
-// A launch on the caller's stream: its begin event is also the end event of the launch before it on that stream.
-// side = true: a launch on the handle's second stream -- call end_side_launch right after it.
+// A launch on the caller's stream: its begin event is also the end event of the launch before it.
 static int32_t mark_launch(byolo_t* h, int layer, int variant, int64_t m, int64_t n, int64_t k, double algo, hipStream_t st,
-                           int ksplit = 1, int split_tiles = 0, bool side = false) {
+                           int ksplit = 1, int split_tiles = 0) {
     byolo::ProfSlot& ps = h->wslot();
     int e; int32_t rc = next_event(h, st, &e); if (rc) return rc;
-    if (!side) {
-        if (ps.last_main >= 0) ps.launches[ps.last_main].ev_end = e;
-        ps.last_main = (int)ps.launches.size();
-    }
+    if (ps.last_main >= 0) ps.launches[ps.last_main].ev_end = e;
+    ps.last_main = (int)ps.launches.size();
     ps.launches.push_back({layer, variant, m, n, k, algo, ksplit, split_tiles, e, -1});
-    return BYOLO_OK;
-}
-static int32_t end_side_launch(byolo_t* h, hipStream_t side) {
-    int e; int32_t rc = next_event(h, side, &e); if (rc) return rc;
-    h->wslot().launches.back().ev_end = e;
-    return BYOLO_OK;
-}
-
-static int32_t ensure_side_stream(byolo_t* h) {
-    if (h->side) return BYOLO_OK;
-    HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&h->ev_fork, &h->ev_ready[0], &h->ev_ready[1], &h->ev_free[0], &h->ev_free[1]})
-        HIPCHK(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
     return BYOLO_OK;
 }
 
@@ -996,21 +967,10 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
     const bool prof = h->profiling >= 2;
     int32_t rc;
     const int S = c.M / (l.H * l.W), tt = wp.th * wp.tw;
-    float* const V0 = reinterpret_cast<float*>(ws + h->plan.wino_off);
+    float* V = reinterpret_cast<float*>(ws + h->plan.wino_off);
     float* Mb = reinterpret_cast<float*>(ws + h->plan.wino_off + wp.v_bytes);
-    // Overlap (fused kernel, >= 2 chunks, BYOLO_WINO_OVERLAP != 0): two V buffers; the register-slim input transform of
-    // chunk k+1 runs on the handle's second stream while the GEMM of chunk k multiplies on the caller's.
-    const bool overlap = wp.overlap;
-    if (overlap) {
-        if ((rc = ensure_side_stream(h))) return rc;
-        HIPCHK(h, hipEventRecord(h->ev_fork, st));                 // the layer's input is complete, both V buffers are free
-        HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    }
-    int chunk_no = 0;
-    for (int s0 = 0; s0 < S; s0 += wp.chunk, ++chunk_no) {
+    for (int s0 = 0; s0 < S; s0 += wp.chunk) {
         const int ns = std::min(wp.chunk, S - s0);
-        const int vb = overlap ? (chunk_no & 1) : 0;
-        float* V = reinterpret_cast<float*>(reinterpret_cast<char*>(V0) + (size_t)vb * wp.v_bytes);
         WinoParams w; memset(&w, 0, sizeof w);
         w.x = c.src0; w.v = V; w.m = Mb; w.y = c.dst;
         w.residual = (c.flags & EPI_RESIDUAL) ? c.residual : nullptr;
@@ -1022,17 +982,8 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
         w.d_c4 = make_fastdiv((uint32_t)(c.C0 / 4)); w.d_n4 = make_fastdiv((uint32_t)(c.N / 4));
         // variants of the profile entries: -2 input transform, BN of the GEMM tile, -3 output transform; the GEMM
         // entry carries the direct-convolution FLOPs its samples stand for, its m/n/k are the executed extents
-        if (overlap) {
-            if (chunk_no >= 2) HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_free[vb], 0));    // the GEMM of chunk k-2 is done with this buffer
-            if (prof && (rc = mark_launch(h, s.layer, -4, w.P, c.C0, 0, 0.0, h->side, 1, 0, true))) return rc;
-            HIPCHK(h, launch_wino_input_slim(w, h->side));
-            if (prof && (rc = end_side_launch(h, h->side))) return rc;
-            HIPCHK(h, hipEventRecord(h->ev_ready[vb], h->side));
-            HIPCHK(h, hipStreamWaitEvent(st, h->ev_ready[vb], 0));
-        } else {
-            if (prof && (rc = mark_launch(h, s.layer, -2, w.P, c.C0, 0, 0.0, st))) return rc;
-            HIPCHK(h, launch_wino_input(w, st));
-        }
+        if (prof && (rc = mark_launch(h, s.layer, -2, w.P, c.C0, 0, 0.0, st))) return rc;
+        HIPCHK(h, launch_wino_input(w, st));
 
         const int rows = 16 * w.P_pad;
         if (wp.fused) {                                         // GEMM + output transform + epilogue in one kernel: no M
@@ -1049,7 +1000,6 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
             f.d_ntiles = make_fastdiv((uint32_t)f.n_tiles); f.d_tt = w.d_tt; f.d_tw = w.d_tw;
             if (prof && (rc = mark_launch(h, s.layer, 130, rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
             HIPCHK(h, launch_wino_fused(f, st));
-            if (overlap) HIPCHK(h, hipEventRecord(h->ev_free[vb], st));
             continue;
         }
         static const bool stream_on = [] { const char* e = getenv("BYOLO_GEMM_STREAM"); return !e || atoi(e) != 0; }();

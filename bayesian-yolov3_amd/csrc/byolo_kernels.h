@@ -138,7 +138,7 @@ hipError_t launch_wino_fused(const WinoFusedParams& p, hipStream_t st);
 bool gemm_stream_ok(int C, int N);
 hipError_t launch_gemm_stream(const GemmStreamParams& p, hipStream_t st);
 hipError_t launch_wino_input(const WinoParams& p, hipStream_t st);
-hipError_t launch_wino_input_slim(const WinoParams& p, hipStream_t st);   // <= 48 registers: co-resident with wino_fused_kernel
+hipError_t launch_side_delay(int microseconds, hipStream_t st);   // <= 48 registers: co-resident with wino_fused_kernel
 hipError_t launch_wino_output(const WinoParams& p, hipStream_t st);
 void wino_weight_transform(const float g[9], float u[16]);   // host: U = G g G^T
 

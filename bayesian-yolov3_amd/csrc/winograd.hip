@@ -63,49 +63,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     }
 }
 
-// The same transform with a register budget of 48: thread = (tile p, 2 channels), 16 x 8-byte loads and stores.  The fused
-// GEMM (wino_fused.hip) occupies a SIMD with two waves of 232 registers; 48 of the 512 are left, so waves of THIS
-// kernel can be co-resident with it: the transform of chunk k+1 runs on a second HIP stream while the GEMM of chunk k
-// multiplies (byolo_api.hip run_winograd) -- its loads and stores wait on HBM, its ~3 vector instructions per value
-// take issue slots from the matrix pipe, but the 4 ms of transform time per step leave the critical path.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48))) void wino_input_slim_kernel(const WinoParams p) {
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t c2n = (uint32_t)p.C >> 1;
-    const uint32_t t = wdiv(gid, p.d_c4), c2 = gid - t * c2n;          // d_c4 = C / 2 for this kernel (launcher)
-    if (t >= (uint32_t)p.P) return;
-    const uint32_t tt = (uint32_t)(p.th * p.tw);
-    const uint32_t s = wdiv(t, p.d_tt), r = t - s * tt;
-    const uint32_t ty = wdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
-    const float* img = p.x + ((size_t)(p.s0 + s) * p.H * p.W) * p.C + c2 * 2;
-    const int y0 = 2 * (int)ty - 1, x0 = 2 * (int)tx - 1;
-    float* v = p.v + (size_t)t * p.C + c2 * 2;
-    const size_t xi_stride = (size_t)p.P_pad * p.C;
-    // column by column: u[.][j] = B^T d[.][j]; the row transform needs all four columns of a row, so u stays (32 registers)
-    f32x2 u[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x2 d[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int y = y0 + i, x = x0 + j;
-            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            d[i] = ok ? *reinterpret_cast<const f32x2*>(img + ((size_t)y * p.W + x) * p.C) : f32x2{0.f, 0.f};
-        }
-        u[0][j] = d[0] - d[2];
-        u[1][j] = d[1] + d[2];
-        u[2][j] = d[2] - d[1];
-        u[3][j] = d[1] - d[3];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                    // (B^T d) B
-        *reinterpret_cast<f32x2*>(v + (size_t)(i * 4 + 0) * xi_stride) = u[i][0] - u[i][2];
-        *reinterpret_cast<f32x2*>(v + (size_t)(i * 4 + 1) * xi_stride) = u[i][1] + u[i][2];
-        *reinterpret_cast<f32x2*>(v + (size_t)(i * 4 + 2) * xi_stride) = u[i][2] - u[i][1];
-        *reinterpret_cast<f32x2*>(v + (size_t)(i * 4 + 3) * xi_stride) = u[i][1] - u[i][3];
-    }
-}
-
 // thread = (tile p, 4 output channels): 16 x 16-byte loads, up to 4 x 16-byte stores; epilogue as in conv_igemm.hip
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
@@ -168,13 +125,6 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
 hipError_t launch_wino_input(const WinoParams& p, hipStream_t st) {
     const uint64_t total = (uint64_t)p.P * (p.C >> 2);
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
-    return hipGetLastError();
-}
-hipError_t launch_wino_input_slim(const WinoParams& p, hipStream_t st) {
-    WinoParams q = p;
-    q.d_c4 = make_fastdiv((uint32_t)(p.C >> 1));
-    const uint64_t total = (uint64_t)p.P * (p.C >> 1);
-    hipLaunchKernelGGL(wino_input_slim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q);
     return hipGetLastError();
 }
 hipError_t launch_wino_output(const WinoParams& p, hipStream_t st) {

@@ -254,8 +254,7 @@ def main():
             # and its transforms are separate, HBM-bound launches.
             dom = max(mm, key=lambda v: acc[v][1])
             f, ms, n, fx, fu, ab = acc[dom]
-            # (-4: input transforms that ran on the second stream under the GEMM of the chunk before: not on the critical path)
-            tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for v, a in acc.items() if v != -4)
+            tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for a in acc.values())
             ach = fu / (ms * 1e-3)
             wino_ms = sum(acc[v][1] for v in (-2, -3) if v in acc)
             # HBM/fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
@@ -281,7 +280,6 @@ def main():
                                 # per-image figure is made of these): not a matrix-pipe utilisation where Winograd runs
                                 "achieved_algorithmic": f / (ms * 1e-3) / 1e12,
                                 "share_of_conv_time": ms / tot_ms, "winograd_transform_share_of_conv_time": wino_ms / tot_ms,
-                                "overlapped_transform_ms_per_step": (acc[-4][1] / args.steps) if -4 in acc else 0.0,
                                 # algorithmic (direct-convolution) FLOPs of the whole conv stack / its time, transforms
                                 # included: exceeds what the matrix pipe executes where Winograd F(2x2,3x3) is used
                                 "all_conv_algorithmic": tot_f / (tot_ms * 1e-3) / 1e12,

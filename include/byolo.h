@@ -184,8 +184,7 @@ BYOLO_API int32_t byolo_set_profile_depth(byolo_t* h, int32_t depth);
 BYOLO_API int32_t byolo_select_profile(byolo_t* h, int32_t age);
 /* per kernel launch of the convolution stack in the LAST forward (profiling level 2): graph layer, kernel
  * variant (BN of the implicit-GEMM tile: 128 / 64 / 32; -1 the direct small-Cin kernels; -2 / -3 the Winograd
- * input / output transforms; -4 an input transform that ran on the handle's second stream, overlapped with the GEMM of
- * the chunk before it (its time is NOT on the step's critical path); 129 the row-streaming Winograd-domain GEMM; 130 the same with output transform and
+ * input / output transforms; 129 the row-streaming Winograd-domain GEMM; 130 the same with output transform and
  * epilogue fused in; 131 / 132 a 1x1 convolution / detection head as a row-streaming launch, 128- / 64-wide tile), the EXECUTED extents {M, N, K} (for a Winograd-domain GEMM: 16 * tiles rows, cout, cin), the launch's device time and the ALGORITHMIC FLOPs it stands for (2*M*N*K of the layer as
  * written; differs from the executed work for the T-invariant de-duplicated launches -- conv once per image +
  * T masked epilogues; the per-image partial sum of a concat's tiled half carries 0 -- and for Winograd, where
