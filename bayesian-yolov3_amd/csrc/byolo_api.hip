@@ -771,11 +771,12 @@ static void make_plan(byolo_t* h, int B, int T) {
     { const char* e = getenv("BYOLO_WINOGRAD");
       const int on = e ? atoi(e) : 1;
       const char* mf = getenv("BYOLO_WINO_MIN_GFLOP");                     // tuning knob: smallest layer (direct GFLOP) to transform
-      // (measured at config 4: 100 -> 144.97, 20 -> 147.35, 5 -> 147.32 img/s)
+      // (measured at config 4: 100 -> 144.97, 20 -> 147.35, 5 -> 147.32 img/s; at config 2 (416x416, 8 images) the 52x52
+      //  layers are 12.8 GFLOP: 20 -> 1375, 10 -> 1506, 5 -> 1504 img/s.  Default 10.)
       const char* bm = getenv("BYOLO_WINO_CHUNK_MB");                      // tuning knob: V + M bytes of one chunk
       // (chunk budget measured at config 4: 2600 MB 177.6, 600 MB 179.4, 300 MB 150.6 img/s -- below ~500 MB the fused
       //  kernel's slots run out of row tiles; 800 MB keeps the scratch small without costing rounds)
-      const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 20.0) * 1e9, budget = (bm ? atof(bm) : 800.0) * 1e6;   // on == 2: every eligible layer (tests)
+      const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 10.0) * 1e9, budget = (bm ? atof(bm) : 800.0) * 1e6;   // on == 2: every eligible layer (tests)
       for (size_t si = 0; on && si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];

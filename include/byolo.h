@@ -182,13 +182,16 @@ BYOLO_API int32_t byolo_stage_ms(byolo_t* h, float ms[4]);
  * synchronisation inside the timed region (bench.py). */
 BYOLO_API int32_t byolo_set_profile_depth(byolo_t* h, int32_t depth);
 BYOLO_API int32_t byolo_select_profile(byolo_t* h, int32_t age);
-/* per kernel launch of the convolution stack in the LAST forward (profiling level 2): graph layer, kernel
- * variant (BN of the implicit-GEMM tile: 128 / 64 / 32; -1 the direct small-Cin kernels; -2 / -3 the Winograd
- * input / output transforms; 129 the row-streaming Winograd-domain GEMM; 130 the same with output transform and
- * epilogue fused in; 131 / 132 a 1x1 convolution / detection head as a row-streaming launch, 128- / 64-wide tile), the EXECUTED extents {M, N, K} (for a Winograd-domain GEMM: 16 * tiles rows, cout, cin), the launch's device time and the ALGORITHMIC FLOPs it stands for (2*M*N*K of the layer as
- * written; differs from the executed work for the T-invariant de-duplicated launches -- conv once per image +
- * T masked epilogues; the per-image partial sum of a concat's tiled half carries 0 -- and for Winograd, where
- * the GEMM launch carries the direct-convolution FLOPs of its samples and the transforms carry 0).
+/* per kernel launch of the convolution stack in the LAST forward (profiling level 2): graph layer, kernel variant --
+ *   128 / 64 / 32   conv_igemm_kernel, BN of the tile            -1   the direct small-Cin kernels
+ *   -2 / -3         Winograd input / output transform            129  the row-streaming Winograd-domain GEMM
+ *   130             the same with output transform + epilogue    131 / 132  a 1x1 convolution / detection head as a
+ *                   fused in (wino_fused_kernel)                            row-streaming launch, 128- / 64-wide tile
+ * -- the EXECUTED extents {M, N, K} (for a Winograd-domain GEMM: 16 * tiles rows, cout, cin), the launch's device time
+ * (hipEvents on `stream` around it) and the ALGORITHMIC FLOPs it stands for (2*M*N*K of the layer as written; differs
+ * from the executed work for the T-invariant de-duplicated launches -- conv once per image + T masked epilogues; the
+ * per-image partial sum of a concat's tiled half carries 0 -- and for Winograd, where the GEMM launch carries the
+ * direct-convolution FLOPs of its samples and the transforms carry 0).
  * byolo_num_steps = launches of the last profiled forward. */
 BYOLO_API int32_t byolo_num_steps(const byolo_t* h);
 BYOLO_API int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int32_t* variant, int64_t mnk[3], float* ms,

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--kernel", default="conv_igemm_kernel<128, 128")
     ap.add_argument("--launches", type=int, default=66, help="launches of the kernel in ONE bench step")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--tag", default=None, help="profile round the passes belong to (recorded in the output)")
     a = ap.parse_args()
     res = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -42,6 +43,16 @@ def main():
     out = {"kernel": a.kernel, "launches": n, "read_bytes_per_launch": read_b / n, "write_bytes_per_launch": write_b / n,
            "traffic_bytes_per_launch": (read_b + write_b) / n,
            "note": "FETCH_SIZE x2 (gfx950 wide-read correction), KiB units; last step of bench.py; includes Infinity-Cache hits"}
+    # when and on which source state the counters were collected: bench.py copies this next to `roofline.traffic`
+    import datetime
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+    except Exception:
+        commit = ""
+    out["measured_at"] = {"commit": commit, "date": datetime.date.today().isoformat(), "profile": a.tag,
+                          "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_round.sh"}
     print(json.dumps(out, indent=1))
     if a.out:
         json.dump(out, open(a.out, "w"), indent=1)
