@@ -98,7 +98,7 @@ def test_config2_as_benched():
     print("config 2 launch variants:", _variants(launches))
     sk = [s for s in launches if s["ksplit"] < 0]
     print("config 2: %d of %d launches stream-K" % (len(sk), len(launches)))
-    assert len(sk) >= 20, "the small-M 3x3 convolutions (13x13 / 26x26 grids at 8 images) must take the stream-K schedule"
+    assert len(sk) >= 10, "small-M convolutions (13x13 / 26x26 grids at 8 images: fewer tiles than CUs) must take the stream-K schedule"
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     params = eng.get_params()
     with torch.no_grad():
