@@ -558,10 +558,11 @@ ConvSplit conv_plan_split(int M, int Npad, int KT, int tile) {
         const int64_t U = (int64_t)tiles * KT;
         int G = (int)std::min<int64_t>(slots, U / (sk_knob >= 2 ? 1 : 6)) & ~7;       // >= 6 K-tiles per workgroup
         if (G >= 8 && U * G < ((int64_t)1 << 31) && U > G) {
+            // In units of `whole` (one tile's time on a CU of its own pipe): two workgroups share a CU's matrix pipe, so a
+            // round of `slots` tiles takes 2 wholes; a tile alone on its CU takes 1.16 (measured 0.58 of the shared time).
             const double rounds = (double)tiles / slots;
-            const double plain = tiles * 2 <= slots ? 0.95 : std::ceil(rounds);       // <= one workgroup per CU: a lone tile-time
-            // a workgroup's share in tile-times (two workgroups share a CU's matrix pipe unless G <= CUs) + the hand-off
-            const double sk = (double)tiles / G * (G * 2 <= slots ? 0.6 : 1.0) + t_slice / whole;
+            const double plain = tiles * 2 <= slots ? 1.16 : 2.0 * std::ceil(rounds);
+            const double sk = (double)tiles / G * (G * 2 <= slots ? 1.16 : 2.0) + t_slice / whole;
             if (sk_knob >= 2 || (rounds < 4.0 && sk < 0.93 * plain)) { r.sk_grid = G; return r; }
         }
     }
