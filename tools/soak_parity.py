@@ -41,7 +41,9 @@ def one_case(rng, idx, a):
     nms_mode = int(rng.integers(0, 2)) if cls_cnt == 2 else 0      # the 2-class mode is defined for C = 2
     env = {"BYOLO_WINOGRAD": str(rng.choice(["", "0", "2"])), "BYOLO_WINO_FUSED": str(rng.choice(["", "0", "2"])),
            "BYOLO_KSPLIT": str(rng.choice(["", "", "0", "2", "3", "5"])),
-           "BYOLO_WINO_CHUNK_MB": str(rng.choice(["", "", "1", "8", "64"]))}       # small budgets: many chunks per layer
+           "BYOLO_WINO_CHUNK_MB": str(rng.choice(["", "", "1", "8", "64"])),       # small budgets: many chunks per layer
+           "BYOLO_STREAMK": str(rng.choice(["", "", "0", "2"])),                   # stream-K never / on every launch
+           "BYOLO_STREAM1X1": str(rng.choice(["", "", "0", "2"]))}                 # row-streaming 1x1 kernel never / wherever expressible
     for k, v in env.items():
         if v:
             os.environ[k] = v
