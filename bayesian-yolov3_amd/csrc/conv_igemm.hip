@@ -33,6 +33,7 @@
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
 #include "mfma_pipe.h"
+#include "epilogue.h"
 
 namespace byk {
 
@@ -354,21 +355,17 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
             float* dst_row[TM];
             const float* res_row[TM];
             uint64_t idx_row[TM];
-            uint32_t gp_lo[TM], k1h_row[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const uint32_t mo = rep > 1 ? (row_img[i] * rep + t) * hw + row_pix[i] : row_m[i];
                 dst_row[i] = p.dst + (size_t)mo * p.ldc + nb;
                 res_row[i] = do_res ? p.residual + (size_t)mo * p.ldc + nb : nullptr;
                 idx_row[i] = p.idx_base + (uint64_t)mo * (uint64_t)p.N + (uint64_t)nb;
-                // VEC: pair index of the row's first element and the key word of its high half (and of high half + 1:
-                // a group further along the row may sit past a 2^32 pair boundary) -- once per row, not per group
-                gp_lo[i] = (uint32_t)(idx_row[i] >> 1);
-                k1h_row[i] = p.k1 + (uint32_t)(idx_row[i] >> 33) * 0x9E3779B9u;
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if (row_m[i] >= (uint32_t)p.M) continue;
+                const epi::DropRow drow(idx_row[i], p.k1);        // VEC: pair index / high-half key word, once per row
                 // VEC: the row's addend (joins before scale) or residual (joins after the activation) values are
                 // fetched up front, all TN*4 groups in flight at once -- a load + wait per group serialises the
                 // epilogue on memory latency (the staging / fragment registers of the K loop are dead here)
@@ -407,24 +404,13 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                         const uint64_t idx0 = idx_row[i] + (uint64_t)dn;
                         bool keep[4] = {true, true, true, true};
                         if (do_drop) {
-                            if constexpr (VEC) {
-                                const uint32_t g_lo = gp_lo[i] + (uint32_t)(dn >> 1);       // even: g_lo + 1 never carries
-                                const uint32_t k1h = g_lo < gp_lo[i] ? k1h_row[i] + 0x9E3779B9u : k1h_row[i];
-                                const uint32_t h0 = byolo_pair_hash(g_lo, p.k0, k1h);
-                                const uint32_t h1 = byolo_pair_hash(g_lo + 1u, p.k0, k1h);
-                                keep[0] = (h0 & 0xFFFFu) < p.thr; keep[1] = (h0 >> 16) < p.thr;
-                                keep[2] = (h1 & 0xFFFFu) < p.thr; keep[3] = (h1 >> 16) < p.thr;
-                            } else {
+                            if constexpr (VEC) epi::keep4(drow, dn, p.k0, p.thr, keep);
+                            else {
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) keep[q] = byolo_keep(idx0 + q, p.k0, p.k1, p.thr);
                             }
                         }
-                        f32x4 v;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float x = __builtin_fmaf(a4[q], keep[q] ? sc4[q] : 0.f, sf4[q]);   // mask * scale, + shift
-                            v[q] = fmaxf(x, slope * x);                   // slope = 0.1 (leaky) or 1 (linear)
-                        }
+                        f32x4 v = epi::bn_act4(a4, sc4, sf4, keep, slope);    // slope = 0.1 (leaky) or 1 (linear)
                         float* d = dst_row[i] + dn;
                         if constexpr (VEC) {
                             // (a launch with BOTH an addend and a residual -- a de-duplicated concat convolution

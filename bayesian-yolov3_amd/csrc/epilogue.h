@@ -1,0 +1,52 @@
+// epilogue.h -- the ONE definition of the convolution epilogue's arithmetic on a group of 4 consecutive output
+// channels of one pixel (lib_yolo/layers.py:560-574: conv -> dropout -> BN -> leaky, dropout BETWEEN conv and BN):
+//
+//     v = leaky( keep * (acc * scale) + shift )          scale = gamma * rsqrt(var + eps)  [/ (1 - p) with the masks on]
+//                                                         shift = beta - mean * gamma * rsqrt(var + eps)   (not masked)
+//
+// used by every kernel that finishes a convolution: conv_igemm.hip, gemm_stream.hip (1x1 convolutions), wino_fused.hip
+// and winograd.hip (output transform).  Epilogue instructions are paid in matrix-pipe time (mfma_pipe.h), so the forms
+// here are the cheapest measured: mask and scale as ONE select feeding ONE fused multiply-add; leaky as max(x, slope*x)
+// with slope = 1 for linear layers; the dropout mask of the group from two pair hashes (byolo_rng.h) whose key word
+// of the index's high half is prepared once per pixel by the caller.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "byolo_rng.h"
+
+namespace byk {
+namespace epi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Dropout position of one pixel's channel run: pair index of its first element and the key word of the index's high
+// half.  `idx` = NHWC element index of the run's first channel in the dropout input [S, h, w, cout] (a multiple of 4).
+struct DropRow {
+    uint32_t gp_lo, k1h;
+    __device__ __forceinline__ DropRow(uint64_t idx, uint32_t k1) : gp_lo((uint32_t)(idx >> 1)), k1h(k1 + (uint32_t)(idx >> 33) * 0x9E3779B9u) {}
+};
+
+// keep bits of the 4-channel group `dn` channels further along the row (dn % 4 == 0): two pair hashes, 16 bits each.
+// A group further along the row may sit past a 2^32 pair boundary: the high-half key word then moves on by one step.
+__device__ __forceinline__ void keep4(const DropRow& r, int dn, uint32_t k0, uint32_t thr, bool (&keep)[4]) {
+    const uint32_t g_lo = r.gp_lo + (uint32_t)(dn >> 1);             // even: g_lo + 1 never carries
+    const uint32_t k1h = g_lo < r.gp_lo ? r.k1h + 0x9E3779B9u : r.k1h;
+    const uint32_t h0 = byolo_pair_hash(g_lo, k0, k1h);
+    const uint32_t h1 = byolo_pair_hash(g_lo + 1u, k0, k1h);
+    keep[0] = (h0 & 0xFFFFu) < thr; keep[1] = (h0 >> 16) < thr;
+    keep[2] = (h1 & 0xFFFFu) < thr; keep[3] = (h1 >> 16) < thr;
+}
+
+// leaky(keep * (a * scale) + shift), slope = 0.1 (leaky) or 1 (linear)
+__device__ __forceinline__ f32x4 bn_act4(const f32x4 a, const f32x4 sc, const f32x4 sf, const bool (&keep)[4], float slope) {
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x = __builtin_fmaf(a[q], keep[q] ? sc[q] : 0.f, sf[q]);      // mask * scale, + shift
+        v[q] = fmaxf(x, slope * x);
+    }
+    return v;
+}
+
+}  // namespace epi
+}  // namespace byk

@@ -28,6 +28,7 @@
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
 #include "mfma_pipe.h"
+#include "epilogue.h"
 
 namespace byk {
 
@@ -137,15 +138,13 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmStreamPar
                             }
                 } else {
                     // N % 4 == 0: a lane's 4-channel group is entirely inside or outside N, its element index is a
-                    // multiple of 4 -> one 16-byte store, two pair hashes (byolo_rng.h) -- as conv_igemm.hip's epilogue
+                    // multiple of 4 -> one 16-byte store, two pair hashes: the shared epilogue of epilogue.h
                     const float* add_row = nullptr;
                     if (p.addend) {               // raw partial sums of the concat's T-invariant half, one row per IMAGE pixel
                         const uint32_t img = fdiv(m, p.d_hw), pix = m - img * hw;
                         add_row = p.addend + (size_t)(fdiv(img, p.d_addT) * hw + pix) * p.N + nb;
                     }
-                    const uint64_t idx_row = p.idx_base + (uint64_t)m * (uint64_t)p.N + (uint64_t)nb;
-                    const uint32_t gp_lo = (uint32_t)(idx_row >> 1);
-                    const uint32_t k1h_row = p.k1 + (uint32_t)(idx_row >> 33) * 0x9E3779B9u;
+                    const epi::DropRow drow(p.idx_base + (uint64_t)m * (uint64_t)p.N + (uint64_t)nb, p.k1);
                     f32x4 extra[TN * 4];
                     if (add_row) {
 #pragma unroll
@@ -167,21 +166,8 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const GemmStreamPar
                             for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
                             if (add_row) a4 += extra[j * 4 + g];
                             bool keep[4] = {true, true, true, true};
-                            if (do_drop) {
-                                const uint32_t g_lo = gp_lo + (uint32_t)(dn >> 1);          // even: g_lo + 1 never carries
-                                const uint32_t k1h = g_lo < gp_lo ? k1h_row + 0x9E3779B9u : k1h_row;
-                                const uint32_t h0 = byolo_pair_hash(g_lo, p.k0, k1h);
-                                const uint32_t h1 = byolo_pair_hash(g_lo + 1u, p.k0, k1h);
-                                keep[0] = (h0 & 0xFFFFu) < p.thr; keep[1] = (h0 >> 16) < p.thr;
-                                keep[2] = (h1 & 0xFFFFu) < p.thr; keep[3] = (h1 >> 16) < p.thr;
-                            }
-                            f32x4 v;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float xv = __builtin_fmaf(a4[q], keep[q] ? sc4[q] : 0.f, sf4[q]);   // mask * scale, + shift
-                                v[q] = fmaxf(xv, slope * xv);                                              // slope = 0.1 (leaky) or 1
-                            }
-                            *reinterpret_cast<f32x4*>(d + dn) = v;
+                            if (do_drop) epi::keep4(drow, dn, p.k0, p.thr, keep);
+                            *reinterpret_cast<f32x4*>(d + dn) = epi::bn_act4(a4, sc4, sf4, keep, slope);
                         }
                 }
             }

@@ -21,6 +21,7 @@
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
 #include "mfma_pipe.h"
+#include "epilogue.h"
 
 namespace byk {
 
@@ -160,9 +161,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
                     const uint64_t pix = ((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox;
                     const size_t off = (size_t)pix * p.N + nb;
                     // pair index of the pixel's first element here and the key word of its high half: once per pixel
-                    const uint64_t idx_px = p.idx_base + pix * (uint64_t)p.N + (uint64_t)nb;
-                    const uint32_t gp_lo = (uint32_t)(idx_px >> 1);
-                    const uint32_t k1h_px = p.k1 + (uint32_t)(idx_px >> 33) * 0x9E3779B9u;
+                    const epi::DropRow drow(p.idx_base + pix * (uint64_t)p.N + (uint64_t)nb, p.k1);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if constexpr ((WFA & 2) != 0) {
@@ -176,20 +175,11 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFusedParam
                         const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + SS_BASE + (wn * 32 + 4 * lh + 8 * g) * 4);
                         const f32x4 sf = *reinterpret_cast<const f32x4*>(lds + SS_BASE + (BN + wn * 32 + 4 * lh + 8 * g) * 4);
                         bool keep[4] = {true, true, true, true};
-                        if (do_drop) {
-                            const uint32_t g_lo = gp_lo + 4u * g;                  // even: g_lo + 1 never carries
-                            const uint32_t k1h = g_lo < gp_lo ? k1h_px + 0x9E3779B9u : k1h_px;
-                            const uint32_t h0 = byolo_pair_hash(g_lo, p.k0, k1h);
-                            const uint32_t h1 = byolo_pair_hash(g_lo + 1u, p.k0, k1h);
-                            keep[0] = (h0 & 0xFFFFu) < p.thr; keep[1] = (h0 >> 16) < p.thr;
-                            keep[2] = (h1 & 0xFFFFu) < p.thr; keep[3] = (h1 >> 16) < p.thr;
-                        }
-                        f32x4 v;
+                        if (do_drop) epi::keep4(drow, 8 * g, p.k0, p.thr, keep);
+                        f32x4 y4;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float xv = __builtin_fmaf(Y[o][t][4 * g + q], keep[q] ? sc[q] : 0.f, sf[q]);
-                            v[q] = fmaxf(xv, slope * xv);
-                        }
+                        for (int q = 0; q < 4; ++q) y4[q] = Y[o][t][4 * g + q];
+                        f32x4 v = epi::bn_act4(y4, sc, sf, keep, slope);
                         if (do_res) v += *reinterpret_cast<const f32x4*>(p.residual + off + 8 * g);
                         if constexpr ((WFA & 64) != 0) { if (p.P >= 0) continue; }
                         *reinterpret_cast<f32x4*>(p.y + off + 8 * g) = v;

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
+#include "epilogue.h"
 
 namespace byk {
 
@@ -100,22 +101,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
             const uint64_t pix = ((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox;
             const uint64_t idx0 = p.idx_base + pix * (uint64_t)p.N + (uint64_t)n0;
             bool keep[4] = {true, true, true, true};
-            if (do_drop) {
-                const uint64_t gp = idx0 >> 1;           // N % 4 == 0: idx0 is a multiple of 4, gp + 1 never carries
-                const uint32_t k1h = p.k1 + (uint32_t)(gp >> 32) * 0x9E3779B9u;
-                const uint32_t h0 = byolo_pair_hash((uint32_t)gp, p.k0, k1h);
-                const uint32_t h1 = byolo_pair_hash((uint32_t)gp + 1u, p.k0, k1h);
-                keep[0] = (h0 & 0xFFFFu) < p.thr; keep[1] = (h0 >> 16) < p.thr;
-                keep[2] = (h1 & 0xFFFFu) < p.thr; keep[3] = (h1 >> 16) < p.thr;
-            }
-            f32x4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float x = yv[q] * sc[q];
-                x = keep[q] ? x : 0.f;
-                x += sf[q];
-                o[q] = fmaxf(x, slope * x);
-            }
+            if (do_drop) epi::keep4(epi::DropRow(idx0, p.k1), 0, p.k0, p.thr, keep);     // N % 4 == 0: idx0 is a multiple of 4
+            f32x4 o = epi::bn_act4(yv, sc, sf, keep, slope);
             const size_t off = (size_t)pix * p.N + n0;
             if (p.residual) o += *reinterpret_cast<const f32x4*>(p.residual + off);
             *reinterpret_cast<f32x4*>(p.y + off) = o;
