@@ -172,5 +172,46 @@ def main(block_size=700):
     print("wrote", prefix, "index", os.path.getsize(prefix + ".index"), "B,", index.n, "data blocks; data", offset, "B")
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# A TFRecord file of tf.train.Example protos, likewise assembled from the published formats (tensorflow/core/lib/io/
+# record_writer.cc: u64 length, masked CRC-32C of the length, payload, masked CRC-32C of the payload;
+# tensorflow/core/example/{example,feature}.proto) with the feature keys the reference's dataset writer uses
+# (create_tf_records_citypersons.py:132-147) -- the input-feed side of SURVEY.md section 8(f1).  The PNGs are encoded by
+# Pillow; the expected pixels are records() below.
+def records(n=3, H=32, W=32):
+    g = np.random.default_rng(99)
+    return [("frame_%02d.png" % i, g.integers(0, 256, (H, W, 3), dtype=np.uint8)) for i in range(n)]
+
+
+def example_proto(name, img_u8):
+    import io
+    from PIL import Image
+    png = io.BytesIO()
+    Image.fromarray(img_u8).save(png, format="PNG")
+
+    def feature_bytes(b):
+        return pb_bytes_field(1, pb_bytes_field(1, b))                    # Feature{bytes_list{value}}
+
+    def feature_int(v):
+        return pb_bytes_field(3, pb_bytes_field(1, varint(v)))            # Feature{int64_list{value (packed)}}
+
+    feats = {"image/encoded": feature_bytes(png.getvalue()), "image/filename": feature_bytes(name.encode()),
+             "image/format": feature_bytes(b"png"), "image/height": feature_int(img_u8.shape[0]),
+             "image/width": feature_int(img_u8.shape[1])}
+    entries = b"".join(pb_bytes_field(1, pb_bytes_field(1, k.encode()) + pb_bytes_field(2, v)) for k, v in sorted(feats.items()))
+    return pb_bytes_field(1, entries)                                     # Example{features{feature map}}
+
+
+def write_tfrecord():
+    path = os.path.join(OUT, "ecp-day-val-00000-of-00001")
+    with open(path, "wb") as f:
+        for name, img in records():
+            payload = example_proto(name, img)
+            head = struct.pack("<Q", len(payload))
+            f.write(head + struct.pack("<I", masked(crc32c(head))) + payload + struct.pack("<I", masked(crc32c(payload))))
+    print("wrote", path, os.path.getsize(path), "B")
+
+
 if __name__ == "__main__":
     main()
+    write_tfrecord()

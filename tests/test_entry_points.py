@@ -103,6 +103,26 @@ def test_tfrecord_feed(tmp_path):
     assert ex == {"a": [b"xyz"], "n": [-3], "s": [b"str"]}
 
 
+def test_tfrecord_fixture_from_the_published_format():
+    """tests/golden/tf_bundle/ecp-day-val-00000-of-00001: a TFRecord file of tf.train.Example protos assembled byte by
+    byte by tests/golden/make_bundle_fixture.py (its own varint / CRC-32C / masking / proto encoder; the feature keys of the
+    reference's dataset writer, create_tf_records_citypersons.py:132-147; PNGs by Pillow) -- read through TestingDataset,
+    CRC verification on."""
+    import importlib.util
+    from conftest import GOLDEN
+    from lib_yolo import dataset_utils as du
+    spec = importlib.util.spec_from_file_location("make_bundle_fixture", os.path.join(GOLDEN, "make_bundle_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    cfg = {"batch_size": 2, "full_img_size": [32, 32, 3], "data": {"file_pattern": os.path.join(GOLDEN, "tf_bundle", "ecp-day-val-*")}}
+    batches = list(du.TestingDataset(cfg))
+    assert [len(n) for _, n in batches] == [2, 1]
+    want = mk.records()
+    assert [n for _, ns in batches for n in ns] == [n for n, _ in want]
+    for a, (_, u8) in zip(np.concatenate([x for x, _ in batches]), want):
+        assert np.array_equal(a, u8.astype(np.float32) * np.float32(1.0 / 255.0))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_inference_driver_end_to_end(variant, tmp_path):
