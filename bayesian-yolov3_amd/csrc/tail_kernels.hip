@@ -730,7 +730,9 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(int max_out, int pass, co
                                                        const int* n_cand_all, const int* more_all,
                                                        const unsigned long long* mask_all, int* kidx_all, int* cnt_all,
                                                        int* need) {
-    __shared__ unsigned long long rows[64][NMS_WORDS];       // 32 KiB: the 64 matrix rows of this step
+    // The 64 matrix rows of a step, double-buffered (2 x 32 KiB, dynamic LDS): waves 1..3 fetch the rows of step c+1
+    // while wave 0 resolves step c -- the fetch latency (L2) leaves the serial chain.
+    extern __shared__ __attribute__((aligned(16))) unsigned long long rows_all[];   // [2][64][NMS_WORDS]
     __shared__ int s_nk, s_done;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_cand = n_cand_all[b];
@@ -741,16 +743,22 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(int max_out, int pass, co
     const int base = pass ? cnt_all[2 * b] : 0;
     int* kidx = kidx_all + (size_t)b * 2 * NMS_MAXK + base;
     if (tid == 0) { s_nk = 0; s_done = 0; }
-    unsigned long long rem = 0ull;                           // wave 0, lane w: word w of the removed set
-    __syncthreads();
-    for (int c = 0; c < nwords; ++c) {
-        for (int t = tid; t < 64 * NMS_WORDS; t += 256) {
+    auto fetch = [&](int c, int first, int nthreads) {       // rows of step c -> buffer c & 1, by `nthreads` threads from `first`
+        unsigned long long (*rows)[NMS_WORDS] = reinterpret_cast<unsigned long long (*)[NMS_WORDS]>(rows_all + (size_t)(c & 1) * 64 * NMS_WORDS);
+        for (int t = tid - first; t < 64 * NMS_WORDS; t += nthreads) {
             const int r = t / NMS_WORDS, w = t - r * NMS_WORDS;
             const int gi = c * 64 + r;
             rows[r][w] = (w >= c && w < nwords && gi < Kc) ? mask[(size_t)gi * NMS_WORDS + w] : 0ull;
         }
-        __syncthreads();
-        if (wave == 0) {
+    };
+    unsigned long long rem = 0ull;                           // wave 0, lane w: word w of the removed set
+    if (nwords > 0) fetch(0, 0, 256);
+    __syncthreads();
+    for (int c = 0; c < nwords; ++c) {
+        if (wave != 0) {
+            if (c + 1 < nwords) fetch(c + 1, 64, 192);
+        } else {
+            const unsigned long long (*rows)[NMS_WORDS] = reinterpret_cast<const unsigned long long (*)[NMS_WORDS]>(rows_all + (size_t)(c & 1) * 64 * NMS_WORDS);
             // The only serial dependency is the removed-word of THIS step (`cur`); everything on its
             // chain stays in registers: lane i holds word c of row i (suppression inside the step) and
             // candidate i's box index.  Folding the kept rows into the other 63 words of the removed set
@@ -766,16 +774,26 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(int max_out, int pass, co
             unsigned long long keptmask = 0ull;
             int nk = nk0;
             const int lim = Kc - c * 64 < 64 ? Kc - c * 64 : 64;
-            for (int i = 0; i < lim && nk < max_out; ++i) {
-                if (!((cur >> i) & 1ull)) {
-                    keptmask |= 1ull << i;
-                    ++nk;
-                    cur |= ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)own_hi, i) << 32) |
-                           (unsigned int)__builtin_amdgcn_readlane((int)own_lo, i);
-                }
+            if (lim < 64) cur |= ~0ull << lim;               // positions past the last candidate are never kept
+            // visit only the survivors: the next candidate that is not suppressed = the lowest clear bit of `cur`
+            // at or above the last kept one (a suppressed run costs nothing)
+            unsigned long long done = 0ull;                  // bits below the scan position
+            while (nk < max_out) {
+                const unsigned long long open = ~(cur | done);
+                if (!open) break;
+                const int i = __builtin_ctzll(open);
+                keptmask |= 1ull << i;
+                ++nk;
+                cur |= ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)own_hi, i) << 32) |
+                       (unsigned int)__builtin_amdgcn_readlane((int)own_lo, i);
+                done = (i == 63) ? ~0ull : ((2ull << i) - 1ull);
             }
             if ((keptmask >> lane) & 1ull) kidx[nk0 + __popcll(keptmask & ((1ull << lane) - 1ull))] = my_idx;
-            for (unsigned long long m = keptmask; m; m &= m - 1) rem |= rows[__builtin_ctzll(m)][lane];
+            // fold the kept rows into the removed set: 64 independent LDS reads per lane, selected by the kept bit
+            unsigned long long acc = 0ull;
+#pragma unroll 16
+            for (int i = 0; i < 64; ++i) acc |= ((keptmask >> i) & 1ull) ? rows[i][lane] : 0ull;
+            rem |= acc;
             if (lane == 0) { s_nk = nk; s_done = nk >= max_out ? 1 : 0; }
         }
         __syncthreads();
@@ -820,13 +838,16 @@ hipError_t launch_sort_nms(const NmsParams& p, hipStream_t st) {
         static std::atomic<uint64_t> attr_done{0};
         const size_t lds = (size_t)NMS_CAP * sizeof(unsigned long long);
         if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(topk_select_kernel), lds, attr_done); e != hipSuccess) return e;
+        static std::atomic<uint64_t> scan_attr_done{0};
+        const size_t scan_lds = (size_t)2 * 64 * NMS_WORDS * sizeof(unsigned long long);      // 64 KiB
+        if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(nms_scan_kernel), scan_lds, scan_attr_done); e != hipSuccess) return e;
         const int npass = p.two_class ? 2 : 1;
         for (int pass = 0; pass < npass; ++pass) {
             hipLaunchKernelGGL(topk_select_kernel, dim3(p.B), dim3(1024), lds, st, p.boxes, p.N, p.D, p.obj_idx, p.cls_start,
                                p.two_class, pass, w.cand, w.n_cand, w.more, w.need);
             hipLaunchKernelGGL(nms_matrix_kernel, dim3(NMS_WORDS, NMS_WORDS, p.B), dim3(64), 0, st, p.boxes, p.N, p.D,
                                p.iou_thr, w.cand, w.n_cand, w.mask);
-            hipLaunchKernelGGL(nms_scan_kernel, dim3(p.B), dim3(256), 0, st, p.max_out, pass, w.cand, w.n_cand, w.more,
+            hipLaunchKernelGGL(nms_scan_kernel, dim3(p.B), dim3(256), scan_lds, st, p.max_out, pass, w.cand, w.n_cand, w.more,
                                w.mask, w.kidx, w.cnt, w.need);
         }
         hipLaunchKernelGGL(nms_finish_kernel, dim3(p.B), dim3(1024), 0, st, p.boxes, p.N, p.D, p.max_out, npass, w.kidx,
