@@ -55,6 +55,9 @@ PROTOTYPES = {
     "byolo_set_first_image": (_i32, [_vp, _i64]),
     "byolo_max_images": (_i32, [_vp, _i32, _P(_i32)]),
     "byolo_layer_output": (_i32, [_vp, _i32, _P(_vp), _P(_i64)]),
+    "byolo_copy_layer_output": (_i32, [_vp, _i32, _vp, _i64, _vp]),
+    "byolo_set_precision": (_i32, [_vp, _i32]),
+    "byolo_get_precision": (_i32, [_vp]),
     "byolo_decode": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _P(_f32), _i32, _vp, _i64, _i64, _vp]),
     "byolo_epistemic_stats": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "byolo_nms_workspace_bytes": (_sz, [_i32, _i64]),

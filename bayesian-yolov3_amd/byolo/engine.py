@@ -34,6 +34,17 @@ class Engine:
         self._ws_key = None
         self.finalized = False
 
+    # ---- arithmetic of the convolution stack (include/byolo.h: BYOLO_PREC_*) ----------------------------
+    @property
+    def precision(self):
+        return "split" if check(self._h, lib.byolo_get_precision(self._h)) == 1 else "f32"
+
+    def set_precision(self, precision):
+        """'f32' (fp32 matrix instruction) or 'split' (hi + lo fp16 pairs, three fp16 products per fp32 product).
+        Call before finalize()."""
+        check(self._h, lib.byolo_set_precision(self._h, {"f32": 0, "split": 1}[precision]))
+        self.finalized = False
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             lib.byolo_destroy(self._h)
@@ -235,8 +246,12 @@ class Engine:
         off = ptr.value - ws.data_ptr() if ws is not None else -1
         if ws is None or off < 0 or off + 4 * n > ws.numel():
             raise RuntimeError("layer_output: the workspace of the last forward is gone")
+        # float32 values whatever the handle's precision (split-f16 activations are hi/lo pairs in the workspace)
+        out = torch.empty(shape, dtype=torch.float32, device="cuda:%d" % self.device)
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        check(self._h, lib.byolo_copy_layer_output(self._h, int(idx), ctypes.c_void_p(out.data_ptr()), n, ctypes.c_void_p(stream)))
         torch.cuda.synchronize(self.device)
-        return ws[off:off + 4 * n].view(torch.float32).reshape(shape).clone()
+        return out
 
     def calibrate_bn(self, img):
         self._check_img(img)

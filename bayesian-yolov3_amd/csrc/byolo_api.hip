@@ -67,6 +67,7 @@ struct Layer {
     size_t scalek_off = 0;             // dropout layers: scale / (1 - p), what the epilogue multiplies with when the masks are on
     int tile = 0, Npad = 0;
     bool direct = false;
+    int wshift = 0;                // split precision: the packed weights hold w * 2^wshift (largest |w'| in [2^13, 2^14))
     int64_t box_base = 0;
 };
 
@@ -113,6 +114,10 @@ struct Plan {
     size_t wino_off = 0;           // scratch for V and M of one chunk (shared by all steps)
 };
 static constexpr int CNT_PER_STEP = 1024;      // >= resident workgroups of any tile configuration
+// split precision: every activation tensor holds ACT_SCALE * value, so that the lo half of a value >= 2^-6 is a normal
+// fp16 (smaller values keep an absolute error of 2^-25 / ACT_SCALE = 1.9e-9); an activation beyond 65504 / ACT_SCALE
+// = 4094 overflows to infinity.  A power of two: folded into scale / shift exactly.
+static constexpr float ACT_SCALE = 16.f;
 
 }  // namespace
 
@@ -132,6 +137,11 @@ struct byolo {
     std::vector<Step> steps;
     std::vector<AuxTensor> aux;    // auxiliary tensors (ids n_layers + k): partial sums of split convs
     bool dedup = true;             // T-invariant de-duplication (BYOLO_NO_DEDUP=1 disables, for A/B)
+    // Arithmetic of the convolution stack (byolo_set_precision; BYOLO_PRECISION=f32|split):
+    //   0  fp32 operands on v_mfma_f32_32x32x2_f32 (+ Winograd F(2x2,3x3) where it pays)
+    //   1  split-f16 operands ("hi + lo", ~23 significant bits, fp32 accumulation) on v_mfma_f32_32x32x16_f16:
+    //      activations live in memory as [4 hi | 4 lo] groups holding ACT_SCALE * value, weights as 2^wshift * w
+    int precision = 0;
     std::vector<int> last_use;     // per tensor id: index of the last step reading it
     float* d_blob = nullptr;       // packed weights + scale/shift
     size_t blob_floats = 0;
@@ -176,7 +186,7 @@ static int32_t fail(byolo_t* h, int32_t code, const char* fmt, ...) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" const char* byolo_version(void) { return "byolo 0.1 (gfx950, fp32 MFMA)"; }
+extern "C" const char* byolo_version(void) { return "byolo 0.2 (gfx950; fp32 MFMA and split-f16 MFMA)"; }
 
 extern "C" const char* byolo_last_error(const byolo_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -195,9 +205,18 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
     if (!h) return fail(nullptr, BYOLO_ERR_NOMEM, "byolo_create: out of host memory");
     h->cfg = *cfg;
     h->device = device;
+    if (const char* e = getenv("BYOLO_PRECISION")) h->precision = (!strcmp(e, "split") || !strcmp(e, "1")) ? 1 : 0;
     *out = h;
     return BYOLO_OK;
 }
+
+extern "C" int32_t byolo_set_precision(byolo_t* h, int32_t precision) {
+    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_set_precision: null handle");
+    if (precision != BYOLO_PREC_F32 && precision != BYOLO_PREC_SPLIT_F16) return fail(h, BYOLO_ERR_ARG, "byolo_set_precision: unknown precision %d", precision);
+    if (precision != h->precision) { h->precision = precision; h->finalized = false; h->plan.B = -1; h->plan.T = -1; }
+    return BYOLO_OK;
+}
+extern "C" int32_t byolo_get_precision(const byolo_t* h) { return h ? h->precision : BYOLO_ERR_ARG; }
 
 extern "C" int32_t byolo_destroy(byolo_t* h) {
     if (!h) return BYOLO_OK;
@@ -599,6 +618,15 @@ static void fold_layer(const byolo_t* h, const Layer& l, std::vector<float>& sca
     }
 }
 
+// split precision: the accumulators hold ACT_SCALE * 2^wshift * conv (the stem: conv -- fp32 image, fp32 weights) and the
+// output tensor holds ACT_SCALE * value (a detection head: the value itself, fp32) -- powers of two, folded exactly
+static void fold_split(const Layer& l, std::vector<float>& scale, std::vector<float>& shift) {
+    const float acc_scale = l.direct ? 1.f : ACT_SCALE * ldexpf(1.f, l.wshift);
+    const float out_scale = l.op == OP_DETECTION ? 1.f : ACT_SCALE;
+    for (float& v : scale) v *= out_scale / acc_scale;
+    for (float& v : shift) v *= out_scale;
+}
+
 // inverted dropout's 1 / (1 - p) (layers.py:520-527 via tf.layers.dropout) is folded into the per-channel scale
 static void scale_keep(const byolo_t* h, std::vector<float>& scale) {
     const float inv_keep = 1.0f / (1.0f - h->cfg.drop_prob);
@@ -625,6 +653,21 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
     }
     std::vector<float> blob(off, 0.f);
     std::vector<float> sc, sf;
+    if (h->precision == 1) {
+        for (auto& l : h->layers) {
+            if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
+            if (l.op == OP_CONV && (l.filters % 4))
+                return fail(h, BYOLO_ERR_ARG, "byolo_finalize: split precision stores activations in groups of 4 channels; layer '%s' has %d", l.scope.c_str(), l.filters);
+            if (l.direct && l.prev >= 0)
+                return fail(h, BYOLO_ERR_ARG, "byolo_finalize: split precision: layer '%s' needs the general direct convolution (input channels not a multiple of 32), which reads fp32 only", l.scope.c_str());
+            const Param& k = h->params[l.p_kernel];
+            float mx = 0.f;
+            for (float v : k.data) mx = std::max(mx, std::fabs(v));
+            int e = 0;
+            if (mx > 0.f && std::isfinite(mx)) (void)std::frexp(mx, &e);          // mx = m * 2^e, m in [0.5, 1)
+            l.wshift = mx > 0.f ? 14 - e : 0;
+        }
+    }
     for (auto& st : h->steps) {
         if (!st.is_conv()) continue;
         const Layer& l = h->layers[st.layer];
@@ -632,7 +675,23 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         const float* w = h->params[l.p_kernel].data.data();     // HWIO == [K][N], k = (ky*ks + kx)*Cin + c
         float* dst = blob.data() + st.w_off;
         if (l.direct) memcpy(dst, w, sizeof(float) * (size_t)taps * l.Cin * N);
-        else {
+        else if (h->precision == 1) {
+            // split-f16 weights (mfma_pipe.h): w' = w * 2^wshift with the layer's largest |w'| in [2^13, 2^14), each
+            // element as hi = RNE_f16(w'), lo = RNE_f16(w' - hi); a packed row [kt][n] of 32 k is 8 groups [4 hi | 4 lo]
+            _Float16* d16 = reinterpret_cast<_Float16*>(dst);
+            const float ws = ldexpf(1.f, l.wshift);
+            for (int tap = 0; tap < taps; ++tap)
+                for (int c = 0; c < Cs; ++c) {
+                    const int k = tap * Cs + c, kt = k >> 5, kk = k & 31;
+                    const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
+                    _Float16* d = d16 + ((size_t)kt * st.Npad) * 64 + (kk >> 2) * 8 + (kk & 3);
+                    for (int nn = 0; nn < N; ++nn) {
+                        const float v = wr[nn] * ws;
+                        const _Float16 hi = (_Float16)v;
+                        d[(size_t)nn * 64] = hi; d[(size_t)nn * 64 + 4] = (_Float16)(v - (float)hi);
+                    }
+                }
+        } else {
             for (int tap = 0; tap < taps; ++tap)
                 for (int c = 0; c < Cs; ++c) {                  // this launch's channel slice of every tap
                     const int k = tap * Cs + c, kt = k >> 5, kk = k & 31;
@@ -641,7 +700,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
                     for (int nn = 0; nn < N; ++nn) d[(size_t)nn * 32] = wr[nn];
                 }
         }
-        if (st.wino_ok) {                                       // U[xi][c][n] = (G g G^T)[xi], each xi packed like a 1x1 conv
+        if (st.wino_ok && h->precision == 0) {                  // U[xi][c][n] = (G g G^T)[xi], each xi packed like a 1x1 conv
             float* u = blob.data() + st.wino_off;
             const size_t xi_stride = (size_t)(Cs / 32) * st.Npad * 32;
             float g9[9], u16[16];
@@ -655,6 +714,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         }
         if (st.mode == STEP_PARTIAL) continue;
         fold_layer(h, l, sc, sf);
+        if (h->precision == 1) fold_split(l, sc, sf);
         memcpy(blob.data() + l.scale_off, sc.data(), sizeof(float) * N);
         memcpy(blob.data() + l.shift_off, sf.data(), sizeof(float) * N);
         if (l.drop_ordinal >= 0) {
@@ -769,7 +829,7 @@ static void make_plan(byolo_t* h, int B, int T) {
     p.wino.assign(h->steps.size(), WinoPlan{});
     size_t wino_scratch = 0;
     { const char* e = getenv("BYOLO_WINOGRAD");
-      const int on = e ? atoi(e) : 1;
+      const int on = h->precision == 1 ? 0 : (e ? atoi(e) : 1);   // split precision: direct convolutions only (memory-bound transforms do not pay there)
       const char* mf = getenv("BYOLO_WINO_MIN_GFLOP");                     // tuning knob: smallest layer (direct GFLOP) to transform
       // (measured at config 4: 100 -> 144.97, 20 -> 147.35, 5 -> 147.32 img/s; at config 2 (416x416, 8 images) the 52x52
       //  layers are 12.8 GFLOP: 20 -> 1375, 10 -> 1506, 5 -> 1504 img/s.  Default 10.)
@@ -828,7 +888,7 @@ static void make_plan(byolo_t* h, int B, int T) {
     // BYOLO_STREAM1X1=0 keeps them on conv_igemm (A/B), =2 takes it for every shape the kernel can express (tests).
     p.stream1x1.assign(h->steps.size(), 0);
     { const char* e = getenv("BYOLO_STREAM1X1");
-      const bool on = !e || atoi(e) != 0, force = e && atoi(e) >= 2;
+      const bool on = h->precision == 0 && (!e || atoi(e) != 0), force = e && atoi(e) >= 2;
       for (size_t si = 0; on && si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
@@ -925,6 +985,7 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.d_hw = make_fastdiv((uint32_t)(l.H * l.W)); p.d_wout = make_fastdiv((uint32_t)l.W);
     p.d_sdiv0 = make_fastdiv((uint32_t)sdiv[0]); p.d_sdiv1 = make_fastdiv((uint32_t)sdiv[1]);
     p.rep = st.mode == STEP_REP ? T : 1;
+    p.split = h->precision == 1 && !l.direct;
     if (st.mode == STEP_MAIN) {
         p.addend = reinterpret_cast<const float*>(ws + h->plan.off[st.addend_tensor]);
         p.addend_T = l.stacked ? T : 1;
@@ -936,7 +997,7 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
 static int32_t run_aux_step(byolo_t* h, const Step& s, const ConvParams& p, hipStream_t st) {
     const Layer& l = h->layers[s.layer];
     if (s.mode == STEP_GATHER) { HIPCHK(h, launch_view_gather(p, st)); }
-    else { HIPCHK(h, launch_tensor_add(p.src0, p.src1, p.dst, (int64_t)p.M * l.C, st)); }
+    else { HIPCHK(h, launch_tensor_add(p.src0, p.src1, p.dst, (int64_t)p.M * l.C, h->precision == 1, st)); }
     return BYOLO_OK;
 }
 
@@ -1112,6 +1173,10 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
             }
         }
         if (s.mode == STEP_PARTIAL) p.flags = EPI_RAW;          // raw partial sums for the STEP_MAIN launch
+        if (h->precision == 1) {
+            if (l.op == OP_DETECTION) p.flags |= EPI_F32OUT;    // the decode kernels read plain fp32
+            else if (l.direct) p.split = 2;                     // the stem: fp32 in, split-f16 out
+        }
         // tile configuration and split-K of the last partial round: decided per (B, T) in make_plan
         const int tile = h->plan.tile[si];
         const ConvSplit& sp = h->plan.split[si];
@@ -1178,8 +1243,22 @@ extern "C" int32_t byolo_layer_output(const byolo_t* h, int32_t idx, const float
         return fail(hh, BYOLO_ERR_STATE, "byolo_layer_output: handle created without keep_all_outputs");
     if (!h->last_ws || h->plan.B < 0) return fail(hh, BYOLO_ERR_STATE, "byolo_layer_output: no forward has run");
     if (!l.materialized) return fail(hh, BYOLO_ERR_ARG, "byolo_layer_output: layer %d has no tensor of its own (fused or a view)", idx);
-    if (d_ptr) *d_ptr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->last_ws) + h->plan.off[idx]);
+    const float* t = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->last_ws) + h->plan.off[idx]);
+    if (d_ptr) *d_ptr = t;
     if (shape) { shape[0] = l.stacked ? (int64_t)h->plan.B * h->plan.T : h->plan.B; shape[1] = l.H; shape[2] = l.W; shape[3] = l.C; }
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_copy_layer_output(const byolo_t* h, int32_t idx, float* d_dst, int64_t count, void* stream) {
+    byolo_t* hh = const_cast<byolo_t*>(h);
+    const float* src; int64_t shp[4];
+    int32_t rc = byolo_layer_output(h, idx, &src, shp); if (rc) return rc;
+    const int64_t n = shp[0] * shp[1] * shp[2] * shp[3];
+    if (!d_dst || count != n) return fail(hh, BYOLO_ERR_ARG, "byolo_copy_layer_output: destination of %lld floats, the layer has %lld", (long long)count, (long long)n);
+    HIPCHK(hh, hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (h->precision == 1 && h->layers[idx].op != OP_DETECTION) HIPCHK(hh, launch_split_to_f32(src, d_dst, n, 1.f / ACT_SCALE, st));
+    else HIPCHK(hh, hipMemcpyAsync(d_dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     return BYOLO_OK;
 }
 
@@ -1256,8 +1335,10 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         Layer& l = h->layers[s.layer];
         ConvParams p; fill_conv(h, s, d_img, ws, B, 1, p);
         if (!s.is_conv()) { int32_t rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
-        if (l.op == OP_DETECTION) { HIPCHK(h, launch_conv_igemm(p, s.tile, st)); continue; }
-        p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = 0;             // raw conv output (+ addend for STEP_MAIN)
+        const bool split = h->precision == 1;
+        if (l.op == OP_DETECTION) { if (split) p.flags |= EPI_F32OUT; HIPCHK(h, launch_conv_igemm(p, s.tile, st)); continue; }
+        // raw conv output (+ addend for STEP_MAIN), fp32; split precision: the accumulators, ACT_SCALE * 2^wshift * conv
+        p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = split ? (s.mode == STEP_PARTIAL ? EPI_RAW : EPI_F32OUT) : 0;
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, s.tile, st));
         if (s.mode == STEP_PARTIAL) continue;                              // half of a split conv: statistics at STEP_MAIN
         const int N = l.filters;
@@ -1265,7 +1346,12 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         HIPCHK(h, hipMemcpyAsync(h->params[l.p_mean].data.data(), d_mean, sizeof(float) * N, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipMemcpyAsync(h->params[l.p_var].data.data(), d_var, sizeof(float) * N, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
+        if (split && !l.direct) {                                          // statistics of the accumulators -> of the convolution
+            const float f = 1.f / (ACT_SCALE * ldexpf(1.f, l.wshift));
+            for (int c = 0; c < N; ++c) { h->params[l.p_mean].data[c] *= f; h->params[l.p_var].data[c] *= f * f; }
+        }
         fold_layer(h, l, sc, sf);
+        if (split) fold_split(l, sc, sf);
         HIPCHK(h, hipMemcpyAsync(dptr(h, l.scale_off), sc.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
         HIPCHK(h, hipMemcpyAsync(dptr(h, l.shift_off), sf.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
         HIPCHK(h, hipStreamSynchronize(st));
@@ -1276,7 +1362,7 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         }
         const float* res = l.fused_residual >= 0
             ? reinterpret_cast<const float*>(ws + h->plan.off[h->layers[l.fused_residual].ref[0]]) : nullptr;
-        HIPCHK(h, launch_bn_act_inplace(p.dst, p.M, N, dptr(h, l.scale_off), dptr(h, l.shift_off), res, 1, st));
+        HIPCHK(h, launch_bn_act_inplace(p.dst, p.M, N, dptr(h, l.scale_off), dptr(h, l.shift_off), res, 1, split, st));
     }
     HIPCHK(h, hipStreamSynchronize(st));
     return BYOLO_OK;

@@ -21,7 +21,8 @@ inline hipError_t set_dynamic_lds_once(const void* fn, size_t bytes, std::atomic
 }
 
 
-enum : int { EPI_LEAKY = 1, EPI_DROPOUT = 2, EPI_RESIDUAL = 4, EPI_RAW = 8 /* store the accumulators as they are */ };
+enum : int { EPI_LEAKY = 1, EPI_DROPOUT = 2, EPI_RESIDUAL = 4, EPI_RAW = 8 /* store the accumulators as they are */,
+              EPI_F32OUT = 16 /* split-f16 launch: plain fp32 output (detection heads) */ };
 
 // n / d for n < 2^31 as (umulhi(n, mul) + n) >> shr: the kernels divide by launch constants only
 // (h*w, w, T, #column tiles), and a 32-bit integer division costs ~30 vector-ALU instructions that
@@ -67,6 +68,7 @@ struct ConvParams {
     int M, N, Npad, ldc;
     int KT, cin_tiles;                // K/32, (C0+C1)/32
     int flags;                        // EPI_*
+    int split;                        // 1: split-f16 sources / weights / residual / output (mfma_pipe.h), 0: fp32; 2 (stem): fp32 in, split-f16 out
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
     uint64_t idx_base;                // dropout element index of dst[0] (sub-batch / shard of a logical batch)
     FastDiv d_hw, d_wout, d_sdiv0, d_sdiv1, d_addT;   // Hout*Wout, Wout, sdiv0, sdiv1, addend_T
@@ -153,7 +155,8 @@ int conv_pick_tile(int N);            // tile config for cout = N
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st);
 // a route / upsample / stack view copied into a dense [M][C0 + C1] tensor (sources, extents and dst as in ConvParams)
 hipError_t launch_view_gather(const ConvParams& p, hipStream_t st);
-hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, hipStream_t st);   // dst = a + b
+hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, bool split, hipStream_t st);   // dst = a + b (split: all three in [4 hi | 4 lo] groups)
+hipError_t launch_split_to_f32(const float* src, float* dst, int64_t n, float mul, hipStream_t st);   // dst[i] = mul * (hi + lo) of a split-f16 tensor
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st);   // small-cin (stem) direct conv
 
 // ---- calibration helpers -------------------------------------------------------------------
@@ -161,8 +164,9 @@ hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st);   // small-c
 hipError_t launch_channel_stats(const float* x, int64_t M, int C, float* d_mean, float* d_var, double* d_tmp,
                                 hipStream_t st);
 // in place: x = [residual +] leaky(x * scale + shift)
+// split: x holds fp32 on entry and [4 hi | 4 lo] groups on exit (C % 4 == 0), the residual is a split-f16 tensor
 hipError_t launch_bn_act_inplace(float* x, int64_t M, int C, const float* scale, const float* shift,
-                                 const float* residual, int leaky, hipStream_t st);
+                                 const float* residual, int leaky, bool split, hipStream_t st);
 // scale = gamma * rsqrt(var + eps), shift = beta - mean * scale   (device-side fold)
 hipError_t launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                           float* scale, float* shift, int C, hipStream_t st);

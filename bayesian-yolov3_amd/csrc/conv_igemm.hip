@@ -69,10 +69,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // the epilogue.  counter < 0: the block computes the whole tile.
 struct TileShare { int counter, my_slab, nseg, base, stride, first_add; };
 
-template <int BM, int BN, int WM, int WN, bool FAST>
+// SPLIT: split-f16 operands and activations (mfma_pipe.h): sources, weights and residual are [4 hi | 4 lo] groups, three
+// fp16 MFMAs per product into the same fp32 accumulators; the output is encoded the same way unless EPI_F32OUT / EPI_RAW.
+template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT>
 __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical, const int kt_begin,
                                           const int kt_end, const TileShare sh) {
-    using BT = BlockTile<BM, BN, WM, WN>;
+    using BT = std::conditional_t<SPLIT, SplitTile<BM, BN, WM, WN>, BlockTile<BM, BN, WM, WN>>;
     constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD, B_LD = BT::B_LD;
     const BT bt(smem);
     const int tid = bt.tid;
@@ -204,41 +206,53 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     // (issuing them in group 0 of tile t+1 measured -0.3 %).
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
-    f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    using yes = std::true_type;
+    using no = std::false_type;
     const int KT = kt_end - kt_begin;            // K-tiles of this block
     next_tile();
     issue_loads();
     store_tile(c0{});
     if (KT > 1) { next_tile(); issue_loads(); }   // tile 1 waits in the staging registers
     __syncthreads();
-    bt.template read_frags<0, 0>(af0, bf0);
-
-    auto mf = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int) { mfma_group<TM, TN>(acc, af, bf); };
-    auto none = [] {};
     // tile t lives in LDS buffer BUF = t & 1.  HN: tile t+1 exists (stage it);  LD: tile t+2 exists (fetch it)
-    auto tile_body = [&](auto buf_tag, auto has_next_tag, auto load_tag) {
-        constexpr int BUF = decltype(buf_tag)::value;
-        constexpr bool HN = decltype(has_next_tag)::value;
-        constexpr bool LD3 = decltype(load_tag)::value && !(ABL & 1);
-        constexpr int N_ST = (ABL & 2) ? 0 : BT::NLD;
-        pipe::tile_body<BUF, HN, 0, LD3 ? BT::NLD : 0, N_ST, ABL>(
-            bt, af0, bf0, af1, bf1, mf, none, issue_loads, [&] { store_tile(std::integral_constant<int, BUF ^ 1>{}); });
+    auto run_tiles = [&](auto&& tile_body) {
+        int kt = 0;
+        for (; kt + 3 < KT; kt += 2) {                      // tiles kt, kt+1: both stage t+1 and fetch t+2
+            next_tile(); tile_body(c0{}, yes{}, yes{});
+            next_tile(); tile_body(c1{}, yes{}, yes{});
+        }
+        auto tail = [&](auto buf_tag, const int t) {          // the last 1..3 tiles (block-uniform branches)
+            if (t >= KT) return;
+            if (t + 2 < KT) { next_tile(); tile_body(buf_tag, yes{}, yes{}); }
+            else if (t + 1 < KT) tile_body(buf_tag, yes{}, no{});
+            else tile_body(buf_tag, no{}, no{});
+        };
+        tail(c0{}, kt); tail(c1{}, kt + 1); tail(c0{}, kt + 2);
     };
-    using yes = std::true_type;
-    using no = std::false_type;
-    // (s_setprio around this loop was measured: no effect.)
-    int kt = 0;
-    for (; kt + 3 < KT; kt += 2) {                      // tiles kt, kt+1: both stage t+1 and fetch t+2
-        next_tile(); tile_body(c0{}, yes{}, yes{});
-        next_tile(); tile_body(c1{}, yes{}, yes{});
+    if constexpr (SPLIT) {
+        f16x8 af0[TM][2], bf0[TN][2], af1[TM][2], bf1[TN][2];
+        bt.template read_frags<0, 0>(af0, bf0);
+        run_tiles([&](auto buf_tag, auto has_next_tag, auto load_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool HN = decltype(has_next_tag)::value, LD3 = decltype(load_tag)::value;
+            pipe::tile_body_split<BUF, HN, LD3 ? BT::NLD : 0, BT::NLD>(
+                bt, acc, af0, bf0, af1, bf1, issue_loads, [&] { store_tile(std::integral_constant<int, BUF ^ 1>{}); });
+        });
+    } else {
+        f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+        bt.template read_frags<0, 0>(af0, bf0);
+        auto mf = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int) { mfma_group<TM, TN>(acc, af, bf); };
+        auto none = [] {};
+        // (s_setprio around this loop was measured: no effect.)
+        run_tiles([&](auto buf_tag, auto has_next_tag, auto load_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool HN = decltype(has_next_tag)::value;
+            constexpr bool LD3 = decltype(load_tag)::value && !(ABL & 1);
+            constexpr int N_ST = (ABL & 2) ? 0 : BT::NLD;
+            pipe::tile_body<BUF, HN, 0, LD3 ? BT::NLD : 0, N_ST, ABL>(
+                bt, af0, bf0, af1, bf1, mf, none, issue_loads, [&] { store_tile(std::integral_constant<int, BUF ^ 1>{}); });
+        });
     }
-    auto tail = [&](auto buf_tag, const int t) {          // the last 1..3 tiles (block-uniform branches)
-        if (t >= KT) return;
-        if (t + 2 < KT) { next_tile(); tile_body(buf_tag, yes{}, yes{}); }
-        else if (t + 1 < KT) tile_body(buf_tag, yes{}, no{});
-        else tile_body(buf_tag, no{}, no{});
-    };
-    tail(c0{}, kt); tail(c1{}, kt + 1); tail(c0{}, kt + 2);
 
     // ---- split-K hand-off (block-uniform): slab write, ticket, ordered reduce by the last arriver ---------
     // Per-XCD L2s are not coherent with each other and a CU's L1 is not refreshed by other CUs' stores, so
@@ -307,6 +321,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     // dropout element index) is derived once per row; the (j, g) channel-group part is an immediate.
     const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT, do_res = p.flags & EPI_RESIDUAL;
     const float slope = do_leaky ? 0.1f : 1.f;
+    const bool split_out = !(p.flags & EPI_F32OUT);            // SPLIT: encode the output (everything but a detection head)
     // T-invariant de-duplication (lowering in byolo_api.hip):
     //   rep > 1     the conv ran once per IMAGE (its input does not depend on the MC sample); only the
     //               dropout mask differs between the T samples, so the epilogue is replayed T times and
@@ -415,8 +430,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
                         if constexpr (VEC) {
                             // (a launch with BOTH an addend and a residual -- a de-duplicated concat convolution
                             //  followed by a residual add: no reference model has one -- prefetched the addend)
-                            if (do_res) v += p.addend ? *reinterpret_cast<const f32x4*>(res_row[i] + dn) : extra[j * 4 + g];
-                            *reinterpret_cast<f32x4*>(d) = v;
+                            if (do_res) {
+                                const f32x4 r4 = p.addend ? *reinterpret_cast<const f32x4*>(res_row[i] + dn) : extra[j * 4 + g];
+                                v += SPLIT ? epi::split_decode4(r4) : r4;
+                            }
+                            *reinterpret_cast<f32x4*>(d) = (SPLIT && split_out) ? epi::split_encode4(v) : v;
                         } else {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
@@ -439,7 +457,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
 //  number)
 // 2nd launch bound = waves per SIMD: two workgroups per CU (what the LDS allows for the 128x128 tile) must
 // also fit the register file, i.e. VGPRs + AGPRs <= 256 per wave.
-template <int BM, int BN, int WM, int WN, bool FAST>
+template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT>
 __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // One loop, one inlined conv_tile: the work items of this workgroup are either
@@ -490,7 +508,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kern
                 sh = TileShare{tile_local, tile_local * p.ksplit + slice, p.ksplit, tile_local * p.ksplit, 1, 0};
             }
         }
-        conv_tile<BM, BN, WM, WN, FAST>(p, smem, logical, kb, ke, sh);
+        conv_tile<BM, BN, WM, WN, FAST, SPLIT>(p, smem, logical, kb, ke, sh);
     }
 }
 
@@ -502,10 +520,10 @@ int conv_pick_tile(int N) {
     return TILE_128x32;
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST>
+template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT>
 static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
-    constexpr size_t lds = BlockTile<BM, BN, WM, WN>::LDS_BYTES;
-    auto k = conv_igemm_kernel<BM, BN, WM, WN, FAST>;
+    constexpr size_t lds = BlockTile<BM, BN, WM, WN>::LDS_BYTES;     // the split image has the same size
+    auto k = conv_igemm_kernel<BM, BN, WM, WN, FAST, SPLIT>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), lds, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, st, p);
@@ -599,7 +617,8 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     static const int persist = [] { const char* e = getenv("BYOLO_PERSIST"); return e ? atoi(e) : 0; }();
     if (persist > 0 && q.sk_grid == 0 && grid > 256 * persist) grid = 256 * persist;
     const bool fast = p.C1 == 0 && p.sh0 == 0 && p.ksize <= 3;
-    return fast ? launch_one<BM, BN, WM, WN, true>(q, grid, st) : launch_one<BM, BN, WM, WN, false>(q, grid, st);
+    if (p.split) return fast ? launch_one<BM, BN, WM, WN, true, true>(q, grid, st) : launch_one<BM, BN, WM, WN, false, true>(q, grid, st);
+    return fast ? launch_one<BM, BN, WM, WN, true, false>(q, grid, st) : launch_one<BM, BN, WM, WN, false, false>(q, grid, st);
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "byolo_kernels.h"
 #include "byolo_rng.h"
+#include "epilogue.h"
 
 namespace byk {
 
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
             const float y = acc[n + q] * p.scale[n + q] + p.shift[n + q];
             v[q] = fmaxf(y, slope * y);
         }
-        *reinterpret_cast<f32x4*>(d + n) = v;
+        *reinterpret_cast<f32x4*>(d + n) = p.split == 2 ? epi::split_encode4(v) : v;     // split precision: [4 hi | 4 lo]
     }
 }
 
@@ -128,7 +129,7 @@ hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st) {
         hipLaunchKernelGGL(conv_stem3x3_kernel<32>, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st, p);
         return hipGetLastError();
     }
-    if (p.rep != 1 || p.addend) return hipErrorInvalidValue;          // the de-duplicated forms are implicit-GEMM only
+    if (p.rep != 1 || p.addend || p.split) return hipErrorInvalidValue;   // the de-duplicated forms are implicit-GEMM only; fp32 only
     const size_t wbytes = (size_t)p.ksize * p.ksize * (p.C0 + p.C1) * p.N * sizeof(float);
     const int w_in_lds = wbytes <= 48 * 1024;
     const int64_t total = (int64_t)p.M * ((p.N + 7) >> 3);
@@ -161,13 +162,31 @@ __global__ __launch_bounds__(256) void view_gather_kernel(const ConvParams p) {
 __global__ __launch_bounds__(256) void tensor_add_kernel(const float* a, const float* b, float* d, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = a[i] + b[i];
 }
+__global__ __launch_bounds__(256) void tensor_add_split_kernel(const f32x4* a, const f32x4* b, f32x4* d, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = epi::split_encode4(epi::split_decode4(a[i]) + epi::split_decode4(b[i]));
+}
+__global__ __launch_bounds__(256) void split_to_f32_kernel(const f32x4* s, f32x4* d, int64_t n4, float mul) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = epi::split_decode4(s[i]) * mul;
+}
 static unsigned grid_for(int64_t n) { int64_t b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 256 * 32 ? 256 * 32 : b)); }
 hipError_t launch_view_gather(const ConvParams& p, hipStream_t st) {
     hipLaunchKernelGGL(view_gather_kernel, dim3(grid_for((int64_t)p.M * (p.C0 + p.C1))), dim3(256), 0, st, p);
     return hipGetLastError();
 }
-hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(tensor_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, b, dst, n);
+hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, bool split, hipStream_t st) {
+    if (split) {
+        if (n & 3) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(tensor_add_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(a),
+                           reinterpret_cast<const f32x4*>(b), reinterpret_cast<f32x4*>(dst), n / 4);
+    } else hipLaunchKernelGGL(tensor_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, b, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_split_to_f32(const float* src, float* dst, int64_t n, float mul, hipStream_t st) {
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(split_to_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), n / 4, mul);
     return hipGetLastError();
 }
 
@@ -231,11 +250,32 @@ __global__ void bn_act_inplace_kernel(float* x, int64_t total, int C, const floa
         x[i] = v;
     }
 }
+// split precision: fp32 in, [4 hi | 4 lo] groups out (in place, one group per thread); the residual is a split-f16 tensor
+__global__ void bn_act_inplace_split_kernel(f32x4* x, int64_t total4, int C4, const float* scale, const float* shift,
+                                            const f32x4* residual, int leaky) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = x[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = v[q] * scale[c + q] + shift[c + q];
+            if (leaky) v[q] = fmaxf(v[q], 0.1f * v[q]);
+        }
+        if (residual) v += epi::split_decode4(residual[i]);
+        x[i] = epi::split_encode4(v);
+    }
+}
 hipError_t launch_bn_act_inplace(float* x, int64_t M, int C, const float* scale, const float* shift,
-                                 const float* residual, int leaky, hipStream_t st) {
+                                 const float* residual, int leaky, bool split, hipStream_t st) {
     const int64_t total = M * C;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    if (split) {
+        if (C & 3) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(bn_act_inplace_split_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<f32x4*>(x), total / 4,
+                           C / 4, scale, shift, reinterpret_cast<const f32x4*>(residual), leaky);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(bn_act_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, total, C, scale, shift,
                        residual, leaky);
     return hipGetLastError();

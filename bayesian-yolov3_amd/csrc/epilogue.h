@@ -48,5 +48,27 @@ __device__ __forceinline__ f32x4 bn_act4(const f32x4 a, const f32x4 sc, const f3
     return v;
 }
 
+
+// Split-f16 storage of 4 consecutive channels (mfma_pipe.h): 16 bytes = [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3],
+// hi = RNE_f16(x), lo = RNE_f16(x - hi).  x is in the tensor's pre-scaled domain (byolo_api.hip folds the powers of two
+// into scale / shift); |x| >= 65520 overflows to infinity like any fp16.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 split_encode4(const f32x4 v) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { hi[q] = (_Float16)v[q]; lo[q] = (_Float16)(v[q] - (float)hi[q]); }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 h2 = __builtin_bit_cast(f32x2, hi), l2 = __builtin_bit_cast(f32x2, lo);
+    return f32x4{h2[0], h2[1], l2[0], l2[1]};
+}
+__device__ __forceinline__ f32x4 split_decode4(const f32x4 w) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f16x4 hi = __builtin_bit_cast(f16x4, f32x2{w[0], w[1]}), lo = __builtin_bit_cast(f16x4, f32x2{w[2], w[3]});
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (float)hi[q] + (float)lo[q];
+    return v;
+}
+
 }  // namespace epi
 }  // namespace byk

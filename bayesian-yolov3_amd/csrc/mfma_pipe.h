@@ -166,5 +166,121 @@ __device__ __forceinline__ void tile_body(const BT& t, f32x4 (&af0)[BT::TM], f32
     __builtin_amdgcn_sched_barrier(0);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-f16 operands ("hi + lo"): the same pipeline on v_mfma_f32_32x32x16_f16, three products per fp32 product.
+//
+// Every activation / weight element is stored as TWO fp16 values, hi = RNE_f16(x), lo = RNE_f16(x - hi) (x = hi + lo to
+// ~23 significant bits; tensors are pre-scaled by powers of two -- byolo_api.hip -- so that lo stays a normal fp16 for
+// every value that matters), in groups of 4 elements: 16 bytes = [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3].  A tensor keeps
+// 4 bytes per element and 16 bytes per 4 channels, so every address of the fp32 kernels is unchanged.  The product
+//     x * w  ~=  hi_x hi_w + hi_x lo_w + lo_x hi_w        (lo_x lo_w < 2^-22 |x w| is dropped)
+// runs as three MFMAs into ONE fp32 accumulator: products of fp16 values are exact in fp32 and the instruction sums its
+// 16 products before one rounding (tools/mfma_f16_probe.hip), so the result is fp32-grade at
+// 3/16 of the fp32 MFMA's time per product (measured 2.1 - 2.45 PFLOP/s fp16 = 700 - 800 TFLOP/s fp32-equivalent).
+//
+// LDS image (bytes): a staged row = [32 hi | 32 lo] fp16 = 128 bytes + 16 pad (the same 144-byte stride as the fp32
+// image: conflict-free ds_read_b128); a 16-byte global load (4 channels) lands as two 8-byte halves (ds_write2_b64:
+// hi at +8q, lo at +64+8q).  MFMA step s (k = 16 channels) of lane-half h consumes channels 16s + 8h .. +7: ONE
+// ds_read_b128 per operand plane.  Same transposed C/D map as the fp32 kernels (lane = pixel, 4 groups of 4 channels).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct SplitTile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int NT = 64 * WM * WN;
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static constexpr int A_LD = BM * 8 / NT, B_LD = BN * 8 / NT;
+    static constexpr int ROWB = LD * 4, A_BUF = BM * ROWB, B_BUF = BN * ROWB, B_BASE = 2 * A_BUF;
+    static constexpr int JSTEP = (NT / 8) * ROWB;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * ROWB;
+    static constexpr int G = 3 * TM * TN;                    // MFMAs per step (16 channels) per wave
+    static constexpr int NFR = 2 * (TM + TN);                // fragment reads per step
+    static constexpr int NLD = A_LD + B_LD;                  // 16-byte loads per K-tile per thread
+    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile config");
+
+    char* lds;
+    int tid, wm, wn, li, lh;
+    int a_q, a_r;
+    int st_off, fa_off, fb_off;
+
+    __device__ __forceinline__ explicit SplitTile(float* smem) {
+        lds = reinterpret_cast<char*>(smem);
+        tid = threadIdx.x;
+        const int wave = tid >> 6, lane = tid & 63;
+        wm = wave / WN; wn = wave % WN;
+        li = lane & 31; lh = lane >> 5;
+        a_q = tid & 7; a_r = tid >> 3;
+        st_off = a_r * ROWB + a_q * 8;
+        fa_off = (wm * TM * 32 + li) * ROWB + lh * 16;
+        fb_off = (wn * TN * 32 + li) * ROWB + lh * 16;
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ void store_row(char* at, const f32x4& v) const {     // hi half, lo half: one ds_write2_b64
+        *reinterpret_cast<f32x2*>(at) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(at + 64) = f32x2{v[2], v[3]};
+    }
+    template <int BUF> __device__ __forceinline__ void store_a(const f32x4 (&a)[A_LD]) const {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) store_row(lds + st_off + (BUF * A_BUF + j * JSTEP), a[j]);
+    }
+    template <int BUF> __device__ __forceinline__ void store_b(const f32x4 (&b)[B_LD]) const {
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) store_row(lds + st_off + (B_BASE + BUF * B_BUF + j * JSTEP), b[j]);
+    }
+    // fragments of step S (0 | 1) of the K-tile in buffer BUF: [0] = hi plane, [1] = lo plane
+    template <int BUF, int S> __device__ __forceinline__ void read_frags(f16x8 (&af)[TM][2], f16x8 (&bf)[TN][2]) const {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                af[i][h] = *reinterpret_cast<const f16x8*>(lds + fa_off + (BUF * A_BUF + S * 32 + h * 64 + i * 32 * ROWB));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                bf[j][h] = *reinterpret_cast<const f16x8*>(lds + fb_off + (B_BASE + BUF * B_BUF + S * 32 + h * 64 + j * 32 * ROWB));
+    }
+};
+
+// One step (16 channels): hi*hi, hi*lo, lo*hi of every 32x32 block; product-major, so consecutive MFMAs go to different
+// accumulators (a dependent MFMA would wait out the 8 passes of its predecessor).
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_step_split(f32x16 (&acc)[TM][TN], const f16x8 (&af)[TM][2], const f16x8 (&bf)[TN][2]) {
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][pr == 2 ? 1 : 0], af[i][pr == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+}
+
+// One K-tile (32 channels = 2 steps) of the split pipeline; tile t lives in LDS buffer BUF, the fragments of its step 0
+// already in (af0, bf0).
+//   step 0 | fragment reads of step 1, then (HN) the LDS writes of tile t+1 into the other buffer
+//   barrier  (every read of the current buffer is in registers; tile t+1 is visible afterwards)
+//   step 1 | [loads: global loads of tile t+2 into the staging registers just freed], (HN) fragment reads of step 0 of
+//          | tile t+1
+template <int BUF, bool HN, int N_LD, int N_ST, class BT, class L, class St>
+__device__ __forceinline__ void tile_body_split(const BT& t, f32x16 (&acc)[BT::TM][BT::TN], f16x8 (&af0)[BT::TM][2], f16x8 (&bf0)[BT::TN][2],
+                                                f16x8 (&af1)[BT::TM][2], f16x8 (&bf1)[BT::TN][2], L&& loads, St&& store_next) {
+    constexpr int G = BT::G, NFR = BT::NFR;
+    __builtin_amdgcn_sched_barrier(0);
+    t.template read_frags<BUF, 1>(af1, bf1);
+    if constexpr (HN) store_next();
+    mfma_step_split<BT::TM, BT::TN>(acc, af0, bf0);
+    sched_interleave<G, 0, NFR, HN ? N_ST : 0>();
+    __builtin_amdgcn_sched_barrier(0);
+
+    __syncthreads();
+    if constexpr (N_LD > 0) loads();
+    if constexpr (HN) t.template read_frags<BUF ^ 1, 0>(af0, bf0);
+    mfma_step_split<BT::TM, BT::TN>(acc, af1, bf1);
+    sched_interleave<G, N_LD, HN ? NFR : 0, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 }  // namespace pipe
 }  // namespace byk

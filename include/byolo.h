@@ -59,6 +59,18 @@ typedef struct byolo_cfg {
 /* ---- lifetime ---------------------------------------------------------------------------- */
 BYOLO_API int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** out);
 BYOLO_API int32_t byolo_destroy(byolo_t* h);
+/* Arithmetic of the convolution stack (the reference runs TensorFlow's float32 kernels, lib_yolo/layers.py:550; both
+ * modes accumulate in fp32 and hold the 1e-4 contract against the float32 CPU restatement):
+ *   BYOLO_PREC_F32        fp32 operands on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32), Winograd F(2x2,3x3)
+ *                         for the large 3x3 convolutions;
+ *   BYOLO_PREC_SPLIT_F16  every activation / weight as hi + lo, two fp16 values (~23 significant bits), three fp16
+ *                         matrix products per fp32 product into fp32 accumulators (v_mfma_f32_32x32x16_f16); an
+ *                         activation beyond +-4094 overflows (fp16 range / 16).
+ * Default: environment BYOLO_PRECISION = f32 | split, else BYOLO_PREC_F32.  Call before byolo_finalize (a finalized
+ * handle must be finalized again). */
+enum { BYOLO_PREC_F32 = 0, BYOLO_PREC_SPLIT_F16 = 1 };
+BYOLO_API int32_t byolo_set_precision(byolo_t* h, int32_t precision);
+BYOLO_API int32_t byolo_get_precision(const byolo_t* h);
 BYOLO_API const char* byolo_last_error(const byolo_t* h);
 BYOLO_API const char* byolo_version(void);
 
@@ -141,6 +153,10 @@ BYOLO_API int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images);
  * (the reference's model.layers[idx], model.py:191); for detection layers the raw conv output
  * (DetLayer.raw_output, model.py:241) -- those are readable on any handle (they are never overwritten). */
 BYOLO_API int32_t byolo_layer_output(const byolo_t* h, int32_t idx, const float** d_ptr, int64_t shape[4]);
+/* The same tensor as float32 values, copied into caller-owned device memory d_dst[count] (count = the product of the
+ * shape) on `stream`.  Under BYOLO_PREC_SPLIT_F16 the pointer of byolo_layer_output addresses the hi/lo pairs the
+ * kernels exchange (only detection layers are plain float32 there): read activations through this call. */
+BYOLO_API int32_t byolo_copy_layer_output(const byolo_t* h, int32_t idx, float* d_dst, int64_t count, void* stream);
 
 /* ---- staged tail entry points (parity tests on oracle-provided inputs) ------------------------ */
 /* decode one detection layer: d_raw [S,lh,lw,F] -> rows written at their concat_bbox position in
