@@ -97,6 +97,7 @@ struct Step {
     size_t w_off = 0; int Npad = 0, tile = 0;   // packed weights of this launch
     bool wino_ok = false;          // 3x3 / stride 1 over one plain source: Winograd F(2x2,3x3) is possible
     size_t wino_off = 0;           // the 16 transformed weight matrices U[xi], each packed [Cin/32][Npad][32]
+    bool kx3 = false;              // split precision: 3x3 / stride 1 over one plain source -- shared-tap stages (conv_tile_kx3), weights in (ky, chunk, kx) order
 };
 // per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
 struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; };
@@ -672,23 +673,33 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         if (!st.is_conv()) continue;
         const Layer& l = h->layers[st.layer];
         const int Cs = st.c_hi - st.c_lo, taps = l.ksize * l.ksize, N = l.filters;
+        st.kx3 = false;
         const float* w = h->params[l.p_kernel].data.data();     // HWIO == [K][N], k = (ky*ks + kx)*Cin + c
         float* dst = blob.data() + st.w_off;
         if (l.direct) memcpy(dst, w, sizeof(float) * (size_t)taps * l.Cin * N);
         else if (h->precision == 1) {
+            static const bool kx3_on = [] { const char* e = getenv("BYOLO_KX3"); return !e || atoi(e) != 0; }();
+            st.kx3 = kx3_on && l.ksize == 3 && l.stride == 1 && st.in.n == 1 && st.in.s[0].sh == 0 && st.in.s[0].layer >= 0 && st.Npad >= 64 &&
+                     (st.mode == STEP_NORMAL || st.mode == STEP_REP);
+            const int cts = Cs / 32;
             // split-f16 weights (mfma_pipe.h): w' = w * 2^wshift with the layer's largest |w'| in [2^13, 2^14), each
-            // element as hi = RNE_f16(w'), lo = RNE_f16(w' - hi); a packed row [kt][n] of 32 k is 8 groups [4 hi | 4 lo]
+            // element as hi = RNE_f16(w'), lo = RNE_f16(w' - hi), in FRAGMENT ORDER: [K-tile][32-column block][step s]
+            // [plane: hi, lo][lane = 32 * half + column][8 fp16: k = 32 kt + 16 s + 8 half + 0..7] -- the operand
+            // registers of v_mfma_f32_32x32x16_f16 as one coalesced 1 KB load per (step, plane).
+            // K-tile order: (tap, chunk); shared-tap launches: (ky, chunk, kx)
             _Float16* d16 = reinterpret_cast<_Float16*>(dst);
             const float ws = ldexpf(1.f, l.wshift);
+            const size_t blocks = st.Npad / 32;
             for (int tap = 0; tap < taps; ++tap)
                 for (int c = 0; c < Cs; ++c) {
-                    const int k = tap * Cs + c, kt = k >> 5, kk = k & 31;
+                    const int kk = c & 31, step = kk >> 4, half = (kk >> 3) & 1, e = kk & 7;
+                    const int kt = st.kx3 ? ((tap / 3) * cts + (c >> 5)) * 3 + tap % 3 : tap * cts + (c >> 5);
                     const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
-                    _Float16* d = d16 + ((size_t)kt * st.Npad) * 64 + (kk >> 2) * 8 + (kk & 3);
                     for (int nn = 0; nn < N; ++nn) {
                         const float v = wr[nn] * ws;
                         const _Float16 hi = (_Float16)v;
-                        d[(size_t)nn * 64] = hi; d[(size_t)nn * 64 + 4] = (_Float16)(v - (float)hi);
+                        _Float16* d = d16 + (((size_t)kt * blocks + (nn >> 5)) * 4 + step * 2) * 512 + (half * 32 + (nn & 31)) * 8 + e;
+                        d[0] = hi; d[512] = (_Float16)(v - (float)hi);
                     }
                 }
         } else {
@@ -820,7 +831,9 @@ static void make_plan(byolo_t* h, int B, int T) {
         int tile = s.tile;
         if (tile == TILE_128x128 && (l.filters % 128) == 0 && (int64_t)((M + 127) / 128) * (l.filters / 128) < 512) tile = TILE_128x64;
         p.tile[si] = tile;
-        p.split[si] = conv_plan_split(M, s.Npad, KT, tile);
+        // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
+        const bool sp = h->precision == 1, kx3 = sp && s.kx3;
+        p.split[si] = conv_plan_split(M, s.Npad, kx3 ? KT / 3 : KT, tile, sp ? (kx3 ? 1.2 : 0.4) : 1.0);
         slab = std::max(slab, conv_split_slab_bytes(p.split[si], tile));
     }
     // Winograd F(2x2,3x3) for the large 3x3 / stride-1 convolutions (winograd.hip): samples per chunk such that
@@ -986,6 +999,7 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.d_sdiv0 = make_fastdiv((uint32_t)sdiv[0]); p.d_sdiv1 = make_fastdiv((uint32_t)sdiv[1]);
     p.rep = st.mode == STEP_REP ? T : 1;
     p.split = h->precision == 1 && !l.direct;
+    if (p.split && st.kx3) { p.kx3 = 1; p.KT = 3 * p.cin_tiles; }       // scheduling unit = stage (ky, chunk) = 3 K-tiles
     if (st.mode == STEP_MAIN) {
         p.addend = reinterpret_cast<const float*>(ws + h->plan.off[st.addend_tensor]);
         p.addend_T = l.stacked ? T : 1;
@@ -1208,7 +1222,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
             HIPCHK(h, launch_gemm_stream(q, st));
             continue;
         }
-        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st, l.direct ? 1 : (sp.sk_grid > 0 ? -sp.sk_grid : sp.ksplit), l.direct ? 0 : sp.split_tiles); if (rc) return rc; }
+        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile) + (p.kx3 ? 3000 : (p.split ? 1000 : 0)), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st, l.direct ? 1 : (sp.sk_grid > 0 ? -sp.sk_grid : sp.ksplit), l.direct ? 0 : sp.split_tiles); if (rc) return rc; }
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, tile, st));
     }
     if (per_step) {

@@ -69,6 +69,7 @@ struct ConvParams {
     int KT, cin_tiles;                // K/32, (C0+C1)/32
     int flags;                        // EPI_*
     int split;                        // 1: split-f16 sources / weights / residual / output (mfma_pipe.h), 0: fp32; 2 (stem): fp32 in, split-f16 out
+    int kx3;                          // split 3x3 / stride-1 launch on shared-tap stages (conv_tile_kx3): weights packed in (ky, chunk, kx) order, KT counts stages
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
     uint64_t idx_base;                // dropout element index of dst[0] (sub-batch / shard of a logical batch)
     FastDiv d_hw, d_wout, d_sdiv0, d_sdiv1, d_addT;   // Hout*Wout, Wout, sdiv0, sdiv1, addend_T
@@ -145,7 +146,8 @@ hipError_t launch_wino_output(const WinoParams& p, hipStream_t st);
 void wino_weight_transform(const float g[9], float u[16]);   // host: U = G g G^T
 
 struct ConvSplit { int full_tiles, split_tiles, split_blocks, ksplit; int sk_grid = 0; };
-ConvSplit conv_plan_split(int M, int Npad, int KT, int tile);      // decision (shape-only, deterministic)
+// decision (shape-only, deterministic); KT in the launch's scheduling units, tk_scale = time of a unit / time of an fp32 K-tile
+ConvSplit conv_plan_split(int M, int Npad, int KT, int tile, double tk_scale = 1.0);
 size_t conv_split_slab_bytes(const ConvSplit& sp, int tile);
 
 // tile configuration ids

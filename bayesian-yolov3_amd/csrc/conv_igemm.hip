@@ -69,191 +69,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // the epilogue.  counter < 0: the block computes the whole tile.
 struct TileShare { int counter, my_slab, nseg, base, stride, first_add; };
 
-// SPLIT: split-f16 operands and activations (mfma_pipe.h): sources, weights and residual are [4 hi | 4 lo] groups, three
-// fp16 MFMAs per product into the same fp32 accumulators; the output is encoded the same way unless EPI_F32OUT / EPI_RAW.
-template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT>
-__device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical, const int kt_begin,
-                                          const int kt_end, const TileShare sh) {
-    using BT = std::conditional_t<SPLIT, SplitTile<BM, BN, WM, WN>, BlockTile<BM, BN, WM, WN>>;
-    constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD, B_LD = BT::B_LD;
-    const BT bt(smem);
-    const int tid = bt.tid;
-    const uint32_t n_tiles = (uint32_t)p.Npad / BN;
-    const uint32_t tile_m = fdiv((uint32_t)logical, p.d_ntiles), tile_n = (uint32_t)logical - tile_m * n_tiles;
-
-    // ---- per-thread A-row bookkeeping (4 rows at BM = 128, 256 threads) -----------------------------
-    // Each thread stages the same A_LD rows of every K-tile.  Row state = output pixel (sample, oy, ox).
-    const int a_q = bt.a_q, a_r = bt.a_r;
+// The end of a tile, shared by every K loop of this file: split-K hand-off, then the fused epilogue on the accumulators
+// (wave (wm, wn) of the WM x WN block owns TM x TN blocks of 32 x 32; lane = pixel li (+32 per block row), 4 groups of 4
+// consecutive channels from 4 * lh).
+template <int BM, int BN, int WM, int WN, bool SPLIT>
+__device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
+                                            const uint32_t tile_m, const uint32_t tile_n, const TileShare sh) {
+    constexpr int NT = 64 * WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
     const uint32_t hw = (uint32_t)(p.Hout * p.Wout);
-    uint32_t a_voff[A_LD];                       // byte offset of the row for the current (tap, source)
-    uint32_t a_off00[A_LD], a_mask[A_LD];        // FAST: tap (0,0) offset, validity bit per tap
-    int a_iy0[A_LD], a_ix0[A_LD];                // !FAST: input coordinate of tap (0,0)
-    uint32_t a_s0[A_LD], a_s1[A_LD];             //        sample index in each source
-#pragma unroll
-    for (int j = 0; j < A_LD; ++j) {
-        const uint32_t m = tile_m * BM + a_r + (NT / 8) * j;
-        const bool row_ok = m < (uint32_t)p.M;
-        const uint32_t mm = row_ok ? m : 0u;
-        const uint32_t s = fdiv(mm, p.d_hw), rem = mm - s * hw;
-        const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * (uint32_t)p.Wout;
-        const int iy0 = (int)oy * p.stride - p.pad, ix0 = (int)ox * p.stride - p.pad;
-        if constexpr (FAST) {
-            unsigned ym = 0, xm = 0;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                ym |= (t < p.ksize && (unsigned)(iy0 + t) < (unsigned)p.Hin) ? (1u << t) : 0u;
-                xm |= (t < p.ksize && (unsigned)(ix0 + t) < (unsigned)p.Win) ? (1u << t) : 0u;
-            }
-            unsigned mk = 0;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) mk |= ((ym >> t) & 1u) ? xm << (t * p.ksize) : 0u;
-            a_mask[j] = row_ok ? mk : 0u;
-            // 32-bit wrap-around arithmetic: the sum for a VALID tap is the true offset (< 2^32)
-            const uint32_t s0 = fdiv(s, p.d_sdiv0);
-            a_off00[j] = ((((s0 * (uint32_t)p.Hs0 + (uint32_t)iy0) * (uint32_t)p.Ws0 + (uint32_t)ix0) * (uint32_t)p.C0) + a_q * 4) * 4u;
-        } else {
-            a_iy0[j] = row_ok ? iy0 : -(1 << 28);    // every tap out of bounds -> reads 0
-            a_ix0[j] = ix0;
-            a_s0[j] = fdiv(s, p.d_sdiv0);
-            a_s1[j] = fdiv(s, p.d_sdiv1);
-        }
-    }
-
-    // ---- K-tile sequencing: block-uniform, scalar registers ------------------------------------------
-    int ld_tap = (int)fdiv((uint32_t)kt_begin, p.d_cin);     // (channel chunk, tap) of the NEXT tile to load
-    int ld_chunk = kt_begin - ld_tap * p.cin_tiles;
-    int ld_ky = (int)fdiv((uint32_t)ld_tap, p.d_ks), ld_kx = ld_tap - ld_ky * p.ksize;
-    bool ld_first = true;                                   // the first tile sets the row offsets whatever its chunk
-    uint32_t a_soff = 0;                                    // byte offset of that tile's channels inside a row
-    const float* a_base = p.src0;
-    uint32_t a_bytes = p.src0_bytes;
-    const uint32_t w_step = (uint32_t)p.Npad * BK * 4;
-    uint32_t w_soff = (uint32_t)kt_begin * w_step;          // byte offset of the next weight tile
-    if (p.wino_rows) w_soff += fdiv(tile_m * BM, p.d_wino) * p.wino_wstride;   // Winograd: row block xi has its own matrix
-    const uint32_t b_voff = (tile_n * BN * BK + (uint32_t)tid * 4) * 4;
-
-    auto next_tile = [&]() {
-        if constexpr (FAST) {
-            if (ld_chunk == 0 || ld_first) {
-                const uint32_t delta = (uint32_t)((ld_ky * p.Ws0 + ld_kx) * p.C0) * 4u;
-                const uint32_t bit = 1u << ld_tap;
-#pragma unroll
-                for (int j = 0; j < A_LD; ++j) a_voff[j] = (a_mask[j] & bit) ? a_off00[j] + delta : CONV_OOB_OFFSET;
-            }
-            a_soff = (uint32_t)ld_chunk * (BK * 4);
-        } else {
-            const int cc = ld_chunk * BK;
-            const bool second = cc >= p.C0;
-            if (ld_chunk == 0 || cc == p.C0 || ld_first) {
-                const uint32_t C = second ? p.C1 : p.C0, Hs = second ? p.Hs1 : p.Hs0, Ws = second ? p.Ws1 : p.Ws0;
-                const int sh = second ? p.sh1 : p.sh0;
-#pragma unroll
-                for (int j = 0; j < A_LD; ++j) {
-                    const int iy = a_iy0[j] + ld_ky, ix = a_ix0[j] + ld_kx;
-                    const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-                    const uint32_t s = second ? a_s1[j] : a_s0[j];
-                    const uint32_t off = ((((s * Hs + (uint32_t)(iy >> sh)) * Ws + (uint32_t)(ix >> sh)) * C) + a_q * 4) * 4u;
-                    a_voff[j] = ok ? off : CONV_OOB_OFFSET;
-                }
-                a_base = second ? p.src1 : p.src0;
-                a_bytes = second ? p.src1_bytes : p.src0_bytes;
-            }
-            a_soff = (uint32_t)(second ? cc - p.C0 : cc) * 4u;
-        }
-        ld_first = false;
-        if (++ld_chunk == p.cin_tiles) {
-            ld_chunk = 0; ++ld_tap;
-            if (++ld_kx == p.ksize) { ld_kx = 0; ++ld_ky; }
-        }
-    };
-
-    f32x4 a_reg[A_LD], b_reg[B_LD];              // staging registers, one K-tile
-    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wpk, p.w_bytes);
-    auto issue_loads = [&]() {                   // A_LD + B_LD buffer_load_dwordx4 of the tile set up by next_tile()
-        const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_bytes);
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j) a_reg[j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) b_reg[j] = buffer_load_x4(w_rsrc, b_voff, w_soff + j * (NT * 16));
-        w_soff += w_step;
-    };
-    auto store_tile = [&](auto buf_tag) {        // the staged K-tile -> LDS buffer BUF
-        constexpr int BUF = decltype(buf_tag)::value;
-        if constexpr ((ABL & 2) != 0) {
-#pragma unroll
-            for (int j = 0; j < A_LD; ++j) asm volatile("" : : "v"(a_reg[j]));
-#pragma unroll
-            for (int j = 0; j < B_LD; ++j) asm volatile("" : : "v"(b_reg[j]));
-            return;
-        }
-        bt.template store_a<BUF>(a_reg);
-        bt.template store_b<BUF>(b_reg);
-    };
-
-    const int wm = bt.wm, wn = bt.wn, li = bt.li, lh = bt.lh;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- software-pipelined K loop (schedule: mfma_pipe.h tile_body) ----------------------------------------------
-    // The loop body is branch-free (tail tiles peeled).  The buffer loads of tile t+2 go into the staging registers
-    // just freed, in the last MFMA group of tile t: three MFMA groups before the LDS write that waits for them
-    // (issuing them in group 0 of tile t+1 measured -0.3 %).
-    using c0 = std::integral_constant<int, 0>;
-    using c1 = std::integral_constant<int, 1>;
-    using yes = std::true_type;
-    using no = std::false_type;
-    const int KT = kt_end - kt_begin;            // K-tiles of this block
-    next_tile();
-    issue_loads();
-    store_tile(c0{});
-    if (KT > 1) { next_tile(); issue_loads(); }   // tile 1 waits in the staging registers
-    __syncthreads();
-    // tile t lives in LDS buffer BUF = t & 1.  HN: tile t+1 exists (stage it);  LD: tile t+2 exists (fetch it)
-    auto run_tiles = [&](auto&& tile_body) {
-        int kt = 0;
-        for (; kt + 3 < KT; kt += 2) {                      // tiles kt, kt+1: both stage t+1 and fetch t+2
-            next_tile(); tile_body(c0{}, yes{}, yes{});
-            next_tile(); tile_body(c1{}, yes{}, yes{});
-        }
-        auto tail = [&](auto buf_tag, const int t) {          // the last 1..3 tiles (block-uniform branches)
-            if (t >= KT) return;
-            if (t + 2 < KT) { next_tile(); tile_body(buf_tag, yes{}, yes{}); }
-            else if (t + 1 < KT) tile_body(buf_tag, yes{}, no{});
-            else tile_body(buf_tag, no{}, no{});
-        };
-        tail(c0{}, kt); tail(c1{}, kt + 1); tail(c0{}, kt + 2);
-    };
-    if constexpr (SPLIT) {
-        f16x8 af0[TM][2], bf0[TN][2], af1[TM][2], bf1[TN][2];
-        bt.template read_frags<0, 0>(af0, bf0);
-        run_tiles([&](auto buf_tag, auto has_next_tag, auto load_tag) {
-            constexpr int BUF = decltype(buf_tag)::value;
-            constexpr bool HN = decltype(has_next_tag)::value, LD3 = decltype(load_tag)::value;
-            pipe::tile_body_split<BUF, HN, LD3 ? BT::NLD : 0, BT::NLD>(
-                bt, acc, af0, bf0, af1, bf1, issue_loads, [&] { store_tile(std::integral_constant<int, BUF ^ 1>{}); });
-        });
-    } else {
-        f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
-        bt.template read_frags<0, 0>(af0, bf0);
-        auto mf = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int) { mfma_group<TM, TN>(acc, af, bf); };
-        auto none = [] {};
-        // (s_setprio around this loop was measured: no effect.)
-        run_tiles([&](auto buf_tag, auto has_next_tag, auto load_tag) {
-            constexpr int BUF = decltype(buf_tag)::value;
-            constexpr bool HN = decltype(has_next_tag)::value;
-            constexpr bool LD3 = decltype(load_tag)::value && !(ABL & 1);
-            constexpr int N_ST = (ABL & 2) ? 0 : BT::NLD;
-            pipe::tile_body<BUF, HN, 0, LD3 ? BT::NLD : 0, N_ST, ABL>(
-                bt, af0, bf0, af1, bf1, mf, none, issue_loads, [&] { store_tile(std::integral_constant<int, BUF ^ 1>{}); });
-        });
-    }
-
     // ---- split-K hand-off (block-uniform): slab write, ticket, ordered reduce by the last arriver ---------
     // Per-XCD L2s are not coherent with each other and a CU's L1 is not refreshed by other CUs' stores, so
     // the slabs travel with sc1 (write-through / system-coherent) stores and loads: once a wave's vmcnt has
@@ -449,6 +274,334 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     else epilogue(std::false_type{});
 }
 
+// SPLIT: split-f16 operands and activations (mfma_pipe.h): sources, weights and residual are [4 hi | 4 lo] groups, three
+// fp16 MFMAs per product into the same fp32 accumulators; the output is encoded the same way unless EPI_F32OUT / EPI_RAW.
+template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT>
+__device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, const int logical, const int kt_begin,
+                                          const int kt_end, const TileShare sh) {
+    using BT = std::conditional_t<SPLIT, SplitTile<BM, BN, WM, WN>, BlockTile<BM, BN, WM, WN>>;
+    constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD;
+    constexpr int B_LD = SPLIT ? 1 : BN * 8 / NT;            // SPLIT: the weight operand does not pass through LDS
+    const BT bt(smem);
+    const int tid = bt.tid;
+    const uint32_t n_tiles = (uint32_t)p.Npad / BN;
+    const uint32_t tile_m = fdiv((uint32_t)logical, p.d_ntiles), tile_n = (uint32_t)logical - tile_m * n_tiles;
+
+    // ---- per-thread A-row bookkeeping (4 rows at BM = 128, 256 threads) -----------------------------
+    // Each thread stages the same A_LD rows of every K-tile.  Row state = output pixel (sample, oy, ox).
+    const int a_q = bt.a_q, a_r = bt.a_r;
+    const uint32_t hw = (uint32_t)(p.Hout * p.Wout);
+    uint32_t a_voff[A_LD];                       // byte offset of the row for the current (tap, source)
+    uint32_t a_off00[A_LD], a_mask[A_LD];        // FAST: tap (0,0) offset, validity bit per tap
+    int a_iy0[A_LD], a_ix0[A_LD];                // !FAST: input coordinate of tap (0,0)
+    uint32_t a_s0[A_LD], a_s1[A_LD];             //        sample index in each source
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const uint32_t m = tile_m * BM + a_r + (NT / 8) * j;
+        const bool row_ok = m < (uint32_t)p.M;
+        const uint32_t mm = row_ok ? m : 0u;
+        const uint32_t s = fdiv(mm, p.d_hw), rem = mm - s * hw;
+        const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * (uint32_t)p.Wout;
+        const int iy0 = (int)oy * p.stride - p.pad, ix0 = (int)ox * p.stride - p.pad;
+        if constexpr (FAST) {
+            unsigned ym = 0, xm = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ym |= (t < p.ksize && (unsigned)(iy0 + t) < (unsigned)p.Hin) ? (1u << t) : 0u;
+                xm |= (t < p.ksize && (unsigned)(ix0 + t) < (unsigned)p.Win) ? (1u << t) : 0u;
+            }
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) mk |= ((ym >> t) & 1u) ? xm << (t * p.ksize) : 0u;
+            a_mask[j] = row_ok ? mk : 0u;
+            // 32-bit wrap-around arithmetic: the sum for a VALID tap is the true offset (< 2^32)
+            const uint32_t s0 = fdiv(s, p.d_sdiv0);
+            a_off00[j] = ((((s0 * (uint32_t)p.Hs0 + (uint32_t)iy0) * (uint32_t)p.Ws0 + (uint32_t)ix0) * (uint32_t)p.C0) + a_q * 4) * 4u;
+        } else {
+            a_iy0[j] = row_ok ? iy0 : -(1 << 28);    // every tap out of bounds -> reads 0
+            a_ix0[j] = ix0;
+            a_s0[j] = fdiv(s, p.d_sdiv0);
+            a_s1[j] = fdiv(s, p.d_sdiv1);
+        }
+    }
+
+    // ---- K-tile sequencing: block-uniform, scalar registers ------------------------------------------
+    int ld_tap = (int)fdiv((uint32_t)kt_begin, p.d_cin);     // (channel chunk, tap) of the NEXT tile to load
+    int ld_chunk = kt_begin - ld_tap * p.cin_tiles;
+    int ld_ky = (int)fdiv((uint32_t)ld_tap, p.d_ks), ld_kx = ld_tap - ld_ky * p.ksize;
+    bool ld_first = true;                                   // the first tile sets the row offsets whatever its chunk
+    uint32_t a_soff = 0;                                    // byte offset of that tile's channels inside a row
+    const float* a_base = p.src0;
+    uint32_t a_bytes = p.src0_bytes;
+    const uint32_t w_step = (uint32_t)p.Npad * BK * 4;      // (SPLIT: = Npad / 32 blocks of SPLIT_WBLOCK bytes per K-tile)
+    uint32_t w_soff = (uint32_t)kt_begin * w_step;          // byte offset of the next weight tile
+    if constexpr (SPLIT) w_soff += tile_n * (BN / 32) * SPLIT_WBLOCK;
+    if (p.wino_rows) w_soff += fdiv(tile_m * BM, p.d_wino) * p.wino_wstride;   // Winograd: row block xi has its own matrix
+    const uint32_t b_voff = (tile_n * BN * BK + (uint32_t)tid * 4) * 4;
+
+    auto next_tile = [&]() {
+        if constexpr (FAST) {
+            if (ld_chunk == 0 || ld_first) {
+                const uint32_t delta = (uint32_t)((ld_ky * p.Ws0 + ld_kx) * p.C0) * 4u;
+                const uint32_t bit = 1u << ld_tap;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) a_voff[j] = (a_mask[j] & bit) ? a_off00[j] + delta : CONV_OOB_OFFSET;
+            }
+            a_soff = (uint32_t)ld_chunk * (BK * 4);
+        } else {
+            const int cc = ld_chunk * BK;
+            const bool second = cc >= p.C0;
+            if (ld_chunk == 0 || cc == p.C0 || ld_first) {
+                const uint32_t C = second ? p.C1 : p.C0, Hs = second ? p.Hs1 : p.Hs0, Ws = second ? p.Ws1 : p.Ws0;
+                const int sh = second ? p.sh1 : p.sh0;
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) {
+                    const int iy = a_iy0[j] + ld_ky, ix = a_ix0[j] + ld_kx;
+                    const bool ok = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                    const uint32_t s = second ? a_s1[j] : a_s0[j];
+                    const uint32_t off = ((((s * Hs + (uint32_t)(iy >> sh)) * Ws + (uint32_t)(ix >> sh)) * C) + a_q * 4) * 4u;
+                    a_voff[j] = ok ? off : CONV_OOB_OFFSET;
+                }
+                a_base = second ? p.src1 : p.src0;
+                a_bytes = second ? p.src1_bytes : p.src0_bytes;
+            }
+            a_soff = (uint32_t)(second ? cc - p.C0 : cc) * 4u;
+        }
+        ld_first = false;
+        if (++ld_chunk == p.cin_tiles) {
+            ld_chunk = 0; ++ld_tap;
+            if (++ld_kx == p.ksize) { ld_kx = 0; ++ld_ky; }
+        }
+    };
+
+    f32x4 a_reg[A_LD], b_reg[B_LD];              // staging registers, one K-tile (SPLIT: b_reg unused)
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wpk, p.w_bytes);
+    auto issue_loads = [&]() {                   // the buffer_load_dwordx4s of the tile set up by next_tile()
+        const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_bytes);
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) a_reg[j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
+        if constexpr (!SPLIT) {
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) b_reg[j] = buffer_load_x4(w_rsrc, b_voff, w_soff + j * (NT * 16));
+            w_soff += w_step;
+        }
+    };
+    auto store_tile = [&](auto buf_tag) {        // the staged K-tile -> LDS buffer BUF
+        constexpr int BUF = decltype(buf_tag)::value;
+        if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) asm volatile("" : : "v"(a_reg[j]));
+            if constexpr (!SPLIT) {
+#pragma unroll
+                for (int j = 0; j < B_LD; ++j) asm volatile("" : : "v"(b_reg[j]));
+            }
+            return;
+        }
+        bt.template store_a<BUF>(a_reg);
+        if constexpr (!SPLIT) bt.template store_b<BUF>(b_reg);
+    };
+
+    const int wm = bt.wm, wn = bt.wn, li = bt.li, lh = bt.lh;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- software-pipelined K loop (schedule: mfma_pipe.h tile_body) ----------------------------------------------
+    // The loop body is branch-free (tail tiles peeled).  The buffer loads of tile t+2 go into the staging registers
+    // just freed, in the last MFMA group of tile t: three MFMA groups before the LDS write that waits for them
+    // (issuing them in group 0 of tile t+1 measured -0.3 %).
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using yes = std::true_type;
+    using no = std::false_type;
+    const int KT = kt_end - kt_begin;            // K-tiles of this block
+    // SPLIT: weight fragments of tiles t, t+1 in the two register sets (set = t & 1), fetched one K-tile ahead
+    f16x8 bfr[SPLIT ? 2 : 1][2][TN][2];
+    auto issue_b = [&](auto set_tag) {
+        if constexpr (SPLIT) { bt.load_b(bfr[decltype(set_tag)::value], w_rsrc, w_soff); w_soff += w_step; }
+    };
+    next_tile();
+    issue_loads();
+    issue_b(std::integral_constant<int, 0>{});
+    store_tile(std::integral_constant<int, 0>{});
+    if (KT > 1) { next_tile(); issue_loads(); }   // tile 1 waits in the staging registers
+    __syncthreads();
+    // tile t lives in LDS buffer BUF = t & 1.  HN: tile t+1 exists (stage it);  LD: tile t+2 exists (fetch it)
+    auto run_tiles = [&](auto&& tile_body) {
+        int kt = 0;
+        for (; kt + 3 < KT; kt += 2) {                      // tiles kt, kt+1: both stage t+1 and fetch t+2
+            next_tile(); tile_body(c0{}, yes{}, yes{});
+            next_tile(); tile_body(c1{}, yes{}, yes{});
+        }
+        auto tail = [&](auto buf_tag, const int t) {          // the last 1..3 tiles (block-uniform branches)
+            if (t >= KT) return;
+            if (t + 2 < KT) { next_tile(); tile_body(buf_tag, yes{}, yes{}); }
+            else if (t + 1 < KT) tile_body(buf_tag, yes{}, no{});
+            else tile_body(buf_tag, no{}, no{});
+        };
+        tail(c0{}, kt); tail(c1{}, kt + 1); tail(c0{}, kt + 2);
+    };
+    if constexpr (SPLIT) {
+        f16x8 af0[TM][2], af1[TM][2];
+        bt.template read_frags<0, 0>(af0);
+        run_tiles([&](auto buf_tag, auto has_next_tag, auto load_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool HN = decltype(has_next_tag)::value, LD = !(ABL & 1), LD3 = decltype(load_tag)::value && LD;
+            pipe::tile_body_split<BUF, HN, (HN && LD) ? BT::NBF : 0, LD3 ? A_LD : 0, (ABL & 2) ? 0 : A_LD, ABL>(
+                bt, acc, af0, af1, bfr[BUF], [&] { issue_b(std::integral_constant<int, BUF ^ 1>{}); }, issue_loads,
+                [&] { store_tile(std::integral_constant<int, BUF ^ 1>{}); });
+        });
+    } else {
+        f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+        bt.template read_frags<0, 0>(af0, bf0);
+        auto mf = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int) { mfma_group<TM, TN>(acc, af, bf); };
+        auto none = [] {};
+        // (s_setprio around this loop was measured: no effect.)
+        run_tiles([&](auto buf_tag, auto has_next_tag, auto load_tag) {
+            constexpr int BUF = decltype(buf_tag)::value;
+            constexpr bool HN = decltype(has_next_tag)::value;
+            constexpr bool LD3 = decltype(load_tag)::value && !(ABL & 1);
+            constexpr int N_ST = (ABL & 2) ? 0 : BT::NLD;
+            pipe::tile_body<BUF, HN, 0, LD3 ? BT::NLD : 0, N_ST, ABL>(
+                bt, af0, bf0, af1, bf1, mf, none, issue_loads, [&] { store_tile(std::integral_constant<int, BUF ^ 1>{}); });
+        });
+    }
+
+    finish_tile<BM, BN, WM, WN, SPLIT>(p, smem, acc, tile_m, tile_n, sh);
+}
+
+// 3x3 / stride-1 / one plain source, split-f16 (SplitTileKx in mfma_pipe.h): stages [sg_begin, sg_end) of the tile, a
+// stage = (filter row ky, 32-channel chunk) = the three K-tiles kx = 0, 1, 2 on one staged activation tile.  The body
+// is uniform: every K-tile stages the weight tile after it and fetches the one after that, every stage fetches and
+// stages its successor -- past the end of the range those loads read zeros / run past the buffer (bounds-checked) and
+// what they stage is never used.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, const int logical, const int sg_begin,
+                                              const int sg_end, const TileShare sh) {
+    using BT = SplitTileKx<BM, BN, WM, WN>;
+    constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD, A_LDX = BT::A_LDX, ROWB = BT::ROWB;
+    const BT bt(smem);
+    const int tid = bt.tid;
+    const uint32_t n_tiles = (uint32_t)p.Npad / BN;
+    const uint32_t tile_m = fdiv((uint32_t)logical, p.d_ntiles), tile_n = (uint32_t)logical - tile_m * n_tiles;
+    const uint32_t hw = (uint32_t)(p.Hout * p.Wout), W = (uint32_t)p.Wout;
+
+    // ---- staging rows of this thread: A_LD rows of the tile + one halo row (threads 0 .. 15) ---------------------------
+    uint32_t a_off0[A_LDX], a_vm[A_LDX], a_voff[A_LDX];   // offset of input pixel (y - 1, x); bit ky: row y + ky - 1 exists
+#pragma unroll
+    for (int j = 0; j < A_LDX; ++j) {
+        const int rho = j < A_LD ? bt.a_r + (NT / 8) * j + 1 : (bt.a_r == 0 ? 0 : (bt.a_r == 1 ? BM + 1 : -1));
+        const int64_t mm = (int64_t)tile_m * BM - 1 + rho;
+        const bool ok = rho >= 0 && mm >= 0 && mm < (int64_t)p.M;
+        const uint32_t m = ok ? (uint32_t)mm : 0u;
+        const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
+        const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
+        unsigned vm = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) vm |= ((unsigned)((int)oy + t - 1) < (unsigned)p.Hin) ? (1u << t) : 0u;
+        a_vm[j] = ok ? vm : 0u;
+        const uint32_t s0 = fdiv(sidx, p.d_sdiv0);
+        a_off0[j] = ((((s0 * (uint32_t)p.Hs0 + (oy - 1u)) * (uint32_t)p.Ws0 + ox) * (uint32_t)p.C0) + bt.a_q * 4) * 4u;
+        a_voff[j] = CONV_OOB_OFFSET;
+    }
+    // ---- fragment row addresses: block i of this wave, kx = 0 / 1 / 2 -------------------------------------------------
+    uint32_t fa[3][TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const uint32_t rr = bt.wm * TM * 32 + i * 32 + bt.li, m = tile_m * BM + rr;
+        const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
+        const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
+        fa[0][i] = (ox > 0 ? rr : (uint32_t)BT::ZROW) * ROWB + bt.lh * 16;
+        fa[1][i] = (rr + 1) * ROWB + bt.lh * 16;
+        fa[2][i] = (ox + 1 < W ? rr + 2 : (uint32_t)BT::ZROW) * ROWB + bt.lh * 16;
+    }
+
+    // ---- sequencing (scalar): the NEXT stage to load, the next weight tile ------------------------------------------
+    int ld_ky = (int)fdiv((uint32_t)sg_begin, p.d_cin), ld_c = sg_begin - ld_ky * p.cin_tiles;
+    bool ld_first = true;
+    uint32_t a_soff = 0;
+    const uint32_t w_step = (uint32_t)p.Npad * BK * 4;
+    uint32_t w_soff = (uint32_t)sg_begin * 3u * w_step + tile_n * (BN / 32) * SPLIT_WBLOCK;
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.src0, p.src0_bytes);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wpk, p.w_bytes);
+    f32x4 a_reg[A_LDX];
+    f16x8 bfr[2][2][TN][2];                       // weight fragments of K-tiles t, t+1 (set = t & 1), fetched one K-tile ahead
+    auto next_stage = [&]() {
+        if (ld_c == 0 || ld_first) {
+            const uint32_t delta = (uint32_t)(ld_ky * p.Ws0 * p.C0) * 4u, bit = 1u << ld_ky;     // ky >= 3 (past the end): no bit
+#pragma unroll
+            for (int j = 0; j < A_LDX; ++j) a_voff[j] = (a_vm[j] & bit) ? a_off0[j] + delta : CONV_OOB_OFFSET;
+        }
+        a_soff = (uint32_t)ld_c * (BK * 4);
+        ld_first = false;
+        if (++ld_c == p.cin_tiles) { ld_c = 0; ++ld_ky; }
+    };
+    auto load_a = [&]() {
+        if constexpr ((ABL & 1) != 0) return;
+#pragma unroll
+        for (int j = 0; j < A_LDX; ++j) a_reg[j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
+    };
+    auto load_b = [&](auto set_tag) {
+        if constexpr ((ABL & 1) == 0) bt.load_b(bfr[decltype(set_tag)::value], w_rsrc, w_soff);
+        w_soff += w_step;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    f16x8 af0[TM][2], af1[TM][2];
+    next_stage(); load_a(); load_b(c0{});
+    bt.template store_stage<0>(a_reg);
+    __syncthreads();
+    bt.template read_frags_kx<0, 0>(fa[0], af0);
+
+    // K-tile Q (= kx) of a stage in activation buffer AP; its weight fragments are in set (AP + Q) & 1 (a stage flips both)
+    auto ktile = [&](auto ap_tag, auto q_tag) {
+        constexpr int AP = decltype(ap_tag)::value, Q = decltype(q_tag)::value, BS = (AP + Q) & 1;
+        constexpr int G = BT::G, NFR = (ABL & 8) ? 0 : BT::NFR, NLDB = (ABL & 1) ? 0 : BT::NBF, NLDA = (ABL & 1) ? 0 : A_LDX;
+        constexpr int NSTA = (ABL & 2) ? 0 : A_LDX;
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(std::integral_constant<int, BS ^ 1>{});                              // weight fragments of K-tile t+1
+        if constexpr (!(ABL & 8)) bt.template read_frags_kx<AP, 1>(fa[Q], af1);
+        if constexpr (Q == 2 && !(ABL & 2)) bt.template store_stage<AP ^ 1>(a_reg);  // the next stage (fetched in K-tile 0)
+        mfma_step_split<TM, TN>(acc, af0, bfr[BS][0]);
+        sched_interleave<G, NLDB, NFR, Q == 2 ? NSTA : 0>();
+        __builtin_amdgcn_sched_barrier(0);
+
+        if constexpr (Q == 2 && !(ABL & 4)) __syncthreads();                       // the next stage is visible; this one is read out
+        if constexpr (Q == 0) { next_stage(); load_a(); }                          // the next stage's activations
+        if constexpr (!(ABL & 8)) {
+            if constexpr (Q < 2) bt.template read_frags_kx<AP, 0>(fa[Q + 1], af0);
+            else bt.template read_frags_kx<AP ^ 1, 0>(fa[0], af0);
+        }
+        mfma_step_split<TM, TN>(acc, af1, bfr[BS][1]);
+        sched_interleave<G, Q == 0 ? NLDA : 0, NFR, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int NS = sg_end - sg_begin;
+    int sg = 0;
+    for (; sg + 1 < NS; sg += 2) {
+        ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{});
+        ktile(c1{}, c0{}); ktile(c1{}, c1{}); ktile(c1{}, c2{});
+    }
+    if (sg < NS) { ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{}); }
+    __syncthreads();                              // the trailing LDS traffic of the uniform body is done before LDS is reused
+    finish_tile<BM, BN, WM, WN, true>(p, smem, acc, tile_m, tile_n, sh);
+}
+
 // Workgroups walk the tile list with stride gridDim.x: with gridDim.x == #tiles every workgroup owns one
 // tile; with a smaller (persistent) grid a workgroup runs several tiles back to back.  Either way the
 // tiles that are in flight on one XCD at a time are neighbours.
@@ -457,7 +610,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
 //  number)
 // 2nd launch bound = waves per SIMD: two workgroups per CU (what the LDS allows for the 128x128 tile) must
 // also fit the register file, i.e. VGPRs + AGPRs <= 256 per wave.
-template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT>
+template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT, bool KX3 = false>
 __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // One loop, one inlined conv_tile: the work items of this workgroup are either
@@ -508,7 +661,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kern
                 sh = TileShare{tile_local, tile_local * p.ksplit + slice, p.ksplit, tile_local * p.ksplit, 1, 0};
             }
         }
-        conv_tile<BM, BN, WM, WN, FAST, SPLIT>(p, smem, logical, kb, ke, sh);
+        if constexpr (KX3) conv_tile_kx3<BM, BN, WM, WN>(p, smem, logical, kb, ke, sh);    // p.KT, kb, ke count STAGES (3 K-tiles)
+        else conv_tile<BM, BN, WM, WN, FAST, SPLIT>(p, smem, logical, kb, ke, sh);
     }
 }
 
@@ -520,10 +674,10 @@ int conv_pick_tile(int N) {
     return TILE_128x32;
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT>
+template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT, bool KX3 = false>
 static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
-    constexpr size_t lds = BlockTile<BM, BN, WM, WN>::LDS_BYTES;     // the split image has the same size
-    auto k = conv_igemm_kernel<BM, BN, WM, WN, FAST, SPLIT>;
+    constexpr size_t lds = KX3 ? (size_t)SplitTileKx<BM, BN, WM, WN>::LDS_BYTES : (SPLIT ? (size_t)SplitTile<BM, BN, WM, WN>::LDS_BYTES : (size_t)BlockTile<BM, BN, WM, WN>::LDS_BYTES);
+    auto k = conv_igemm_kernel<BM, BN, WM, WN, FAST, SPLIT, KX3>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), lds, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, st, p);
@@ -539,7 +693,7 @@ static int tile_slots(int tile) { return 256 * (tile == TILE_128x32 ? 3 : 2); }
 // the chip-time idle).  The tiles of that last partial round are therefore cut into `ksplit` K slices so that
 // they fill the chip once more with shorter blocks.  Cost model in tile-times of a whole tile; t_k, t_o from
 // DESIGN.md section 3 (per-K-tile and per-tile overhead), a slice pays the overhead + the hand-off fences.
-ConvSplit conv_plan_split(int M, int Npad, int KT, int tile) {
+ConvSplit conv_plan_split(int M, int Npad, int KT, int tile, double tk_scale) {
     const int BN = conv_tile_bn(tile), slots = tile_slots(tile);
     const int tiles = ((M + 127) / 128) * (Npad / BN);
     ConvSplit r; r.full_tiles = tiles; r.split_tiles = 0; r.ksplit = 1; r.split_blocks = 0; r.sk_grid = 0;
@@ -548,7 +702,7 @@ ConvSplit conv_plan_split(int M, int Npad, int KT, int tile) {
     const int knob = env ? atoi(env) : -1;
     // microseconds: K-tile and tile overhead of a whole tile, overhead of a slice (prologue, sc1 slab
     // round trip, ticket; measured on the 19x19 .. 76x76 head shapes and the small backbone launches)
-    const double t_k = 1.8 * BN / 128.0, t_o = 3.3, t_slice = 16.0;
+    const double t_k = 1.8 * BN / 128.0 * tk_scale, t_o = 3.3, t_slice = 16.0;    // tk_scale: K unit of the launch relative to an fp32 K-tile
     const double whole = KT * t_k + t_o;
     // ---- stream-K for small launches --------------------------------------------------------------------------
     // Fewer tiles than a few rounds of resident workgroups: a whole-tile schedule either leaves CUs idle (tiles <
@@ -596,7 +750,7 @@ size_t conv_split_slab_bytes(const ConvSplit& sp, int tile) {
     return sp.ksplit > 1 ? (size_t)sp.split_tiles * sp.ksplit * 128 * conv_tile_bn(tile) * sizeof(float) : 0;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool SPLITCFG = false>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     ConvParams q = p;
     q.d_ntiles = make_fastdiv((uint32_t)(p.Npad / BN));
@@ -617,11 +771,27 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     static const int persist = [] { const char* e = getenv("BYOLO_PERSIST"); return e ? atoi(e) : 0; }();
     if (persist > 0 && q.sk_grid == 0 && grid > 256 * persist) grid = 256 * persist;
     const bool fast = p.C1 == 0 && p.sh0 == 0 && p.ksize <= 3;
-    if (p.split) return fast ? launch_one<BM, BN, WM, WN, true, true>(q, grid, st) : launch_one<BM, BN, WM, WN, false, true>(q, grid, st);
-    return fast ? launch_one<BM, BN, WM, WN, true, false>(q, grid, st) : launch_one<BM, BN, WM, WN, false, false>(q, grid, st);
+    if (p.split != (SPLITCFG ? 1 : 0)) return hipErrorInvalidValue;
+    if constexpr (SPLITCFG) {
+        if constexpr (BN >= 64) {
+            if (p.kx3) {
+                if (!fast || p.ksize != 3 || p.stride != 1) return hipErrorInvalidValue;
+                return launch_one<BM, BN, WM, WN, true, true, true>(q, grid, st);
+            }
+        }
+        return fast ? launch_one<BM, BN, WM, WN, true, true>(q, grid, st) : launch_one<BM, BN, WM, WN, false, true>(q, grid, st);
+    } else
+        return fast ? launch_one<BM, BN, WM, WN, true, false>(q, grid, st) : launch_one<BM, BN, WM, WN, false, false>(q, grid, st);
 }
 
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st) {
+    if (p.split) {      // split-f16: the waves sit side by side along N (each fetches its own weight fragments, mfma_pipe.h)
+        switch (tile) {
+            case TILE_128x128: return launch_cfg<128, 128, 1, 4, true>(p, st);    // 4 waves of 128x32
+            case TILE_128x64:  return launch_cfg<128, 64, 2, 2, true>(p, st);     // 4 waves of 64x32
+            default:           return launch_cfg<128, 32, 4, 1, true>(p, st);     // 4 waves of 32x32
+        }
+    }
     switch (tile) {
         case TILE_128x128: return launch_cfg<128, 128, 2, 2>(p, st);      // 4 waves of 64x64
         case TILE_128x64:  return launch_cfg<128, 64, 2, 2>(p, st);       // 4 waves of 64x32

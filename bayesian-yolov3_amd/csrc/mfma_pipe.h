@@ -172,38 +172,48 @@ __device__ __forceinline__ void tile_body(const BT& t, f32x4 (&af0)[BT::TM], f32
 //
 // Every activation / weight element is stored as TWO fp16 values, hi = RNE_f16(x), lo = RNE_f16(x - hi) (x = hi + lo to
 // ~23 significant bits; tensors are pre-scaled by powers of two -- byolo_api.hip -- so that lo stays a normal fp16 for
-// every value that matters), in groups of 4 elements: 16 bytes = [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3].  A tensor keeps
-// 4 bytes per element and 16 bytes per 4 channels, so every address of the fp32 kernels is unchanged.  The product
+// every value that matters).  The product
 //     x * w  ~=  hi_x hi_w + hi_x lo_w + lo_x hi_w        (lo_x lo_w < 2^-22 |x w| is dropped)
 // runs as three MFMAs into ONE fp32 accumulator: products of fp16 values are exact in fp32 and the instruction sums its
 // 16 products before one rounding (tools/mfma_f16_probe.hip), so the result is fp32-grade at
 // 3/16 of the fp32 MFMA's time per product (measured 2.1 - 2.45 PFLOP/s fp16 = 700 - 800 TFLOP/s fp32-equivalent).
 //
-// LDS image (bytes): a staged row = [32 hi | 32 lo] fp16 = 128 bytes + 16 pad (the same 144-byte stride as the fp32
-// image: conflict-free ds_read_b128); a 16-byte global load (4 channels) lands as two 8-byte halves (ds_write2_b64:
-// hi at +8q, lo at +64+8q).  MFMA step s (k = 16 channels) of lane-half h consumes channels 16s + 8h .. +7: ONE
-// ds_read_b128 per operand plane.  Same transposed C/D map as the fp32 kernels (lane = pixel, 4 groups of 4 channels).
+// At that rate the LDS (a 16-byte staging store costs 13 cycles of its write path) and the CU's load path (64 bytes per
+// clock through the vector L1, tools/l1_l2_bw_probe.hip) are the scarce units, so only the ACTIVATION operand is staged:
+//   * activations live in memory in groups of 4 channels, 16 bytes = [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]: a tensor keeps
+//     4 bytes per element and 16 bytes per 4 channels -- every address of the fp32 kernels is unchanged.  LDS image: a
+//     staged row = [32 hi | 32 lo] fp16 = 128 bytes + 16 pad (the 144-byte stride of the fp32 image: conflict-free
+//     ds_read_b128); a 16-byte global load lands as two 8-byte halves (ds_write2_b64: hi at +8q, lo at +64+8q).  MFMA
+//     step s (k = 16 channels) of lane-half h consumes channels 16s + 8h .. +7: ONE ds_read_b128 per plane;
+//   * weights are packed on the host in FRAGMENT ORDER, [K-tile][32-channel column block][step][plane][lane][8 fp16]: a
+//     wave fetches the operand registers of its column blocks straight from global memory (one coalesced 1 KB
+//     buffer_load_dwordx4 per fragment, no LDS), one K-tile ahead, into a second register set.  The waves of a block sit
+//     side by side along N (128 x 128: 1 x 4 waves of 128 x 32), so no two waves fetch the same weights.
+// Same transposed C/D map as the fp32 kernels (lane = pixel, 4 groups of 4 channels).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int SPLIT_WBLOCK = 4096;          // bytes of one (K-tile, 32-column block) of packed weights
 
 template <int BM_, int BN_, int WM_, int WN_>
 struct SplitTile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
     static constexpr int NT = 64 * WM * WN;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static constexpr int A_LD = BM * 8 / NT, B_LD = BN * 8 / NT;
-    static constexpr int ROWB = LD * 4, A_BUF = BM * ROWB, B_BUF = BN * ROWB, B_BASE = 2 * A_BUF;
+    static constexpr int A_LD = BM * 8 / NT;
+    static constexpr int ROWB = LD * 4, A_BUF = BM * ROWB;
     static constexpr int JSTEP = (NT / 8) * ROWB;
-    static constexpr int LDS_BYTES = 2 * (BM + BN) * ROWB;
+    static constexpr int LDS_BYTES = 2 * A_BUF;
     static constexpr int G = 3 * TM * TN;                    // MFMAs per step (16 channels) per wave
-    static constexpr int NFR = 2 * (TM + TN);                // fragment reads per step
-    static constexpr int NLD = A_LD + B_LD;                  // 16-byte loads per K-tile per thread
-    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && B_LD >= 1 && BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile config");
+    static constexpr int NFR = 2 * TM;                       // LDS fragment reads per step
+    static constexpr int NBF = 4 * TN;                       // weight-fragment loads per K-tile per lane
+    static_assert(TM >= 1 && TN >= 1 && A_LD >= 1 && BM * 8 % NT == 0, "tile config");
 
     char* lds;
     int tid, wm, wn, li, lh;
     int a_q, a_r;
-    int st_off, fa_off, fb_off;
+    int st_off, fa_off;
+    uint32_t b_voff;                  // this lane's byte offset inside a weight block, + the wave's first column block
 
     __device__ __forceinline__ explicit SplitTile(float* smem) {
         lds = reinterpret_cast<char*>(smem);
@@ -214,33 +224,34 @@ struct SplitTile {
         a_q = tid & 7; a_r = tid >> 3;
         st_off = a_r * ROWB + a_q * 8;
         fa_off = (wm * TM * 32 + li) * ROWB + lh * 16;
-        fb_off = (wn * TN * 32 + li) * ROWB + lh * 16;
+        b_voff = (uint32_t)(lane * 16 + wn * TN * SPLIT_WBLOCK);
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    __device__ __forceinline__ void store_row(char* at, const f32x4& v) const {     // hi half, lo half: one ds_write2_b64
+    __device__ __forceinline__ void put(char* at, const f32x4& v) const {        // hi half, lo half: one ds_write2_b64
         *reinterpret_cast<f32x2*>(at) = f32x2{v[0], v[1]};
         *reinterpret_cast<f32x2*>(at + 64) = f32x2{v[2], v[3]};
     }
     template <int BUF> __device__ __forceinline__ void store_a(const f32x4 (&a)[A_LD]) const {
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) store_row(lds + st_off + (BUF * A_BUF + j * JSTEP), a[j]);
+        for (int j = 0; j < A_LD; ++j) put(lds + st_off + (BUF * A_BUF + j * JSTEP), a[j]);
     }
-    template <int BUF> __device__ __forceinline__ void store_b(const f32x4 (&b)[B_LD]) const {
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) store_row(lds + st_off + (B_BASE + BUF * B_BUF + j * JSTEP), b[j]);
-    }
-    // fragments of step S (0 | 1) of the K-tile in buffer BUF: [0] = hi plane, [1] = lo plane
-    template <int BUF, int S> __device__ __forceinline__ void read_frags(f16x8 (&af)[TM][2], f16x8 (&bf)[TN][2]) const {
+    // activation fragments of step S (0 | 1) of the K-tile in buffer BUF: [0] = hi plane, [1] = lo plane
+    template <int BUF, int S> __device__ __forceinline__ void read_frags(f16x8 (&af)[TM][2]) const {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 af[i][h] = *reinterpret_cast<const f16x8*>(lds + fa_off + (BUF * A_BUF + S * 32 + h * 64 + i * 32 * ROWB));
+    }
+    // weight fragments of one K-tile: [step][column block][plane]; soff = byte offset of (K-tile, column block 0 of the tile)
+    __device__ __forceinline__ void load_b(f16x8 (&bf)[2][TN][2], __amdgpu_buffer_rsrc_t rsrc, uint32_t soff) const {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                bf[j][h] = *reinterpret_cast<const f16x8*>(lds + fb_off + (B_BASE + BUF * B_BUF + S * 32 + h * 64 + j * 32 * ROWB));
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    bf[s][j][h] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b_voff, soff + (uint32_t)(j * SPLIT_WBLOCK + (s * 2 + h) * 1024), 0));
     }
 };
 
@@ -257,30 +268,76 @@ __device__ __forceinline__ void mfma_step_split(f32x16 (&acc)[TM][TN], const f16
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][pr == 2 ? 1 : 0], af[i][pr == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
 }
 
-// One K-tile (32 channels = 2 steps) of the split pipeline; tile t lives in LDS buffer BUF, the fragments of its step 0
-// already in (af0, bf0).
-//   step 0 | fragment reads of step 1, then (HN) the LDS writes of tile t+1 into the other buffer
+// One K-tile (32 channels = 2 steps) of the split pipeline; tile t lives in LDS buffer BUF, the activation fragments of
+// its step 0 already in af0, its weight fragments in bcur.
+//   step 0 | [loads_b: the weight fragments of tile t+1 into the other register set], activation fragment reads of step 1,
+//          | then (HN) the LDS writes of tile t+1 into the other buffer
 //   barrier  (every read of the current buffer is in registers; tile t+1 is visible afterwards)
-//   step 1 | [loads: global loads of tile t+2 into the staging registers just freed], (HN) fragment reads of step 0 of
-//          | tile t+1
-template <int BUF, bool HN, int N_LD, int N_ST, class BT, class L, class St>
-__device__ __forceinline__ void tile_body_split(const BT& t, f32x16 (&acc)[BT::TM][BT::TN], f16x8 (&af0)[BT::TM][2], f16x8 (&bf0)[BT::TN][2],
-                                                f16x8 (&af1)[BT::TM][2], f16x8 (&bf1)[BT::TN][2], L&& loads, St&& store_next) {
-    constexpr int G = BT::G, NFR = BT::NFR;
+//   step 1 | [loads_a: global loads of tile t+2's activations into the staging registers just freed], (HN) fragment reads
+//          | of step 0 of tile t+1
+// ABL = timing-ablation bits of the conv build (1: handled by the caller's loads, 2: by its store, 4 no barrier, 8 no
+// LDS fragment reads).
+template <int BUF, bool HN, int N_LDB, int N_LDA, int N_ST, int ABL = 0, class BT, class LB, class LA, class St>
+__device__ __forceinline__ void tile_body_split(const BT& t, f32x16 (&acc)[BT::TM][BT::TN], f16x8 (&af0)[BT::TM][2], f16x8 (&af1)[BT::TM][2],
+                                                const f16x8 (&bcur)[2][BT::TN][2], LB&& loads_b, LA&& loads_a, St&& store_next) {
+    constexpr int G = BT::G;
+    constexpr bool FR = !(ABL & 8);
+    constexpr int NFR = FR ? BT::NFR : 0;
     __builtin_amdgcn_sched_barrier(0);
-    t.template read_frags<BUF, 1>(af1, bf1);
+    if constexpr (N_LDB > 0) loads_b();
+    if constexpr (FR) t.template read_frags<BUF, 1>(af1);
     if constexpr (HN) store_next();
-    mfma_step_split<BT::TM, BT::TN>(acc, af0, bf0);
-    sched_interleave<G, 0, NFR, HN ? N_ST : 0>();
+    mfma_step_split<BT::TM, BT::TN>(acc, af0, bcur[0]);
+    sched_interleave<G, N_LDB, NFR, HN ? N_ST : 0>();
     __builtin_amdgcn_sched_barrier(0);
 
-    __syncthreads();
-    if constexpr (N_LD > 0) loads();
-    if constexpr (HN) t.template read_frags<BUF ^ 1, 0>(af0, bf0);
-    mfma_step_split<BT::TM, BT::TN>(acc, af1, bf1);
-    sched_interleave<G, N_LD, HN ? NFR : 0, 0>();
+    if constexpr (!(ABL & 4)) __syncthreads();
+    if constexpr (N_LDA > 0) loads_a();
+    if constexpr (HN && FR) t.template read_frags<BUF ^ 1, 0>(af0);
+    mfma_step_split<BT::TM, BT::TN>(acc, af1, bcur[1]);
+    sched_interleave<G, N_LDA, HN ? NFR : 0, 0>();
     __builtin_amdgcn_sched_barrier(0);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 convolutions in split-f16: the three horizontal taps of a filter row share ONE staged activation tile.
+//
+// The output rows of a tile are CONSECUTIVE pixels, so the operand of tap (ky, kx) is the operand of tap (ky, 1) shifted
+// by kx - 1 rows.  A "stage" = (filter row ky, 32-channel chunk): BM + 2 rows (pixels m0 - 1 .. m0 + BM) are staged once,
+// and the three K-tiles kx = 0, 1, 2 read their fragments from rows r + kx; a lane whose pixel sits in the first (last)
+// image column reads the stage's ZERO row for kx = 0 (2) -- one address register per (block, kx), set up once per tile.
+// Activation traffic (global and LDS stores) / 3, and a stage's loads have a K-tile and a half to arrive.  Weights are
+// packed in (ky, chunk, kx) order.
+template <int BM_, int BN_, int WM_, int WN_>
+struct SplitTileKx : SplitTile<BM_, BN_, WM_, WN_> {
+    using Base = SplitTile<BM_, BN_, WM_, WN_>;
+    using Base::BM; using Base::TM; using Base::A_LD; using Base::ROWB; using Base::JSTEP; using Base::NT;
+    static constexpr int ZROW = BM + 2;                      // rows 0 .. BM+1: pixels m0-1 .. m0+BM; row BM+2: zeros
+    static constexpr int A_STAGE = (BM + 3) * ROWB;
+    static constexpr int LDS_BYTES = 2 * A_STAGE;
+    static constexpr int A_LDX = A_LD + 1;                   // + the halo load (two rows per stage; the other threads re-zero the zero row)
+    static_assert(NT / 8 >= 2, "two halo rows");
+
+    int sta_off, sth_off;
+
+    __device__ __forceinline__ explicit SplitTileKx(float* smem) : Base(smem) {
+        sta_off = (this->a_r + 1) * ROWB + this->a_q * 8;
+        sth_off = (this->a_r == 0 ? 0 : (this->a_r == 1 ? BM + 1 : ZROW)) * ROWB + this->a_q * 8;
+    }
+    template <int BUF> __device__ __forceinline__ void store_stage(const f32x4 (&a)[A_LDX]) const {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) this->put(this->lds + sta_off + (BUF * A_STAGE + j * JSTEP), a[j]);
+        this->put(this->lds + sth_off + BUF * A_STAGE, a[A_LD]);
+    }
+    // activation fragments of step S from stage buffer ABUF at the lane's row addresses `fa` (one per block, for the K-tile's kx)
+    template <int ABUF, int S> __device__ __forceinline__ void read_frags_kx(const uint32_t (&fa)[TM], f16x8 (&af)[TM][2]) const {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                af[i][h] = *reinterpret_cast<const f16x8*>(this->lds + fa[i] + (ABUF * A_STAGE + S * 32 + h * 64));
+    }
+};
 
 }  // namespace pipe
 }  // namespace byk
