@@ -68,6 +68,7 @@ struct Layer {
     int tile = 0, Npad = 0;
     bool direct = false;
     int wshift = 0;                // split precision: the packed weights hold w * 2^wshift (largest |w'| in [2^13, 2^14))
+    float in_scale = 1.f;          // split precision: scale of the layer's input (ACT_SCALE for activations, 1 for the fp32 image of a direct convolution)
     int64_t box_base = 0;
 };
 
@@ -107,6 +108,7 @@ struct Plan {
     int B = -1, T = -1;
     std::vector<int64_t> off;      // per layer tensor offset in bytes (-1: none)
     size_t arena = 0, boxes_off = 0, nms_off = 0, stats_off = 0, total = 0;
+    size_t img_split_off = 0;      // split precision: the image as hi/lo pairs, for a matrix-pipe convolution that reads it (img_c % 32 == 0)
     size_t slab_off = 0, slab_bytes = 0, cnt_off = 0, cnt_bytes = 0;   // split-K slabs (shared by all steps), per-step ticket counters
     std::vector<ConvSplit> split;  // per step
     std::vector<int> tile;         // per step: tile configuration of the launch
@@ -142,7 +144,8 @@ struct byolo {
     //   0  fp32 operands on v_mfma_f32_32x32x2_f32 (+ Winograd F(2x2,3x3) where it pays)
     //   1  split-f16 operands ("hi + lo", ~23 significant bits, fp32 accumulation) on v_mfma_f32_32x32x16_f16:
     //      activations live in memory as [4 hi | 4 lo] groups holding ACT_SCALE * value, weights as 2^wshift * w
-    int precision = 0;
+    bool img_split = false;        // split precision: some matrix-pipe convolution reads the image -> a hi/lo copy is made per forward
+    int precision = 1;             // default: split-f16 (BYOLO_PRECISION=f32 selects the fp32 matrix instruction)
     std::vector<int> last_use;     // per tensor id: index of the last step reading it
     float* d_blob = nullptr;       // packed weights + scale/shift
     size_t blob_floats = 0;
@@ -206,7 +209,7 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
     if (!h) return fail(nullptr, BYOLO_ERR_NOMEM, "byolo_create: out of host memory");
     h->cfg = *cfg;
     h->device = device;
-    if (const char* e = getenv("BYOLO_PRECISION")) h->precision = (!strcmp(e, "split") || !strcmp(e, "1")) ? 1 : 0;
+    if (const char* e = getenv("BYOLO_PRECISION")) h->precision = (!strcmp(e, "f32") || !strcmp(e, "0")) ? 0 : 1;
     *out = h;
     return BYOLO_OK;
 }
@@ -622,7 +625,7 @@ static void fold_layer(const byolo_t* h, const Layer& l, std::vector<float>& sca
 // split precision: the accumulators hold ACT_SCALE * 2^wshift * conv (the stem: conv -- fp32 image, fp32 weights) and the
 // output tensor holds ACT_SCALE * value (a detection head: the value itself, fp32) -- powers of two, folded exactly
 static void fold_split(const Layer& l, std::vector<float>& scale, std::vector<float>& shift) {
-    const float acc_scale = l.direct ? 1.f : ACT_SCALE * ldexpf(1.f, l.wshift);
+    const float acc_scale = l.in_scale * (l.direct ? 1.f : ldexpf(1.f, l.wshift));     // the direct kernels keep fp32 weights
     const float out_scale = l.op == OP_DETECTION ? 1.f : ACT_SCALE;
     for (float& v : scale) v *= out_scale / acc_scale;
     for (float& v : shift) v *= out_scale;
@@ -654,13 +657,15 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
     }
     std::vector<float> blob(off, 0.f);
     std::vector<float> sc, sf;
+    h->img_split = false;
     if (h->precision == 1) {
         for (auto& l : h->layers) {
             if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
             if (l.op == OP_CONV && (l.filters % 4))
                 return fail(h, BYOLO_ERR_ARG, "byolo_finalize: split precision stores activations in groups of 4 channels; layer '%s' has %d", l.scope.c_str(), l.filters);
-            if (l.direct && l.prev >= 0)
-                return fail(h, BYOLO_ERR_ARG, "byolo_finalize: split precision: layer '%s' needs the general direct convolution (input channels not a multiple of 32), which reads fp32 only", l.scope.c_str());
+            // a direct convolution reads the image as it is (fp32); a matrix-pipe convolution reads a hi/lo copy of it
+            l.in_scale = (l.direct && l.prev < 0) ? 1.f : ACT_SCALE;
+            if (!l.direct && l.prev < 0) h->img_split = true;
             const Param& k = h->params[l.p_kernel];
             float mx = 0.f;
             for (float v : k.data) mx = std::max(mx, std::fabs(v));
@@ -816,6 +821,7 @@ static void make_plan(byolo_t* h, int B, int T) {
     size_t o = p.boxes_off + align_up((size_t)B * h->n_boxes * h->row_len * sizeof(float), 256);
     p.nms_off = o; o += align_up(nms_workspace_bytes(B, h->n_boxes), 256);
     p.stats_off = o; o += align_up((size_t)1024 * 2 * h->maxC * sizeof(double) + 2 * h->maxC * sizeof(float), 256);
+    p.img_split_off = o; if (h->img_split) o += align_up((size_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c * sizeof(float), 256);
     // launch geometry per step: tile configuration and the split-K of the last partial round (shape-only)
     p.split.assign(h->steps.size(), ConvSplit{0, 0, 0, 1});
     p.tile.assign(h->steps.size(), 0);
@@ -967,7 +973,7 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     int64_t nsrc[2] = {0, 0};                 // samples held by each source tensor
     for (int k = 0; k < st.in.n; ++k) {
         const Src& s = st.in.s[k];
-        if (s.layer < 0) { srcs[k] = d_img; Hs[k] = h->cfg.img_h; Wsz[k] = h->cfg.img_w; nsrc[k] = B; }
+        if (s.layer < 0) { srcs[k] = (h->precision == 1 && !l.direct) ? reinterpret_cast<const float*>(ws + h->plan.img_split_off) : d_img; Hs[k] = h->cfg.img_h; Wsz[k] = h->cfg.img_w; nsrc[k] = B; }
         else {
             srcs[k] = reinterpret_cast<const float*>(ws + h->plan.off[s.layer]); Hs[k] = h->layers[s.layer].H; Wsz[k] = h->layers[s.layer].W;
             nsrc[k] = h->layers[s.layer].stacked ? (int64_t)B * T : B;
@@ -998,7 +1004,8 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.d_hw = make_fastdiv((uint32_t)(l.H * l.W)); p.d_wout = make_fastdiv((uint32_t)l.W);
     p.d_sdiv0 = make_fastdiv((uint32_t)sdiv[0]); p.d_sdiv1 = make_fastdiv((uint32_t)sdiv[1]);
     p.rep = st.mode == STEP_REP ? T : 1;
-    p.split = h->precision == 1 && !l.direct;
+    // matrix-pipe launches: 1 = split-f16 operands; direct launches: bit 0 = the sources are hi/lo tensors, bit 1 = so is the output
+    p.split = h->precision != 1 ? 0 : (!l.direct ? 1 : ((l.prev >= 0 ? 1 : 0) | (l.op == OP_DETECTION ? 0 : 2)));
     if (p.split && st.kx3) { p.kx3 = 1; p.KT = 3 * p.cin_tiles; }       // scheduling unit = stage (ky, chunk) = 3 K-tiles
     if (st.mode == STEP_MAIN) {
         p.addend = reinterpret_cast<const float*>(ws + h->plan.off[st.addend_tensor]);
@@ -1164,6 +1171,8 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
     const bool per_step = h->profiling >= 2;
     bool backbone_marked = false;
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
+    if (h->precision == 1 && h->img_split)
+        HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st));
     for (size_t si = 0; si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
@@ -1189,7 +1198,6 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         if (s.mode == STEP_PARTIAL) p.flags = EPI_RAW;          // raw partial sums for the STEP_MAIN launch
         if (h->precision == 1) {
             if (l.op == OP_DETECTION) p.flags |= EPI_F32OUT;    // the decode kernels read plain fp32
-            else if (l.direct) p.split = 2;                     // the stem: fp32 in, split-f16 out
         }
         // tile configuration and split-K of the last partial round: decided per (B, T) in make_plan
         const int tile = h->plan.tile[si];
@@ -1345,6 +1353,8 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
     float* d_mean = reinterpret_cast<float*>(ws + h->plan.stats_off + (size_t)1024 * 2 * h->maxC * sizeof(double));
     float* d_var = d_mean + h->maxC;
     std::vector<float> sc, sf;
+    if (h->precision == 1 && h->img_split)
+        HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st));
     for (const Step& s : h->steps) {
         Layer& l = h->layers[s.layer];
         ConvParams p; fill_conv(h, s, d_img, ws, B, 1, p);
@@ -1353,6 +1363,7 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         if (l.op == OP_DETECTION) { if (split) p.flags |= EPI_F32OUT; HIPCHK(h, launch_conv_igemm(p, s.tile, st)); continue; }
         // raw conv output (+ addend for STEP_MAIN), fp32; split precision: the accumulators, ACT_SCALE * 2^wshift * conv
         p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = split ? (s.mode == STEP_PARTIAL ? EPI_RAW : EPI_F32OUT) : 0;
+        if (split && l.direct) p.split &= 1;                               // direct launch: plain fp32 output here
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, s.tile, st));
         if (s.mode == STEP_PARTIAL) continue;                              // half of a split conv: statistics at STEP_MAIN
         const int N = l.filters;
@@ -1360,8 +1371,8 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         HIPCHK(h, hipMemcpyAsync(h->params[l.p_mean].data.data(), d_mean, sizeof(float) * N, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipMemcpyAsync(h->params[l.p_var].data.data(), d_var, sizeof(float) * N, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
-        if (split && !l.direct) {                                          // statistics of the accumulators -> of the convolution
-            const float f = 1.f / (ACT_SCALE * ldexpf(1.f, l.wshift));
+        if (split) {                                                       // statistics of the accumulators -> of the convolution
+            const float f = 1.f / (l.in_scale * (l.direct ? 1.f : ldexpf(1.f, l.wshift)));
             for (int c = 0; c < N; ++c) { h->params[l.p_mean].data[c] *= f; h->params[l.p_var].data[c] *= f * f; }
         }
         fold_layer(h, l, sc, sf);

@@ -68,7 +68,8 @@ struct ConvParams {
     int M, N, Npad, ldc;
     int KT, cin_tiles;                // K/32, (C0+C1)/32
     int flags;                        // EPI_*
-    int split;                        // 1: split-f16 sources / weights / residual / output (mfma_pipe.h), 0: fp32; 2 (stem): fp32 in, split-f16 out
+    int split;                        // matrix-pipe launch: 1 = split-f16 sources / weights / residual / output (mfma_pipe.h), 0 = fp32;
+                                      // direct launch: bit 0 = sources and residual are hi/lo tensors, bit 1 = the output is
     int kx3;                          // split 3x3 / stride-1 launch on shared-tap stages (conv_tile_kx3): weights packed in (ky, chunk, kx) order, KT counts stages
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
     uint64_t idx_base;                // dropout element index of dst[0] (sub-batch / shard of a logical batch)
@@ -158,6 +159,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st);
 // a route / upsample / stack view copied into a dense [M][C0 + C1] tensor (sources, extents and dst as in ConvParams)
 hipError_t launch_view_gather(const ConvParams& p, hipStream_t st);
 hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, bool split, hipStream_t st);   // dst = a + b (split: all three in [4 hi | 4 lo] groups)
+hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mul, hipStream_t st);   // hi/lo pairs of mul * src
 hipError_t launch_split_to_f32(const float* src, float* dst, int64_t n, float mul, hipStream_t st);   // dst[i] = mul * (hi + lo) of a split-f16 tensor
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st);   // small-cin (stem) direct conv
 

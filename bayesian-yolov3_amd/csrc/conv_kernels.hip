@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
             const float y = acc[n + q] * p.scale[n + q] + p.shift[n + q];
             v[q] = fmaxf(y, slope * y);
         }
-        *reinterpret_cast<f32x4*>(d + n) = p.split == 2 ? epi::split_encode4(v) : v;     // split precision: [4 hi | 4 lo]
+        *reinterpret_cast<f32x4*>(d + n) = (p.split & 2) ? epi::split_encode4(v) : v;    // split precision: [4 hi | 4 lo]
     }
 }
 
@@ -67,6 +67,13 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
 // weights (HWIO, k*k*Cin x cout) are broadcast from LDS when they fit in 48 KB, read through the caches otherwise.
 // Correct, not fast: Darknet-53 / YOLOv3 never come here except for the stem.
 // ---------------------------------------------------------------------------------------------
+// element c of a pixel's channel run starting at px: plain fp32, or hi + lo of a split-f16 tensor ([4 hi | 4 lo] per 4 channels)
+__device__ __forceinline__ float act_at(const float* px, int c, bool split) {
+    if (!split) return px[c];
+    const _Float16* g = reinterpret_cast<const _Float16*>(px + (c & ~3));
+    return (float)g[c & 3] + (float)g[4 + (c & 3)];
+}
+
 __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, const int w_in_lds) {
     extern __shared__ __attribute__((aligned(16))) float wl[];    // [K][N] if w_in_lds
     const int Cin = p.C0 + p.C1, K = p.ksize * p.ksize * Cin, N = p.N;
@@ -78,6 +85,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, co
     const int groups = (N + 7) >> 3;
     const int64_t total = (int64_t)p.M * groups;
     const int hw = p.Hout * p.Wout;
+    const bool in_split = p.split & 1, out_split = p.split & 2;      // split precision (N % 4 == 0 when out_split)
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
          gid += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(gid / groups), g = (int)(gid - (int64_t)m * groups);
@@ -96,19 +104,20 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, co
                 // source 0 then source 1 (channel concat, layers.py:588); each at its own resolution / sample divisor
                 const float* px = p.src0 + (((size_t)(s / p.sdiv0) * p.Hs0 + (iy >> p.sh0)) * p.Ws0 + (ix >> p.sh0)) * p.C0;
                 for (int c = 0; c < p.C0; ++c, w += N) {
-                    const float x = px[c];
+                    const float x = act_at(px, c, in_split);
                     for (int o = 0; o < nv; ++o) acc[o] = fmaf(x, w[o], acc[o]);
                 }
                 if (p.C1) {
                     px = p.src1 + (((size_t)(s / p.sdiv1) * p.Hs1 + (iy >> p.sh1)) * p.Ws1 + (ix >> p.sh1)) * p.C1;
                     for (int c = 0; c < p.C1; ++c, w += N) {
-                        const float x = px[c];
+                        const float x = act_at(px, c, in_split);
                         for (int o = 0; o < nv; ++o) acc[o] = fmaf(x, w[o], acc[o]);
                     }
                 }
             }
         }
         float* d = p.dst + (size_t)m * p.ldc + g * 8;
+        float res[8];
         for (int o = 0; o < nv; ++o) {
             const int n = g * 8 + o;
             float v = acc[o] * p.scale[n];                     // scale includes 1 / (1 - p) when the masks are on
@@ -117,19 +126,26 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, co
             }
             v += p.shift[n];
             if (p.flags & EPI_LEAKY) v = fmaxf(v, 0.1f * v);
-            if (p.flags & EPI_RESIDUAL) v += p.residual[(size_t)m * p.ldc + n];
-            d[o] = v;
+            if (p.flags & EPI_RESIDUAL) v += act_at(p.residual + (size_t)m * p.ldc, n, in_split);
+            res[o] = v;
+        }
+        if (out_split) {
+            for (int o = 0; o < nv; o += 4)
+                *reinterpret_cast<f32x4*>(d + o) = epi::split_encode4(f32x4{res[o], res[o + 1], res[o + 2], res[o + 3]});
+        } else {
+            for (int o = 0; o < nv; ++o) d[o] = res[o];
         }
     }
 }
 
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st) {
-    if (p.ksize == 3 && p.C0 == 3 && p.C1 == 0 && p.sh0 == 0 && p.N == 32 && (p.flags & ~EPI_LEAKY) == 0 &&
+    if (p.ksize == 3 && p.C0 == 3 && p.C1 == 0 && p.sh0 == 0 && p.N == 32 && (p.flags & ~EPI_LEAKY) == 0 && !(p.split & 1) &&
         (p.ldc & 3) == 0 && p.rep == 1 && !p.addend) {
         hipLaunchKernelGGL(conv_stem3x3_kernel<32>, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st, p);
         return hipGetLastError();
     }
-    if (p.rep != 1 || p.addend || p.split) return hipErrorInvalidValue;   // the de-duplicated forms are implicit-GEMM only; fp32 only
+    if (p.rep != 1 || p.addend) return hipErrorInvalidValue;              // the de-duplicated forms are implicit-GEMM only
+    if ((p.split & 2) && (p.N & 3)) return hipErrorInvalidValue;
     const size_t wbytes = (size_t)p.ksize * p.ksize * (p.C0 + p.C1) * p.N * sizeof(float);
     const int w_in_lds = wbytes <= 48 * 1024;
     const int64_t total = (int64_t)p.M * ((p.N + 7) >> 3);
@@ -166,6 +182,10 @@ __global__ __launch_bounds__(256) void tensor_add_split_kernel(const f32x4* a, c
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
         d[i] = epi::split_encode4(epi::split_decode4(a[i]) + epi::split_decode4(b[i]));
 }
+__global__ __launch_bounds__(256) void f32_to_split_kernel(const f32x4* s, f32x4* d, int64_t n4, float mul) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = epi::split_encode4(s[i] * mul);
+}
 __global__ __launch_bounds__(256) void split_to_f32_kernel(const f32x4* s, f32x4* d, int64_t n4, float mul) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
         d[i] = epi::split_decode4(s[i]) * mul;
@@ -181,6 +201,12 @@ hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t
         hipLaunchKernelGGL(tensor_add_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(a),
                            reinterpret_cast<const f32x4*>(b), reinterpret_cast<f32x4*>(dst), n / 4);
     } else hipLaunchKernelGGL(tensor_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, b, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mul, hipStream_t st) {
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(f32_to_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), n / 4, mul);
     return hipGetLastError();
 }
 hipError_t launch_split_to_f32(const float* src, float* dst, int64_t n, float mul, hipStream_t st) {

@@ -16,6 +16,14 @@ pytestmark = pytest.mark.gpu
 BN, DROP = 1, 2
 
 
+@pytest.fixture(autouse=True, params=["split", "f32"])
+def precision(request, monkeypatch):
+    """Both arithmetic modes of the convolution stack (include/byolo.h: BYOLO_PREC_SPLIT_F16, the default, and
+    BYOLO_PREC_F32); tests of fp32-only machinery skip the other one."""
+    monkeypatch.setenv("BYOLO_PRECISION", request.param)
+    return request.param
+
+
 def _ref_conv(x, p, scope, k, stride, flags, drop=None):
     """x NHWC torch fp32 -> conv (HWIO kernel) -> [dropout] -> [BN, leaky 0.1];  lib_yolo/layers.py:533-575"""
     import torch
@@ -60,9 +68,11 @@ def _random_params(eng, seed):
 @pytest.mark.parametrize("wino", ["0", "2", "2f"])       # direct / Winograd F(2x2,3x3) on every eligible 3x3 (layer d) / fused kernel
 @pytest.mark.parametrize("ksplit", ["-1", "3"])          # planner's choice / K slices forced on every launch
 @pytest.mark.parametrize("H,W,B", [(64, 64, 1), (32, 96, 3)])
-def test_custom_graph_layer_by_layer(H, W, B, ksplit, wino, monkeypatch):
+def test_custom_graph_layer_by_layer(H, W, B, ksplit, wino, monkeypatch, precision):
     import torch
     from byolo import Engine
+    if precision != "f32" and wino != "0":
+        pytest.skip("Winograd exists in the fp32 mode only")
     monkeypatch.setenv("BYOLO_KSPLIT", ksplit)
     monkeypatch.setenv("BYOLO_WINOGRAD", wino[0])
     monkeypatch.setenv("BYOLO_WINO_FUSED", "2" if wino.endswith("f") else "0")

@@ -142,6 +142,7 @@ int main() {
     }
     // ---- rate ----
     const int iters = 4000;
+    run<1, 0, 0>(1, iters); run<2, 0, 0>(1, iters); run<1, 0, 0>(2, iters); run<2, 0, 0>(2, iters);
     run<4, 0, 0>(1, iters); run<4, 0, 0>(2, iters); run<8, 0, 0>(1, iters);
     printf("-- VALU instructions in the shadow of the MFMAs\n");
     run<4, 1, 0>(1, iters); run<4, 2, 0>(1, iters); run<4, 4, 0>(1, iters); run<4, 6, 0>(1, iters); run<4, 8, 0>(1, iters);
