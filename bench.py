@@ -10,8 +10,11 @@ Darknet-53 once per image, the three heads on B*T MC samples (dropout masks from
 per-box T-reduction + decode, sort + NMS, and (N > 1) ONE RCCL all-gather of the padded box lists.
 Weights are random-init with BN statistics calibrated on the device (no checkpoints, no network).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel = the fp32-MFMA kernel with the most
-device time in the timed region (the fused Winograd-domain GEMM at this config; `by_kernel` lists all of them), its
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel = the matrix-pipe kernel with the most
+device time in the timed region (`by_kernel` lists all of them): in the default precision (split-f16: every operand as
+hi + lo fp16 pairs, three fp16 matrix products per fp32 product, fp32 accumulation -- DESIGN.md section 5) the
+shared-tap 3x3 kernel conv_igemm_kernel<128,128,1,4,kx3>, priced against the fp16 matrix peak / 3; under
+BYOLO_PRECISION=f32 the fused Winograd-domain GEMM, priced against the fp32 matrix peak.  Its
 launches timed with hipEvents recorded around every launch on the launch stream (byolo_step_profile; the records of
 all K steps are read AFTER the timed region -- no host synchronisation inside it).  One definition:
 
@@ -49,6 +52,11 @@ CONFIGS = {   # BASELINE.json configs[1..4]  (per-GPU batch)
     6: dict(variant="bayesian_yolov3_aleatoric", H=1024, W=1920, B=1, T=50, nms=1),
 }
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA = 2500e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
+# split-f16 precision: three fp16 matrix products per fp32 product, so the matrix-pipe ceiling of a split kernel in
+# fp32-equivalent FLOP/s is PEAK_F16_MFMA / 3; under the 1300 W socket cap an MFMA-only loop on random operands sustains
+# 1756 TFLOP/s fp16 (tools/mfma_f16_power_probe.hip, profiles/r2_probes.md) -- reported beside the nominal peak
+SUSTAINED_F16_MFMA = 1756e12
 
 
 def build(cfg, device):
@@ -231,16 +239,21 @@ def main():
             "metric": "img/s at T=%d MC-dropout, %dx%d" % (T, cfg["H"], cfg["W"]),
             "value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" [EXPERIMENT: dropout off, invalid]" if args.no_dropout else ""),
+            "vs_baseline": None, "dtype": "f32" if eng.precision == "f32" else "f32 via split-f16 (hi+lo fp16 pairs, 3 fp16 MFMA products, fp32 accumulate)", "data": "synthetic" + (" [EXPERIMENT: dropout off, invalid]" if args.no_dropout else ""),
             "config": {"workload": "%s: %s %dx%d T=%d, %d images/GPU (global batch %d), "
                                    "class-%s NMS max_out=1000, random-init weights with device-calibrated BN"
                                    % ("BASELINE configs[%d]" % (args.config - 1) if args.config <= 5 else "reference default frame",
                                       cfg["variant"], cfg["H"], cfg["W"], T, B, B * world,
                                       "wise 2-class" if cfg["nms"] else "agnostic"),
                        "images_per_gpu": B, "T": T, "img_size": [cfg["H"], cfg["W"]], "parallelism": "dp%d" % world,
-                       "gflop_per_image": flops_img / 1e9},
+                       "gflop_per_image": flops_img / 1e9, "precision": eng.precision},
         }
-        KERNELS = {130: "wino_fused_kernel (Winograd-domain GEMM + output transform + epilogue, fp32 v_mfma_f32_32x32x2_f32)",
+        SPLIT = (3128, 3064, 1128, 1064, 1032)
+        KERNELS = {3128: "conv_igemm_kernel<128,128,1,4,kx3> (split-f16 3x3/stride-1 on shared-tap stages, v_mfma_f32_32x32x16_f16 x3)",
+                   3064: "conv_igemm_kernel<128,64,2,2,kx3> (split-f16 3x3/stride-1 on shared-tap stages)",
+                   1128: "conv_igemm_kernel<128,128,1,4,split> (split-f16 1x1 / stride-2 / two-source convolutions)",
+                   1064: "conv_igemm_kernel<128,64,2,2,split>", 1032: "conv_igemm_kernel<128,32,4,1,split>",
+                   130: "wino_fused_kernel (Winograd-domain GEMM + output transform + epilogue, fp32 v_mfma_f32_32x32x2_f32)",
                    129: "gemm_stream_kernel<128,0> (Winograd-domain GEMM, fp32 v_mfma_f32_32x32x2_f32)",
                    131: "gemm_stream_kernel<128,1> (row-streaming 1x1 convolution)",
                    132: "gemm_stream_kernel<64,*> (row-streaming 1x1 convolution / detection head, 64-wide tile)",
@@ -256,6 +269,8 @@ def main():
             f, ms, n, fx, fu, ab = acc[dom]
             tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for a in acc.values())
             ach = fu / (ms * 1e-3)
+            split = dom in SPLIT
+            peak = PEAK_F16_MFMA / 3.0 if split else PEAK_FP32_MFMA
             wino_ms = sum(acc[v][1] for v in (-2, -3) if v in acc)
             # HBM/fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
             # over this same command (tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent
@@ -266,16 +281,17 @@ def main():
                 if tj.get("kernel", "").split("<")[0].strip() in KERNELS[dom]:
                     traffic = tj.get("traffic_bytes_per_launch")
                     measured_at = tj.get("measured_at")
-            line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                                "frac": ach / PEAK_FP32_MFMA, "traffic": traffic, "traffic_measured_at": measured_at,
+            line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                                "frac": ach / peak, "traffic": traffic, "traffic_measured_at": measured_at,
                                 "algorithmic_bytes_per_launch": ab / n,
                                 "traffic_vs_algorithmic": (traffic / (ab / n)) if traffic else None,
                                 "kernel": KERNELS[dom],
                                 "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
-                                "definition": "achieved = useful FLOPs (direct: 2MNK; Winograd-domain GEMM: direct-convolution "
-                                              "FLOPs of its samples / 2.25, tile padding not counted) / hipEvent time of the launches",
+                                "definition": "achieved = useful fp32-equivalent FLOPs (direct: 2MNK; Winograd-domain GEMM: direct-convolution "
+                                              "FLOPs of its samples / 2.25, tile padding not counted) / hipEvent time of the launches; peak = "
+                                              + ("fp16 MFMA dense peak 2500 / 3 (three fp16 products per fp32 product)" if split else "fp32 MFMA dense peak"),
                                 "achieved_executed_padded": fx / (ms * 1e-3) / 1e12,
-                                "frac_executed_padded": fx / (ms * 1e-3) / PEAK_FP32_MFMA,
+                                "frac_executed_padded": fx / (ms * 1e-3) / peak,
                                 # the same launches priced by the direct-convolution FLOPs they stand for (SURVEY 8d's
                                 # per-image figure is made of these): not a matrix-pipe utilisation where Winograd runs
                                 "achieved_algorithmic": f / (ms * 1e-3) / 1e12,
@@ -287,7 +303,12 @@ def main():
                                                                           "useful_tflops": acc[v][4] / (acc[v][1] * 1e-3) / 1e12,
                                                                           "executed_tflops": acc[v][3] / (acc[v][1] * 1e-3) / 1e12}
                                               for v in sorted(mm, key=lambda v: -acc[v][1])},
-                                "end_to_end_frac": (imgs / dt) * flops_img / (world * PEAK_FP32_MFMA)}
+                                "end_to_end_frac": (imgs / dt) * flops_img / (world * peak),
+                                "end_to_end_vs_fp32_mfma_peak": (imgs / dt) * flops_img / (world * PEAK_FP32_MFMA)}
+            if split:
+                line["roofline"].update({"fp16_executed_tflops": 3.0 * fx / (ms * 1e-3) / 1e12, "fp16_peak_tflops": PEAK_F16_MFMA / 1e12,
+                                         "fp16_sustained_under_power_cap_tflops": SUSTAINED_F16_MFMA / 1e12,
+                                         "frac_of_sustained": 3.0 * fu / (ms * 1e-3) / SUSTAINED_F16_MFMA})
             line["stage_ms_per_step"] = {k: v / args.steps for k, v in stage.items()}
         if world == 1 and not args.no_cpu_baseline:
             try:

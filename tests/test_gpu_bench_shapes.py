@@ -3,7 +3,8 @@ bench.py builds them (`bench.build`: same weights, same device BN calibration, d
 on the benchmark's own batch, and
 
   * the launch list of that step (byolo_step_profile / byolo_step_split) must contain the kernels the benchmark's
-    number is about -- at config 4 the fused Winograd kernel (variant 130) in chunks, and split-K launches;
+    number is about -- at config 4 the shared-tap split-f16 kernel (variants 3128 / 3064) on the nine big head
+    convolutions (default precision), or the fused Winograd kernel (variant 130) in chunks under BYOLO_PRECISION=f32;
   * whole images of the batch, INCLUDING THE LAST ONE (its dropout masks sit at sample offset (B-1)*T of the logical
     batch, its rows in the last Winograd chunk), are compared with the CPU restatement per column group at the
     literal bound 1e-4 * max(1, |ref|) (conftest.assert_rows_close);
@@ -67,11 +68,22 @@ def _compare(cfg, eng, imgs, out, which, seed, what):
     _check_nms_against_oracle(boxes, out, cfg["variant"], two_class=bool(cfg["nms"]))     # every image of the batch
 
 
-def test_config4_as_benched():
-    """BASELINE configs[3] = the benchmark's workload: 608x608, T=30, 8 images, default plan."""
+@pytest.mark.parametrize("precision", ["split", "f32"])
+def test_config4_as_benched(precision, monkeypatch):
+    """BASELINE configs[3] = the benchmark's workload: 608x608, T=30, 8 images, default plan -- in the default
+    precision (split-f16) and in the fp32 mode."""
+    monkeypatch.setenv("BYOLO_PRECISION", precision)
     cfg, eng, imgs, out, launches = _step(4)
+    assert eng.precision == precision
     v = _variants(launches)
-    print("config 4 launch variants:", v)
+    print("config 4 (%s) launch variants:" % precision, v)
+    if precision == "split":
+        kx = [s for s in launches if s["variant"] in (3128, 3064)]
+        big = [s for s in kx if s["flops"] > 5e11 and s["variant"] == 3128]     # 817.6 GFLOP each
+        assert len(big) == 9 and {s["K"] for s in big} == {1152, 2304, 4608}, "the nine big head 3x3 convolutions run on the shared-tap kernel: %s" % v
+        assert not any(s["variant"] in (128, 64, 32, 129, 130, 131, 132, -2, -3) for s in launches), "an fp32-mode kernel ran: %s" % v
+        _compare(cfg, eng, imgs, out, (0, cfg["B"] - 1), 1000, "config 4 (608x608 T=30 B=8, split-f16)")
+        return
     fused = [s for s in launches if s["variant"] == 130]
     assert len(fused) >= 18, "the fused Winograd kernel must carry the nine big head convolutions in chunks: %s" % v
     assert {s["K"] for s in fused} == {128, 256, 512}                 # 76x76, 38x38, 19x19 layers
@@ -128,5 +140,5 @@ def test_config5_as_benched():
     cfg, eng, imgs, out, launches = _step(5)
     print("config 5 launch variants:", _variants(launches))
     assert out["boxes"].shape == (1, 64512, 23)
-    assert any(s["variant"] == 130 for s in launches)
+    assert any(s["variant"] == 3128 for s in launches)
     _compare(cfg, eng, imgs, out, (0,), 1000, "config 5 (1024x1024 T=50 2-class)")
