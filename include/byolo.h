@@ -65,7 +65,7 @@ BYOLO_API int32_t byolo_destroy(byolo_t* h);
  *                         for the large 3x3 convolutions;
  *   BYOLO_PREC_SPLIT_F16  every activation / weight as hi + lo, two fp16 values (~23 significant bits), three fp16
  *                         matrix products per fp32 product into fp32 accumulators (v_mfma_f32_32x32x16_f16); an
- *                         activation beyond +-4094 overflows (fp16 range / 16).
+ *                         activation beyond +-16376 overflows (fp16 range / 4).
  * Default: environment BYOLO_PRECISION = f32 | split, else BYOLO_PREC_SPLIT_F16.  Call before byolo_finalize (a finalized
  * handle must be finalized again). */
 enum { BYOLO_PREC_F32 = 0, BYOLO_PREC_SPLIT_F16 = 1 };
