@@ -43,7 +43,8 @@ def one_case(rng, idx, a):
            "BYOLO_KSPLIT": str(rng.choice(["", "", "0", "2", "3", "5"])),
            "BYOLO_WINO_CHUNK_MB": str(rng.choice(["", "", "1", "8", "64"])),       # small budgets: many chunks per layer
            "BYOLO_STREAMK": str(rng.choice(["", "", "0", "2"])),                   # stream-K never / on every launch
-           "BYOLO_STREAM1X1": str(rng.choice(["", "", "0", "2"]))}                 # row-streaming 1x1 kernel never / wherever expressible
+           "BYOLO_STREAM1X1": str(rng.choice(["", "", "0", "2"])),                 # row-streaming 1x1 kernel never / wherever expressible
+           "BYOLO_PRECISION": str(rng.choice(["", "", "f32"]))}                    # default (split-f16) twice as often as the fp32 mode
     for k, v in env.items():
         if v:
             os.environ[k] = v
