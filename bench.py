@@ -225,7 +225,9 @@ def main():
                 a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1; a[3] += s["flops_executed"]
                 a[4] += s["flops"] / 2.25 if wino else s["flops"]
                 # algorithmic bytes of the launch: A operand once + result once + weights once
+                # (a shared-tap 3x3 launch reads its input once: M * K / 9 elements, not the im2col matrix)
                 a[5] += 4.0 * ((s["M"] * s["K"] + (s["M"] // 4) * s["N"] + 16 * s["K"] * s["N"]) if s["variant"] == 130 else
+                               (s["M"] * s["K"] // 9 + s["M"] * s["N"] + s["K"] * s["N"]) if s["variant"] in (3128, 3064) else
                                (s["M"] * s["K"] + s["M"] * s["N"] + (16 if wino else 1) * s["K"] * s["N"]))
                 if args.dump_steps:
                     per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / args.steps
@@ -278,7 +280,10 @@ def main():
             tpath = os.path.join(REPO, "profiles", "traffic_cfg%d.json" % args.config)
             if os.path.exists(tpath) and not args.batch and args.scaling == "weak":
                 tj = json.load(open(tpath))
-                if tj.get("kernel", "").split("<")[0].strip() in KERNELS[dom]:
+                # the counter passes must be of THIS kernel (template arguments as rocprofv3 prints them)
+                want = {3128: "conv_igemm_kernel<128, 128, 1, 4, true, true, true>", 3064: "conv_igemm_kernel<128, 64, 2, 2, true, true, true>",
+                        130: "wino_fused_kernel", 129: "gemm_stream_kernel", 128: "conv_igemm_kernel<128, 128, 2, 2"}.get(dom)
+                if want and tj.get("kernel", "").startswith(want.split(",")[0]) and (want in tj.get("kernel", "") or tj.get("kernel", "") in want):
                     traffic = tj.get("traffic_bytes_per_launch")
                     measured_at = tj.get("measured_at")
             line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
