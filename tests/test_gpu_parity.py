@@ -60,15 +60,31 @@ def _run(variant, B, T=3, seed=42, keep_all=True, dropout_on=True, H=64, W=96, i
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_forward_vs_golden(variant):
+def test_forward_vs_golden(variant, precision):
     """Full forward at 64x96 against the fixtures produced by the reference's own graph code
     (shim-executed): backbone taps, raw detection outputs, pre-NMS rows."""
     B = 1 if variant.startswith("bayes") else 2
     m, out, params, imgs = _run(variant, B)
     g = golden("fwd_%s.npz" % variant)
+    # Backbone taps.  The fixtures are float32 (the oracle's float32 run reproduces them bit for bit), and the deep taps of
+    # this 64x96 network are ill-conditioned: the float32 fixture of layer 74 is itself 0.7 - 0.8 of the bound away from
+    # the float64 run.  Every mode must be within the bound of the FLOAT64 oracle; the fp32 mode (same operand roundings
+    # as the fixture) is also held to the fixture, the split-f16 mode is reported against it (measured: 0.52 from float64,
+    # closer than the fixture; 0.97 - 1.08 from the fixture).
+    import torch
+    from oracle import cpu_ref
+    with torch.no_grad():
+        f64 = cpu_ref.forward(cpu_ref.to_torch_params(params, torch.float64), imgs, variant, T=3, seed=42, dtype=torch.float64, taps=TAPS)
     for i in TAPS:
-        got = m.engine.layer_output(i).cpu().numpy()
-        assert_close(_sub(i, got), g["layer_%d" % i], "%s layer %d" % (variant, i))
+        got = _sub(i, m.engine.layer_output(i).cpu().numpy())
+        ref64 = _sub(i, f64["layers"][i].numpy())
+        e64 = assert_close(got, ref64, "%s layer %d vs the float64 oracle" % (variant, i))
+        if precision == "f32":
+            assert_close(got, g["layer_%d" % i], "%s layer %d" % (variant, i))
+        else:
+            fix = g["layer_%d" % i].astype(np.float64)
+            print("%s layer %d: |err| vs float64 %.2e; vs the float32 fixture %.2e (the fixture vs float64: %.2e)"
+                  % (variant, i, e64, np.abs(got - fix).max(), np.abs(fix - ref64).max()))
     for k, dl in enumerate(m.det_layers):
         assert_close(dl.raw_output.cpu().numpy(), g["raw_%d" % k], "%s raw det output %d" % (variant, k))
     boxes = out["boxes"].cpu().numpy()
