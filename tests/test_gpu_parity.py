@@ -9,7 +9,8 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import (REPO, RTOL, ATOL, golden, golden_params, golden_images, build_model, assert_close)
+from conftest import (REPO, RTOL, ATOL, golden, golden_params, golden_images, build_model, assert_close,
+                      assert_rows_close_vs_oracle)
 
 pytestmark = pytest.mark.gpu
 
@@ -542,11 +543,9 @@ def test_reference_default_frame_vs_cpu_restatement():
     torch.cuda.synchronize()
     assert out["boxes"].shape == (1, 3 * (32 * 60 + 64 * 120 + 128 * 240), 23)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    with torch.no_grad():
-        ref, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(eng.get_params()), imgs, v, T=T, seed=42)
     boxes = out["boxes"].cpu().numpy()
-    err = assert_close(boxes, ref.numpy(), "1024x1920 T=2 pre-NMS rows")
-    print("1024x1920 T=2: max |err| = %.3e over %d values" % (err, boxes.size))
+    # T = 2: the epistemic columns are variances of TWO samples -- the float64 oracle is the reference, the float32 one the yardstick
+    assert_rows_close_vs_oracle(boxes, eng.get_params(), imgs, v, "1024x1920 T=2 pre-NMS rows", T=T, seed=42)
     _check_nms_against_oracle(boxes, out, v, two_class=True)
 
 
