@@ -401,7 +401,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         if constexpr (!SPLIT) bt.template store_b<BUF>(b_reg);
     };
 
-    const int wm = bt.wm, wn = bt.wn, li = bt.li, lh = bt.lh;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -486,7 +485,6 @@ __device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, 
     using BT = SplitTileKx<BM, BN, WM, WN>;
     constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD, A_LDX = BT::A_LDX, ROWB = BT::ROWB;
     const BT bt(smem);
-    const int tid = bt.tid;
     const uint32_t n_tiles = (uint32_t)p.Npad / BN;
     const uint32_t tile_m = fdiv((uint32_t)logical, p.d_ntiles), tile_n = (uint32_t)logical - tile_m * n_tiles;
     const uint32_t hw = (uint32_t)(p.Hout * p.Wout), W = (uint32_t)p.Wout;
