@@ -837,6 +837,12 @@ static void make_plan(byolo_t* h, int B, int T) {
         // depend on BN when N % 128 == 0).
         int tile = s.tile;
         if (tile == TILE_128x128 && (l.filters % 128) == 0 && (int64_t)((M + 127) / 128) * (l.filters / 128) < 512) tile = TILE_128x64;
+        // split precision: a 1x1 convolution with few channels on both sides is bound by HBM latency, not by the matrix pipe
+        // (76x76 head layers: 2.1 GB for 91 GFLOP); the 64-wide tile doubles the workgroups in flight per byte streamed
+        // (measured at config 4: K = 128 / 256 with N = 128: 0.83 -> 0.56, 0.77 -> 0.67 ms; K >= 512: slower; step -0.5 ms)
+        if (h->precision == 1 && l.ksize == 1 && l.stride == 1 && tile == TILE_128x128 && (l.filters % 128) == 0 &&
+            (double)(s.c_hi - s.c_lo) * l.filters / ((s.c_hi - s.c_lo) + l.filters) < 130.0)
+            tile = TILE_128x64;
         p.tile[si] = tile;
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
         const bool sp = h->precision == 1, kx3 = sp && s.kx3;
