@@ -837,12 +837,10 @@ static void make_plan(byolo_t* h, int B, int T) {
         // depend on BN when N % 128 == 0).
         int tile = s.tile;
         if (tile == TILE_128x128 && (l.filters % 128) == 0 && (int64_t)((M + 127) / 128) * (l.filters / 128) < 512) tile = TILE_128x64;
-        // split precision: a 1x1 convolution with few channels on both sides is bound by HBM latency, not by the matrix pipe
-        // (76x76 head layers: 2.1 GB for 91 GFLOP); the 64-wide tile doubles the workgroups in flight per byte streamed
-        // (measured at config 4: K = 128 / 256 with N = 128: 0.83 -> 0.56, 0.77 -> 0.67 ms; K >= 512: slower; step -0.5 ms)
-        if (h->precision == 1 && l.ksize == 1 && l.stride == 1 && tile == TILE_128x128 && (l.filters % 128) == 0 &&
-            (double)(s.c_hi - s.c_lo) * l.filters / ((s.c_hi - s.c_lo) + l.filters) < 130.0)
-            tile = TILE_128x64;
+        // split precision: only the shared-tap 3x3 kernel has a 128-wide tile (the plain kernel would need scratch memory there);
+        // the 1x1 / stride-2 / concat convolutions run on the 64-wide tile, which also keeps twice the workgroups in flight per
+        // byte streamed for the HBM-latency-bound 76x76 head layers (measured at config 4: 0.83 -> 0.56, 0.77 -> 0.67 ms)
+        if (h->precision == 1) tile = conv_split_tile(tile, s.kx3);
         p.tile[si] = tile;
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
         const bool sp = h->precision == 1, kx3 = sp && s.kx3;
@@ -1367,11 +1365,12 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         ConvParams p; fill_conv(h, s, d_img, ws, B, 1, p);
         if (!s.is_conv()) { int32_t rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
         const bool split = h->precision == 1;
-        if (l.op == OP_DETECTION) { if (split) p.flags |= EPI_F32OUT; HIPCHK(h, launch_conv_igemm(p, s.tile, st)); continue; }
+        const int ctile = split ? conv_split_tile(s.tile, s.kx3) : s.tile;
+        if (l.op == OP_DETECTION) { if (split) p.flags |= EPI_F32OUT; HIPCHK(h, launch_conv_igemm(p, ctile, st)); continue; }
         // raw conv output (+ addend for STEP_MAIN), fp32; split precision: the accumulators, ACT_SCALE * 2^wshift * conv
         p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = split ? (s.mode == STEP_PARTIAL ? EPI_RAW : EPI_F32OUT) : 0;
         if (split && l.direct) p.split &= 1;                               // direct launch: plain fp32 output here
-        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, s.tile, st));
+        HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, ctile, st));
         if (s.mode == STEP_PARTIAL) continue;                              // half of a split conv: statistics at STEP_MAIN
         const int N = l.filters;
         HIPCHK(h, launch_channel_stats(p.dst, p.M, N, d_mean, d_var, d_tmp, st));

@@ -155,6 +155,7 @@ size_t conv_split_slab_bytes(const ConvSplit& sp, int tile);
 enum : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };
 int conv_tile_bn(int tile);           // BN of a tile config
 int conv_pick_tile(int N);            // tile config for cout = N
+int conv_split_tile(int tile, bool kx3);   // split precision: 128-wide tiles exist for the shared-tap 3x3 kernel only
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st);
 // a route / upsample / stack view copied into a dense [M][C0 + C1] tensor (sources, extents and dst as in ConvParams)
 hipError_t launch_view_gather(const ConvParams& p, hipStream_t st);

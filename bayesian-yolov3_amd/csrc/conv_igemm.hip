@@ -374,9 +374,14 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         }
     };
 
-    f32x4 a_reg[A_LD], b_reg[B_LD];              // staging registers, one K-tile (SPLIT: b_reg unused)
+    // DEEP (split launches on the 64- and 32-wide tiles: the HBM-latency-bound 1x1 convolutions and detection heads, which
+    // have the registers for it): the activations of tile t+3 are fetched while tile t multiplies -- two staging sets, a
+    // tile's loads have two K-tiles to arrive instead of one.
+    constexpr bool DEEP = SPLIT && BN <= 64;
+    f32x4 a_regs[DEEP ? 2 : 1][A_LD], b_reg[B_LD];     // staging registers (SPLIT: b_reg unused)
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wpk, p.w_bytes);
-    auto issue_loads = [&]() {                   // the buffer_load_dwordx4s of the tile set up by next_tile()
+    auto issue_loads_to = [&](auto set_tag) {    // the buffer_load_dwordx4s of the tile set up by next_tile()
+        f32x4 (&a_reg)[A_LD] = a_regs[DEEP ? decltype(set_tag)::value : 0];
         const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_bytes);
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) a_reg[j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
@@ -386,8 +391,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
             w_soff += w_step;
         }
     };
-    auto store_tile = [&](auto buf_tag) {        // the staged K-tile -> LDS buffer BUF
+    auto issue_loads = [&]() { issue_loads_to(std::integral_constant<int, 0>{}); };
+    auto store_tile_from = [&](auto buf_tag, auto set_tag) {        // a staged K-tile -> LDS buffer BUF
         constexpr int BUF = decltype(buf_tag)::value;
+        f32x4 (&a_reg)[A_LD] = a_regs[DEEP ? decltype(set_tag)::value : 0];
         if constexpr ((ABL & 2) != 0) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) asm volatile("" : : "v"(a_reg[j]));
@@ -400,7 +407,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         bt.template store_a<BUF>(a_reg);
         if constexpr (!SPLIT) bt.template store_b<BUF>(b_reg);
     };
-
+    auto store_tile = [&](auto buf_tag) { store_tile_from(buf_tag, std::integral_constant<int, 0>{}); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -428,11 +435,23 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     issue_loads();
     issue_b(std::integral_constant<int, 0>{});
     store_tile(std::integral_constant<int, 0>{});
-    if (KT > 1) { next_tile(); issue_loads(); }   // tile 1 waits in the staging registers
+    if constexpr (DEEP) {                         // tiles 1 and 2 wait in the two staging sets (past the end of K: zeros or unused bytes)
+        next_tile(); issue_loads_to(std::integral_constant<int, 1>{});
+        next_tile(); issue_loads_to(std::integral_constant<int, 0>{});
+    } else if (KT > 1) { next_tile(); issue_loads(); }   // tile 1 waits in the staging registers
     __syncthreads();
     // tile t lives in LDS buffer BUF = t & 1.  HN: tile t+1 exists (stage it);  LD: tile t+2 exists (fetch it)
     auto run_tiles = [&](auto&& tile_body) {
         int kt = 0;
+        if constexpr (DEEP) {                             // every tile with a successor stages t+1 and fetches t+3
+            for (; kt + 2 < KT; kt += 2) {
+                next_tile(); tile_body(c0{}, yes{}, yes{});
+                next_tile(); tile_body(c1{}, yes{}, yes{});
+            }
+            if (kt + 1 < KT) { next_tile(); tile_body(c0{}, yes{}, yes{}); tile_body(c1{}, no{}, no{}); }
+            else if (kt < KT) tile_body(c0{}, no{}, no{});
+            return;
+        }
         for (; kt + 3 < KT; kt += 2) {                      // tiles kt, kt+1: both stage t+1 and fetch t+2
             next_tile(); tile_body(c0{}, yes{}, yes{});
             next_tile(); tile_body(c1{}, yes{}, yes{});
@@ -452,8 +471,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
             constexpr int BUF = decltype(buf_tag)::value;
             constexpr bool HN = decltype(has_next_tag)::value, LD = !(ABL & 1), LD3 = decltype(load_tag)::value && LD;
             pipe::tile_body_split<BUF, HN, (HN && LD) ? BT::NBF : 0, LD3 ? A_LD : 0, (ABL & 2) ? 0 : A_LD, ABL>(
-                bt, acc, af0, af1, bfr[BUF], [&] { issue_b(std::integral_constant<int, BUF ^ 1>{}); }, issue_loads,
-                [&] { store_tile(std::integral_constant<int, BUF ^ 1>{}); });
+                bt, acc, af0, af1, bfr[BUF], [&] { issue_b(std::integral_constant<int, BUF ^ 1>{}); },
+                [&] { issue_loads_to(std::integral_constant<int, BUF ^ 1>{}); },             // DEEP: tile t+3 into the set tile t+1 has just left
+                [&] { store_tile_from(std::integral_constant<int, BUF ^ 1>{}, std::integral_constant<int, BUF ^ 1>{}); });
         });
     } else {
         f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
@@ -666,6 +686,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kern
 
 int conv_tile_bn(int tile) { return tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32); }
 
+// split precision: the tile configuration a launch really runs on
+int conv_split_tile(int tile, bool kx3) { return (tile == TILE_128x128 && !kx3) ? TILE_128x64 : tile; }
+
 int conv_pick_tile(int N) {
     if (N > 64) return TILE_128x128;
     if (N > 32) return TILE_128x64;
@@ -777,7 +800,10 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
                 return launch_one<BM, BN, WM, WN, true, true, true>(q, grid, st);
             }
         }
-        return fast ? launch_one<BM, BN, WM, WN, true, true>(q, grid, st) : launch_one<BM, BN, WM, WN, false, true>(q, grid, st);
+        // (the plain split kernel is not built for the 128-wide tile: it needs more than 256 registers there, and this
+        //  library keeps out of scratch memory -- conv_split_tile() maps such launches to the 64-wide tile)
+        if constexpr (BN >= 128) return hipErrorInvalidValue;
+        else return fast ? launch_one<BM, BN, WM, WN, true, true>(q, grid, st) : launch_one<BM, BN, WM, WN, false, true>(q, grid, st);
     } else
         return fast ? launch_one<BM, BN, WM, WN, true, false>(q, grid, st) : launch_one<BM, BN, WM, WN, false, false>(q, grid, st);
 }

@@ -117,7 +117,12 @@ __global__ void decode_ale_kernel(const DecodeParams p) {
     }
 }
 
-// 4x4 determinant by LU with partial pivoting (what tf.linalg.det does via Eigen PartialPivLU)
+// 4x4 determinant by LU with partial pivoting (what tf.linalg.det does via Eigen PartialPivLU).
+// The pivot row is swapped in with SELECTS over compile-time indices: a run-time row index (a[piv][c]) sends the matrix
+// to scratch memory (20 bytes of private segment per lane in the first version), and this library's kernels stay out
+// of scratch altogether -- kernels with private segments from several HIP streams at once disturbed each other's
+// spilled values on this stack (tests/test_gpu_parity.py::test_engines_on_concurrent_streams: this determinant, whose
+// value is rounding noise for T <= 4 samples, was the one visible symptom).
 __device__ __forceinline__ float det4_(float a[4][4]) {
     float det = 1.f;
 #pragma unroll
@@ -125,11 +130,13 @@ __device__ __forceinline__ float det4_(float a[4][4]) {
         int piv = k; float best = fabsf(a[k][k]);
 #pragma unroll
         for (int r = k + 1; r < 4; ++r) { const float v = fabsf(a[r][k]); if (v > best) { best = v; piv = r; } }
-        if (piv != k) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float t = a[k][c]; a[k][c] = a[piv][c]; a[piv][c] = t; }
-            det = -det;
+        for (int r = k + 1; r < 4; ++r) {
+            const bool sw = piv == r;                              // (same first-maximum choice, same swap as before)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float x = a[k][c], y = a[r][c]; a[k][c] = sw ? y : x; a[r][c] = sw ? x : y; }
         }
+        if (piv != k) det = -det;
         const float d = a[k][k];
         det *= d;
         if (d != 0.f) {
