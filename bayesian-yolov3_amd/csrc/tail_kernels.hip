@@ -56,7 +56,7 @@ __device__ __forceinline__ void corners_(float tx, float ty, float tw, float th,
 
 // thread <-> (image b, cell, prior p), prior fastest: a wave reads 64 * blk contiguous floats.
 template <int CM, bool EXACT>
-__global__ void decode_std_kernel(const DecodeParams p) {
+__global__ __launch_bounds__(256) void decode_std_kernel(const DecodeParams p) {
     const int C = EXACT ? CM : p.C;
     const int BLK = 5 + C, D = 5 + C;
     const int cells = p.lh * p.lw;
@@ -81,7 +81,7 @@ __global__ void decode_std_kernel(const DecodeParams p) {
 }
 
 template <int CM, bool EXACT>
-__global__ void decode_ale_kernel(const DecodeParams p) {
+__global__ __launch_bounds__(256) void decode_ale_kernel(const DecodeParams p) {
     const int C = EXACT ? CM : p.C;
     const int BLK = 2 * (5 + C), D = 14 + C;
     const int cells = p.lh * p.lw;
@@ -154,7 +154,7 @@ __device__ __forceinline__ float det4_(float a[4][4]) {
 // One lane per (image, cell, prior): a single pass over the image's T samples keeps
 // 4 + 10 + 4 + 1 + 1 + C + 1 running sums in registers.
 template <int CM, bool EXACT>
-__global__ void decode_epi_kernel(const DecodeParams p) {
+__global__ __launch_bounds__(256) void decode_epi_kernel(const DecodeParams p) {
     const int C = EXACT ? CM : p.C;
     const int BLK = 2 * (5 + C), D = 21 + C;
     const int cells = p.lh * p.lw;
@@ -241,7 +241,7 @@ __global__ void decode_epi_kernel(const DecodeParams p) {
 // equals the row's columns 4..7 bit for bit) and the per-sample `obj_samples` / `cls_samples`.  One lane per
 // (image, cell, prior); any output may be null.
 template <int CM, bool EXACT>
-__global__ void epi_stats_kernel(const DecodeParams p, float* ev_loc, float* covar, float* obj_s, float* cls_s) {
+__global__ __launch_bounds__(256) void epi_stats_kernel(const DecodeParams p, float* ev_loc, float* covar, float* obj_s, float* cls_s) {
     const int C = EXACT ? CM : p.C;
     const int BLK = 2 * (5 + C);
     const int cells = p.lh * p.lw;

@@ -1,5 +1,5 @@
 """No kernel of libbyolo.so uses scratch memory (a private segment), except the decode kernels of models with more than
-8 classes, whose per-lane arrays do not fit the register file.
+48 classes (the 128-class build), whose per-lane arrays do not fit even a 512-register wave.
 
 Why this is a test: kernels with private segments that ran from several HIP streams at once disturbed each other's
 spilled values on this stack (ROCm 7.2, MI355X) -- the split-f16 convolutions that spilled and decode_epi_kernel's
@@ -19,8 +19,8 @@ from conftest import REPO
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 LIB = os.path.join(REPO, "bayesian-yolov3_amd", "byolo", "libbyolo.so")
-# per-lane state of the large-class-count decode variants (softmax over up to 128 classes) exceeds 128 registers
-ALLOWED = re.compile(r"(decode_(std|ale|epi)_kernel|epi_stats_kernel)ILi(24|48|80|128)E")
+# per-lane state of the largest decode variant (softmax + entropies over up to 128 classes) exceeds the register file
+ALLOWED = re.compile(r"(decode_(std|ale|epi)_kernel|epi_stats_kernel)ILi128E")
 
 
 def test_kernels_stay_out_of_scratch(tmp_path):
