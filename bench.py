@@ -248,7 +248,14 @@ def main():
                                       cfg["variant"], cfg["H"], cfg["W"], T, B, B * world,
                                       "wise 2-class" if cfg["nms"] else "agnostic"),
                        "images_per_gpu": B, "T": T, "img_size": [cfg["H"], cfg["W"]], "parallelism": "dp%d" % world,
-                       "gflop_per_image": flops_img / 1e9, "precision": eng.precision},
+                       "gflop_per_image": flops_img / 1e9, "precision": eng.precision,
+                       "precision_note": ("split-f16: every activation / weight as hi + lo fp16 (23 significant bits, half an fp32 ulp of "
+                                          "representation error), products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 into fp32 "
+                                          "accumulators (the instruction sums its 16 products before one rounding); on the device closer to the "
+                                          "float64 oracle than the float32 oracle is, 1e-4 contract held in every parity test (DESIGN.md "
+                                          "sections 0, 5; tests/test_gpu_bench_shapes.py); BYOLO_PRECISION=f32 runs the fp32 matrix "
+                                          "instruction instead (181.8 img/s at this config)") if eng.precision == "split" else
+                                         "fp32 operands on v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) on the large 3x3 layers"},
         }
         SPLIT = (3128, 3064, 1128, 1064, 1032)
         KERNELS = {3128: "conv_igemm_kernel<128,128,1,4,kx3> (split-f16 3x3/stride-1 on shared-tap stages, v_mfma_f32_32x32x16_f16 x3)",
