@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BYOLO_LIB: load another build of the same library (the timing-ablation builds of csrc/build.py --ablate)
 LIB_PATH = os.environ.get("BYOLO_LIB") or os.path.join(_HERE, "libbyolo.so")
 
-OK, ERR_ARG, ERR_STATE, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4
+OK, ERR_ARG, ERR_STATE, ERR_HIP, ERR_NOMEM, ERR_RANGE = 0, -1, -2, -3, -4, -5
 DET_STANDARD, DET_ALEATORIC, DET_EPISTEMIC = 0, 1, 2
 NMS_AGNOSTIC, NMS_TWO_CLASS = 0, 1
 NORM_BN, NORM_DROPOUT = 1, 2
@@ -51,7 +51,13 @@ PROTOTYPES = {
     "byolo_num_layers": (_i32, [_vp]),
     "byolo_num_boxes": (_i32, [_vp, _P(_i64), _P(_i32)]),
     "byolo_workspace_bytes": (_i32, [_vp, _i32, _i32, _P(_sz)]),
-    "byolo_forward": (_i32, [_vp, _vp, _i32, _i32, _u64, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "byolo_forward": (_i32, [_vp, _vp, _i32, _i32, _u64, _i32, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "byolo_num_dropout": (_i32, [_vp]),
+    "byolo_mask_layout": (_i32, [_vp, _i32, _i32, _i32, _P(_i64), _P(_i64)]),
+    "byolo_set_async": (_i32, [_vp, _i32]),
+    "byolo_status": (_i32, [_vp, _vp, _P(ctypes.c_uint32), _P(_i32)]),
+    "byolo_clear_status": (_i32, [_vp, _vp]),
+    "byolo_precision_note": (_cp, [_vp]),
     "byolo_set_first_image": (_i32, [_vp, _i64]),
     "byolo_max_images": (_i32, [_vp, _i32, _P(_i32)]),
     "byolo_layer_output": (_i32, [_vp, _i32, _P(_vp), _P(_i64)]),

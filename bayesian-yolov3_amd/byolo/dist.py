@@ -32,6 +32,20 @@ def init(backend=None, force=None):
     return rank, local, world
 
 
+def agree_on_error(err, src=0):
+    """Rank `src` passes an exception (or None); every rank gets it back -- so that all ranks of a job raise together
+    instead of the healthy ones blocking in their next collective until the backend's timeout.  No-op without a
+    process group."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return err
+    box = [repr(err) if err is not None else None]
+    dist.broadcast_object_list(box, src=src)
+    if box[0] is None:
+        return None
+    return err if err is not None else RuntimeError("rank %d failed: %s" % (src, box[0]))
+
+
 def shard_range(n_items, rank, world):
     """Contiguous block of the batch axis owned by `rank` (first ranks get the remainder)."""
     q, r = divmod(n_items, world)

@@ -45,6 +45,65 @@ class Engine:
         check(self._h, lib.byolo_set_precision(self._h, {"f32": 0, "split": 1}[precision]))
         self.finalized = False
 
+    @property
+    def precision_note(self):
+        """Why finalize() chose the fp32 mode although split-f16 was asked for ('' if it did not)."""
+        return lib.byolo_precision_note(self._h).decode()
+
+    # ---- numeric status of the split-f16 mode (include/byolo.h: BYOLO_ERR_RANGE) -------------------------
+    def set_async(self, on=True):
+        """on: forward() neither waits for the stream nor checks the status words; the caller asks check_status() where
+        it synchronises anyway.  Off (the default): forward() raises ByoloError(ERR_RANGE) itself."""
+        check(self._h, lib.byolo_set_async(self._h, int(bool(on))))
+        self._async = bool(on)
+
+    def status(self):
+        """(flags, layer) after waiting for the current stream: bit 0 = an activation left the split-f16 range in `layer`,
+        bit 1 = a raw detection output is inf / NaN.  Does not raise."""
+        torch = _torch()
+        flags, layer = ctypes.c_uint32(), ctypes.c_int32()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        lib.byolo_status(self._h, ctypes.c_void_p(stream), ctypes.byref(flags), ctypes.byref(layer))
+        return int(flags.value), int(layer.value)
+
+    def check_status(self):
+        """Wait for the current stream; raise ByoloError(ERR_RANGE) if a forward since the last clear left the range."""
+        torch = _torch()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self._h, lib.byolo_status(self._h, ctypes.c_void_p(stream), None, None))
+
+    def clear_status(self):
+        torch = _torch()
+        check(self._h, lib.byolo_clear_status(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    # ---- injected dropout masks (byolo_forward's d_mask_bits) ---------------------------------------------
+    def num_dropout(self):
+        return check(self._h, lib.byolo_num_dropout(self._h))
+
+    def mask_layout(self, B, T=1):
+        """[(bit_offset, elements)] per dropout layer for a (B, T) call, and the total length in 32-bit words."""
+        off, n = ctypes.c_int64(), ctypes.c_int64()
+        out = []
+        nd = self.num_dropout()
+        for k in range(nd + 1):
+            check(self._h, lib.byolo_mask_layout(self._h, int(B), int(T), k, ctypes.byref(off), ctypes.byref(n)))
+            out.append((int(off.value), int(n.value)))
+        return out[:nd], out[nd][0] // 32
+
+    def pack_masks(self, masks, B, T=1):
+        """masks: one boolean array per dropout layer (creation order), shaped like its dropout input [S,h,w,cout]
+        (True = keep).  Returns the uint32 word array byolo_forward takes (numpy; bit i of a layer at bit_offset + i)."""
+        layout, words = self.mask_layout(B, T)
+        assert len(masks) == len(layout), "%d masks for %d dropout layers" % (len(masks), len(layout))
+        buf = np.zeros(words, dtype=np.uint32)
+        for m, (off, n) in zip(masks, layout):
+            m = np.ascontiguousarray(m, dtype=bool).reshape(-1)
+            assert m.size == n, "mask of %d elements, the layer has %d" % (m.size, n)
+            bits = np.packbits(m, bitorder="little")
+            bits = np.concatenate([bits, np.zeros((-bits.size) % 4, dtype=np.uint8)])
+            buf[off // 32: off // 32 + bits.size // 4] = bits.view("<u4")
+        return buf
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             lib.byolo_destroy(self._h)
@@ -179,7 +238,8 @@ class Engine:
         check(self._h, lib.byolo_max_images(self._h, int(T), ctypes.byref(n)))
         return int(n.value)
 
-    def forward(self, img, T=1, seed=0, dropout_on=True, want_boxes=False, want_nms=True, out=None, slot=0, first_image=0):
+    def forward(self, img, T=1, seed=0, dropout_on=True, want_boxes=False, want_nms=True, out=None, slot=0, first_image=0,
+                mask_bits=None):
         """One sess.run of the reference (inference_epistemic.py:76).  Returns a dict of device
         tensors: rows [B,cap,D], kept [B,cap] int32, count [B,2] int32 and (want_boxes) boxes [B,N,D].
         Everything is enqueued on torch's current stream; no host synchronisation.
@@ -206,6 +266,7 @@ class Engine:
             for lo in range(0, B, cap_b):
                 hi = min(B, lo + cap_b)
                 sub = {k: v[lo:hi] for k, v in res.items() if v is not None}
+                assert mask_bits is None, "injected masks describe ONE byolo_forward call: keep B <= max_images(T)"
                 self.forward(img[lo:hi], T=T, seed=seed, dropout_on=dropout_on, want_boxes=want_boxes, want_nms=want_nms,
                              out=sub, slot=slot, first_image=first_image + lo)
             return dict(boxes=res.get("boxes"), rows=res.get("rows"), kept=res.get("kept"), count=res.get("count"))
@@ -229,8 +290,11 @@ class Engine:
                 count = torch.empty((B, 2), dtype=torch.int32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        if mask_bits is not None:
+            assert mask_bits.is_cuda and mask_bits.dtype in (torch.int32, torch.uint32) and mask_bits.is_contiguous()
+            assert mask_bits.numel() >= self.mask_layout(B, T)[1], "mask_bits shorter than byolo_mask_layout's total"
         check(self._h, lib.byolo_forward(self._h, p(img), B, int(T), ctypes.c_uint64(int(seed) & (2**64 - 1)),
-                                         int(bool(dropout_on)), p(ws), ws.numel(), p(boxes), p(rows), p(kept),
+                                         int(bool(dropout_on)), p(mask_bits), p(ws), ws.numel(), p(boxes), p(rows), p(kept),
                                          p(count), ctypes.c_void_p(stream)))
         return dict(boxes=boxes, rows=rows, kept=kept, count=count)
 

@@ -162,7 +162,9 @@ class InferenceLoop:
         self.config = config
         self.img_size = config['full_img_size']
         assert not config['crop']
-        self.rank, self.local_rank, self.world = bdist.env_rank()
+        # the process group exists BEFORE any rank-specific side effect: a rank that fails below (rank 0 refusing an
+        # existing output directory) tells the others, and all of them stop together instead of waiting for a dead peer
+        self.rank, self.local_rank, self.world = bdist.init()
         if self.world > 1:                                # one engine per process, on this process's GPU
             yolo.set_engine_option('device', self.local_rank)
 
@@ -174,8 +176,15 @@ class InferenceLoop:
         else:
             self.checkpoint = find_checkpoint(config)
         self.out_path = '{}_{}'.format(config['out_path'], step_of(self.checkpoint))
+        err = None
         if self.rank == 0:
-            os.makedirs(self.out_path)                    # like the reference: refuses to overwrite an existing run
+            try:
+                os.makedirs(self.out_path)                # like the reference: refuses to overwrite an existing run
+            except OSError as e:
+                err = e
+        err = bdist.agree_on_error(err)                   # every rank learns of rank 0's failure (one broadcast)
+        if err is not None:
+            raise err
         self.worker_thread = None
 
     def _load_weights(self):

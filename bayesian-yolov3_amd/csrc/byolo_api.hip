@@ -67,7 +67,7 @@ struct Layer {
     size_t scalek_off = 0;             // dropout layers: scale / (1 - p), what the epilogue multiplies with when the masks are on
     int tile = 0, Npad = 0;
     bool direct = false;
-    int wshift = 0;                // split precision: the packed weights hold w * 2^wshift (largest |w'| in [2^13, 2^14))
+    std::vector<int> wshift;       // split precision, per OUTPUT CHANNEL n: the packed weights hold w[.][n] * 2^wshift[n] (the channel's largest |w'| in [2^13, 2^14)); folded into scale[n]
     float in_scale = 1.f;          // split precision: scale of the layer's input (ACT_SCALE for activations, 1 for the fp32 image of a direct convolution)
     int64_t box_base = 0;
 };
@@ -147,6 +147,13 @@ struct byolo {
     //      activations live in memory as [4 hi | 4 lo] groups holding ACT_SCALE * value, weights as 2^wshift * w
     bool img_split = false;        // split precision: some matrix-pipe convolution reads the image -> a hi/lo copy is made per forward
     int precision = 1;             // default: split-f16 (BYOLO_PRECISION=f32 selects the fp32 matrix instruction)
+    int prec_requested = 1;        // what byolo_set_precision / BYOLO_PRECISION asked for
+    std::string prec_note;         // why byolo_finalize fell back to BYOLO_PREC_F32 (empty: it did not)
+    // Numeric status (byolo_status): two device words {flags, first layer} every split-f16 epilogue / decode launch of this
+    // handle may raise (sticky until byolo_clear_status), and their pinned host mirror
+    unsigned* d_status = nullptr; unsigned* h_status = nullptr;
+    bool async_status = false;     // byolo_set_async: byolo_forward does not wait for the status words
+    bool plan_inject = false;      // the current plan was made for injected dropout masks (fp32 mode: conv_igemm launches only)
     std::vector<int> last_use;     // per tensor id: index of the last step reading it
     float* d_blob = nullptr;       // packed weights + scale/shift
     size_t blob_floats = 0;
@@ -211,6 +218,7 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
     h->cfg = *cfg;
     h->device = device;
     if (const char* e = getenv("BYOLO_PRECISION")) h->precision = (!strcmp(e, "f32") || !strcmp(e, "0")) ? 0 : 1;
+    h->prec_requested = h->precision;
     *out = h;
     return BYOLO_OK;
 }
@@ -218,20 +226,23 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
 extern "C" int32_t byolo_set_precision(byolo_t* h, int32_t precision) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_set_precision: null handle");
     if (precision != BYOLO_PREC_F32 && precision != BYOLO_PREC_SPLIT_F16) return fail(h, BYOLO_ERR_ARG, "byolo_set_precision: unknown precision %d", precision);
-    if (precision != h->precision) { h->precision = precision; h->finalized = false; h->plan.B = -1; h->plan.T = -1; }
+    h->prec_requested = precision;
+    if (precision != h->precision) { h->precision = precision; h->prec_note.clear(); h->finalized = false; h->plan.B = -1; h->plan.T = -1; }
     return BYOLO_OK;
 }
 extern "C" int32_t byolo_get_precision(const byolo_t* h) { return h ? h->precision : BYOLO_ERR_ARG; }
 
 extern "C" int32_t byolo_destroy(byolo_t* h) {
     if (!h) return BYOLO_OK;
-    bool on_device = h->d_blob || h->d_ones;
+    bool on_device = h->d_blob || h->d_ones || h->d_status;
     for (auto& ps : h->prof) on_device = on_device || ps.ev[0] || !ps.step_ev.empty();
     if (on_device) {                               // a handle that never ran (builder-only use, no GPU) touches no HIP call
         (void)hipSetDevice(h->device);
         if (h->d_blob) (void)hipFree(h->d_blob);
         if (h->d_ones) (void)hipFree(h->d_ones);
         if (h->d_zeros) (void)hipFree(h->d_zeros);
+        if (h->d_status) (void)hipFree(h->d_status);
+        if (h->h_status) (void)hipHostFree(h->h_status);
         for (auto& ps : h->prof) {
             for (auto& e : ps.ev) if (e) (void)hipEventDestroy(e);
             for (auto& e : ps.step_ev) (void)hipEventDestroy(e);
@@ -625,10 +636,12 @@ static void fold_layer(const byolo_t* h, const Layer& l, std::vector<float>& sca
 
 // split precision: the accumulators hold ACT_SCALE * 2^wshift * conv (the stem: conv -- fp32 image, fp32 weights) and the
 // output tensor holds ACT_SCALE * value (a detection head: the value itself, fp32) -- powers of two, folded exactly
+static float acc_scale_of(const Layer& l, int c) {                                    // the direct kernels keep fp32 weights
+    return l.in_scale * ((l.direct || l.wshift.empty()) ? 1.f : ldexpf(1.f, l.wshift[c]));
+}
 static void fold_split(const Layer& l, std::vector<float>& scale, std::vector<float>& shift) {
-    const float acc_scale = l.in_scale * (l.direct ? 1.f : ldexpf(1.f, l.wshift));     // the direct kernels keep fp32 weights
     const float out_scale = l.op == OP_DETECTION ? 1.f : ACT_SCALE;
-    for (float& v : scale) v *= out_scale / acc_scale;
+    for (size_t c = 0; c < scale.size(); ++c) scale[c] *= out_scale / acc_scale_of(l, (int)c);
     for (float& v : shift) v *= out_scale;
 }
 
@@ -641,7 +654,41 @@ static void scale_keep(const byolo_t* h, std::vector<float>& scale) {
 extern "C" int32_t byolo_finalize(byolo_t* h) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_finalize: null handle");
     if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
+    // Every parameter must be a number.  The reference would carry an inf / NaN from a checkpoint (tf.train.Saver.restore,
+    // inference_epistemic.py:58) silently into its float32 outputs; here it would also poison the per-channel weight scales.
+    for (const auto& l : h->layers) {
+        if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
+        for (int pi : {l.p_kernel, l.p_bias, l.p_gamma, l.p_beta, l.p_mean, l.p_var}) {
+            if (pi < 0) continue;
+            for (float v : h->params[pi].data)
+                if (!std::isfinite(v)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: variable '%s' holds a non-finite value", h->params[pi].name.c_str());
+        }
+        if (l.p_var >= 0)
+            for (float v : h->params[l.p_var].data)
+                if (!(v + 1e-5f > 0.f)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: variable '%s' holds a variance <= -eps (rsqrt of a negative number)", h->params[l.p_var].name.c_str());
+    }
+    // Split storage keeps activations in groups of 4 channels.  A graph it cannot express (no reference model has one) runs in
+    // the fp32 mode instead of being refused: byolo_get_precision / byolo_precision_note tell.
+    if (h->precision == 0 && !h->prec_note.empty() && h->prec_requested == 1) h->precision = 1;      // the request stands; decide again
+    h->prec_note.clear();
+    if (h->precision == 1)
+        for (const auto& l : h->layers)
+            if (l.op == OP_CONV && (l.filters % 4)) {
+                char buf[256];
+                snprintf(buf, sizeof buf, "fp32 mode: split-f16 storage needs output channels in groups of 4, layer '%s' has %d", l.scope.c_str(), l.filters);
+                h->prec_note = buf; h->precision = 0; h->plan.B = -1; h->plan.T = -1;
+                static const bool quiet = [] { const char* e = getenv("BYOLO_QUIET"); return e && atoi(e); }();
+                if (!quiet) fprintf(stderr, "byolo: %s\n", buf);
+                break;
+            }
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->d_status) {
+        HIPCHK(h, hipMalloc((void**)&h->d_status, 2 * sizeof(unsigned)));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_status, 2 * sizeof(unsigned), hipHostMallocDefault));
+        const unsigned init[2] = {0u, 0xFFFFFFFFu};
+        HIPCHK(h, hipMemcpy(h->d_status, init, sizeof init, hipMemcpyHostToDevice));
+        h->h_status[0] = 0u; h->h_status[1] = 0xFFFFFFFFu;
+    }
     // layout of the device blob
     size_t off = 0; const int maxC = h->maxC;
     for (auto& st : h->steps) {
@@ -662,17 +709,23 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
     if (h->precision == 1) {
         for (auto& l : h->layers) {
             if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
-            if (l.op == OP_CONV && (l.filters % 4))
-                return fail(h, BYOLO_ERR_ARG, "byolo_finalize: split precision stores activations in groups of 4 channels; layer '%s' has %d", l.scope.c_str(), l.filters);
             // a direct convolution reads the image as it is (fp32); a matrix-pipe convolution reads a hi/lo copy of it
             l.in_scale = (l.direct && l.prev < 0) ? 1.f : ACT_SCALE;
             if (!l.direct && l.prev < 0) h->img_split = true;
+            // One power of two PER OUTPUT CHANNEL (folded into scale[n], exactly): the column's largest |w'| lands in
+            // [2^13, 2^14), so a filter whose weights are 2^-10 of its neighbours' -- a checkpoint whose BN gammas absorbed the
+            // scale, e.g. -- keeps its 22 bits.  (One shift per layer gave such a column 12.)  Clamped: 2^shift stays finite.
             const Param& k = h->params[l.p_kernel];
-            float mx = 0.f;
-            for (float v : k.data) mx = std::max(mx, std::fabs(v));
-            int e = 0;
-            if (mx > 0.f && std::isfinite(mx)) (void)std::frexp(mx, &e);          // mx = m * 2^e, m in [0.5, 1)
-            l.wshift = mx > 0.f ? 14 - e : 0;
+            const int N = l.filters;
+            const size_t rows = k.data.size() / (size_t)N;          // HWIO == [K][N]
+            l.wshift.assign((size_t)N, 0);
+            for (int n = 0; n < N; ++n) {
+                float mx = 0.f;
+                for (size_t r = 0; r < rows; ++r) mx = std::max(mx, std::fabs(k.data[r * N + n]));
+                int e = 0;
+                if (mx > 0.f) (void)std::frexp(mx, &e);            // mx = m * 2^e, m in [0.5, 1)
+                l.wshift[n] = mx > 0.f ? std::min(100, std::max(-100, 14 - e)) : 0;
+            }
         }
     }
     for (auto& st : h->steps) {
@@ -694,7 +747,8 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
             // registers of v_mfma_f32_32x32x16_f16 as one coalesced 1 KB load per (step, plane).
             // K-tile order: (tap, chunk); shared-tap launches: (ky, chunk, kx)
             _Float16* d16 = reinterpret_cast<_Float16*>(dst);
-            const float ws = ldexpf(1.f, l.wshift);
+            std::vector<float> ws((size_t)N);
+            for (int nn = 0; nn < N; ++nn) ws[nn] = ldexpf(1.f, l.wshift[nn]);
             const size_t blocks = st.Npad / 32;
             for (int tap = 0; tap < taps; ++tap)
                 for (int c = 0; c < Cs; ++c) {
@@ -702,7 +756,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
                     const int kt = st.kx3 ? ((tap / 3) * cts + (c >> 5)) * 3 + tap % 3 : tap * cts + (c >> 5);
                     const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
                     for (int nn = 0; nn < N; ++nn) {
-                        const float v = wr[nn] * ws;
+                        const float v = wr[nn] * ws[nn];
                         const _Float16 hi = (_Float16)v;
                         _Float16* d = d16 + (((size_t)kt * blocks + (nn >> 5)) * 4 + step * 2) * 512 + (half * 32 + (nn & 31)) * 8 + e;
                         d[0] = hi; d[512] = (_Float16)(v - (float)hi);
@@ -777,9 +831,10 @@ static void step_geometry(const byolo_t* h, const Step& st, int B, int T, int* M
     *KT = l.ksize * l.ksize * ((st.c_hi - st.c_lo) / 32);
 }
 
-static void make_plan(byolo_t* h, int B, int T) {
+static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
     Plan& p = h->plan;
-    if (p.B == B && p.T == T) return;
+    if (p.B == B && p.T == T && h->plan_inject == inject) return;
+    h->plan_inject = inject;
     const int n = (int)h->layers.size() + (int)h->aux.size();     // tensor ids: layers, then auxiliaries
     p.B = B; p.T = T; p.off.assign(n, -1);
     struct Blk { int64_t off, size; };
@@ -841,6 +896,7 @@ static void make_plan(byolo_t* h, int B, int T) {
         // the 1x1 / stride-2 / concat convolutions run on the 64-wide tile, which also keeps twice the workgroups in flight per
         // byte streamed for the HBM-latency-bound 76x76 head layers (measured at config 4: 0.83 -> 0.56, 0.77 -> 0.67 ms)
         if (h->precision == 1) tile = conv_split_tile(tile, s.kx3);
+        else if (inject && tile == TILE_128x128) tile = TILE_128x64;      // the fp32 128-wide build has no mask-injection path (conv_igemm.hip)
         p.tile[si] = tile;
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
         const bool sp = h->precision == 1, kx3 = sp && s.kx3;
@@ -853,7 +909,7 @@ static void make_plan(byolo_t* h, int B, int T) {
     p.wino.assign(h->steps.size(), WinoPlan{});
     size_t wino_scratch = 0;
     { const char* e = getenv("BYOLO_WINOGRAD");
-      const int on = h->precision == 1 ? 0 : (e ? atoi(e) : 1);   // split precision: direct convolutions only (memory-bound transforms do not pay there)
+      const int on = (h->precision == 1 || inject) ? 0 : (e ? atoi(e) : 1);   // split precision: direct convolutions only (memory-bound transforms do not pay there); injected masks: conv_igemm's epilogue reads them
       const char* mf = getenv("BYOLO_WINO_MIN_GFLOP");                     // tuning knob: smallest layer (direct GFLOP) to transform
       // (measured at config 4: 100 -> 144.97, 20 -> 147.35, 5 -> 147.32 img/s; at config 2 (416x416, 8 images) the 52x52
       //  layers are 12.8 GFLOP: 20 -> 1375, 10 -> 1506, 5 -> 1504 img/s.  Default 10.)
@@ -912,7 +968,7 @@ static void make_plan(byolo_t* h, int B, int T) {
     // BYOLO_STREAM1X1=0 keeps them on conv_igemm (A/B), =2 takes it for every shape the kernel can express (tests).
     p.stream1x1.assign(h->steps.size(), 0);
     { const char* e = getenv("BYOLO_STREAM1X1");
-      const bool on = h->precision == 0 && (!e || atoi(e) != 0), force = e && atoi(e) >= 2;
+      const bool on = h->precision == 0 && !inject && (!e || atoi(e) != 0), force = e && atoi(e) >= 2;
       for (size_t si = 0; on && si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
@@ -1017,13 +1073,14 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
         p.addend_T = l.stacked ? T : 1;
     } else { p.addend = nullptr; p.addend_T = 1; }
     p.d_addT = make_fastdiv((uint32_t)p.addend_T);
+    p.status = h->precision == 1 ? h->d_status : nullptr; p.layer_idx = st.layer;
 }
 
 // STEP_GATHER / STEP_ADD (fill_conv has resolved the sources, the output extent and the destination)
 static int32_t run_aux_step(byolo_t* h, const Step& s, const ConvParams& p, hipStream_t st) {
     const Layer& l = h->layers[s.layer];
     if (s.mode == STEP_GATHER) { HIPCHK(h, launch_view_gather(p, st)); }
-    else { HIPCHK(h, launch_tensor_add(p.src0, p.src1, p.dst, (int64_t)p.M * l.C, h->precision == 1, st)); }
+    else { HIPCHK(h, launch_tensor_add(p.src0, p.src1, p.dst, (int64_t)p.M * l.C, h->precision == 1, st, p.status, s.layer)); }
     return BYOLO_OK;
 }
 
@@ -1142,6 +1199,7 @@ static int32_t run_decode(byolo_t* h, char* ws, float* boxes, int B, int T, hipS
         d.raw = reinterpret_cast<const float*>(ws + h->plan.off[l.out_tensor]);
         d.boxes = boxes; d.lh = l.H; d.lw = l.W; d.C = h->cfg.cls_cnt;
         d.n_total = h->n_boxes; d.box_base = l.box_base; d.layer_id = l.det_id;
+        d.status = h->precision == 1 ? h->d_status : nullptr;
         for (int k = 0; k < 3; ++k) { d.ph[k] = l.priors[2 * k]; d.pw[k] = l.priors[2 * k + 1]; }
         if (l.det_kind == BYOLO_DET_EPISTEMIC) { d.B = B; d.T = l.stacked ? T : 1; }
         else { d.B = l.stacked ? B * T : B; d.T = 1; }
@@ -1152,14 +1210,86 @@ static int32_t run_decode(byolo_t* h, char* ws, float* boxes, int B, int T, hipS
     return BYOLO_OK;
 }
 
+// Injected dropout masks: dropout layer `ordinal` (creation order) owns elements_k = S*h*w*cout bits -- element i of its dropout
+// input [S,h,w,cout], S = B*T in the stacked part of the graph -- starting at a 32-bit-aligned bit offset.
+static int64_t mask_layout(const byolo_t* h, int B, int T, int ordinal, int64_t* elements) {
+    int64_t off = 0;
+    for (const auto& l : h->layers) {
+        if (l.drop_ordinal < 0) continue;
+        const int64_t n = (l.stacked ? (int64_t)B * T : B) * l.H * l.W * l.filters;
+        if (l.drop_ordinal == ordinal) { if (elements) *elements = n; return off; }
+        off += (n + 31) / 32 * 32;
+    }
+    if (elements) *elements = 0;
+    return off;                                              // ordinal == n_dropout: the total
+}
+
+extern "C" int32_t byolo_num_dropout(const byolo_t* h) { return h ? h->n_dropout : BYOLO_ERR_ARG; }
+
+extern "C" int32_t byolo_mask_layout(byolo_t* h, int32_t B, int32_t T, int32_t ordinal, int64_t* bit_offset, int64_t* elements) {
+    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_mask_layout: null handle");
+    if (B < 1 || T < 1 || ordinal < 0 || ordinal > h->n_dropout) return fail(h, BYOLO_ERR_ARG, "byolo_mask_layout: bad argument");
+    int64_t n = 0;
+    const int64_t off = mask_layout(h, B, T, ordinal, &n);
+    if (bit_offset) *bit_offset = off;
+    if (elements) *elements = n;
+    return BYOLO_OK;
+}
+
+// the status words after everything enqueued on `st` so far; BLOCKS until the stream is idle
+static int32_t read_status(byolo_t* h, hipStream_t st, unsigned* flags, unsigned* layer) {
+    if (!h->d_status) { *flags = 0; *layer = 0xFFFFFFFFu; return BYOLO_OK; }
+    HIPCHK(h, hipMemcpyAsync(h->h_status, h->d_status, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    *flags = h->h_status[0]; *layer = h->h_status[1];
+    return BYOLO_OK;
+}
+static int32_t range_error(byolo_t* h, const char* what, unsigned flags, unsigned layer) {
+    const char* scope = layer < h->layers.size() ? h->layers[layer].scope.c_str() : "?";
+    if (flags & 1u)
+        return fail(h, BYOLO_ERR_RANGE, "%s: an output of layer %u ('%s') exceeds the split-f16 range (|activation| > %.0f); the reference's float32 "
+                    "tensor (lib_yolo/layers.py:550) holds it -- run this model with byolo_set_precision(BYOLO_PREC_F32)", what, layer, scope, 65504.0 / ACT_SCALE);
+    return fail(h, BYOLO_ERR_RANGE, "%s: a raw detection output is inf / NaN (non-finite activations upstream, or weights the float32 reference overflows on as well)", what);
+}
+
+extern "C" int32_t byolo_set_async(byolo_t* h, int32_t on) {
+    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_set_async: null handle");
+    h->async_status = on != 0;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_status(byolo_t* h, void* stream, uint32_t* flags, int32_t* layer) {
+    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_status: null handle");
+    if (!h->finalized) return fail(h, BYOLO_ERR_STATE, "byolo_status: call byolo_finalize first");
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned f = 0, l = 0xFFFFFFFFu;
+    int32_t rc = read_status(h, reinterpret_cast<hipStream_t>(stream), &f, &l); if (rc) return rc;
+    if (flags) *flags = f;
+    if (layer) *layer = (f & 1u) ? (int32_t)l : -1;
+    return f ? range_error(h, "byolo_status", f, l) : BYOLO_OK;
+}
+
+extern "C" int32_t byolo_clear_status(byolo_t* h, void* stream) {
+    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_clear_status: null handle");
+    if (!h->d_status) return BYOLO_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIPCHK(h, hipMemsetAsync(h->d_status, 0, sizeof(unsigned), st));
+    HIPCHK(h, hipMemsetAsync(h->d_status + 1, 0xFF, sizeof(unsigned), st));
+    return BYOLO_OK;
+}
+
+extern "C" const char* byolo_precision_note(const byolo_t* h) { return h ? h->prec_note.c_str() : ""; }
+
 extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
-                                 void* d_workspace, size_t workspace_bytes, float* d_boxes, float* d_rows,
+                                 const uint32_t* d_mask_bits, void* d_workspace, size_t workspace_bytes, float* d_boxes, float* d_rows,
                                  int32_t* d_kept, int32_t* d_count, void* stream) {
     int32_t rc = check_run(h, B, T, "byolo_forward"); if (rc) return rc;
     if (!d_img || !d_workspace) return fail(h, BYOLO_ERR_ARG, "byolo_forward: null image or workspace");
     if ((d_rows || d_kept || d_count) && !(d_rows && d_kept && d_count))
         return fail(h, BYOLO_ERR_ARG, "byolo_forward: d_rows, d_kept and d_count go together");
-    make_plan(h, B, T);
+    const bool inject = d_mask_bits != nullptr && dropout_on;
+    make_plan(h, B, T, inject);
     if (workspace_bytes < h->plan.total)
         return fail(h, BYOLO_ERR_NOMEM, "byolo_forward: workspace %zu < required %zu bytes", workspace_bytes, h->plan.total);
     HIPCHK(h, hipSetDevice(h->device));
@@ -1177,7 +1307,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
     bool backbone_marked = false;
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     if (h->precision == 1 && h->img_split)
-        HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st));
+        HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st, h->d_status));
     for (size_t si = 0; si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
@@ -1191,6 +1321,13 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
             if (l.drop_ordinal >= 0 && dropout_on) {
                 const byolo_drop_keys k = byolo_layer_keys(seed, (uint32_t)l.drop_ordinal, (double)h->cfg.drop_prob);
                 p.flags |= EPI_DROPOUT; p.k0 = k.k0; p.k1 = k.k1; p.thr = k.thr;
+                if (inject) {                                // this layer's first word; bit i = element i of this call's tensor
+                    int64_t n_el = 0;
+                    const int64_t off = mask_layout(h, B, T, l.drop_ordinal, &n_el);
+                    if ((l.filters & 3) && !l.direct) return fail(h, BYOLO_ERR_ARG, "byolo_forward: injected masks need cout %% 4 == 0 on a matrix-pipe dropout layer; '%s' has %d", l.scope.c_str(), l.filters);
+                    if (n_el >= ((int64_t)1 << 32)) return fail(h, BYOLO_ERR_ARG, "byolo_forward: injected masks index a dropout tensor with 32 bits; layer '%s' has %lld elements", l.scope.c_str(), (long long)n_el);
+                    p.mask_bits = d_mask_bits + off / 32; p.idx_base = 0;
+                }
                 // element index of this call's first output element in the logical batch's [S,h,w,c] tensor
                 p.idx_base = (uint64_t)h->first_image * (uint64_t)(l.stacked ? T : 1) * l.H * l.W * l.filters;
                 p.scale = dptr(h, l.scalek_off);             // scale / (1 - p)
@@ -1258,6 +1395,13 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         HIPCHK(h, launch_sort_nms(n, st));
     }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->wslot().ev[4], st)); h->wslot().ev_valid = true; }
+    // Split precision: wait for the forward and read the status words, unless the caller does that itself (byolo_set_async +
+    // byolo_status).  A raised status is an ERROR here, not a row of inf / NaN: the words are cleared for the next call.
+    if (h->precision == 1 && !h->async_status) {
+        unsigned f = 0, ly = 0xFFFFFFFFu;
+        rc = read_status(h, st, &f, &ly); if (rc) return rc;
+        if (f) { (void)byolo_clear_status(h, stream); return range_error(h, "byolo_forward", f, ly); }
+    }
     return BYOLO_OK;
 }
 
@@ -1378,8 +1522,7 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         HIPCHK(h, hipMemcpyAsync(h->params[l.p_var].data.data(), d_var, sizeof(float) * N, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         if (split) {                                                       // statistics of the accumulators -> of the convolution
-            const float f = 1.f / (l.in_scale * (l.direct ? 1.f : ldexpf(1.f, l.wshift)));
-            for (int c = 0; c < N; ++c) { h->params[l.p_mean].data[c] *= f; h->params[l.p_var].data[c] *= f * f; }
+            for (int c = 0; c < N; ++c) { const float f = 1.f / acc_scale_of(l, c); h->params[l.p_mean].data[c] *= f; h->params[l.p_var].data[c] *= f * f; }
         }
         fold_layer(h, l, sc, sf);
         if (split) fold_split(l, sc, sf);

@@ -73,6 +73,13 @@ struct ConvParams {
     int kx3;                          // split 3x3 / stride-1 launch on shared-tap stages (conv_tile_kx3): weights packed in (ky, chunk, kx) order, KT counts stages
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
     uint64_t idx_base;                // dropout element index of dst[0] (sub-batch / shard of a logical batch)
+    // injected dropout masks (byolo_forward's d_mask_bits; lib_yolo/layers.py:521-524 with the caller's own Bernoulli draw):
+    // bit i decides element i of THIS CALL's dropout input [S,h,w,cout] (1 = keep; < 2^32 elements, idx_base = 0);
+    // null = the counter hash
+    const uint32_t* mask_bits;
+    // numeric status of the handle (byolo_status): status[0] |= 1 when a split-f16 output leaves the fp16 range,
+    // status[1] = min(status[1], layer) -- the first layer it happened in; null = not tracked
+    unsigned* status; int layer_idx;
     FastDiv d_hw, d_wout, d_sdiv0, d_sdiv1, d_addT;   // Hout*Wout, Wout, sdiv0, sdiv1, addend_T
     // split-K of the last partial round of tiles (conv_plan_split): blocks [0, full_tiles) compute whole
     // tiles, the remaining split_tiles tiles are computed by ksplit K-slice blocks each
@@ -159,8 +166,8 @@ int conv_split_tile(int tile, bool kx3);   // split precision: 128-wide tiles ex
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st);
 // a route / upsample / stack view copied into a dense [M][C0 + C1] tensor (sources, extents and dst as in ConvParams)
 hipError_t launch_view_gather(const ConvParams& p, hipStream_t st);
-hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, bool split, hipStream_t st);   // dst = a + b (split: all three in [4 hi | 4 lo] groups)
-hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mul, hipStream_t st);   // hi/lo pairs of mul * src
+hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, bool split, hipStream_t st, unsigned* status = nullptr, int layer = 0);   // dst = a + b (split: all three in [4 hi | 4 lo] groups)
+hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mul, hipStream_t st, unsigned* status = nullptr);   // hi/lo pairs of mul * src
 hipError_t launch_split_to_f32(const float* src, float* dst, int64_t n, float mul, hipStream_t st);   // dst[i] = mul * (hi + lo) of a split-f16 tensor
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st);   // small-cin (stem) direct conv
 
@@ -185,6 +192,8 @@ struct DecodeParams {
     int64_t n_total, box_base;
     float ph[3], pw[3];
     int layer_id;
+    int ld;                  // floats per cell of `raw` (0 = 3*blk, dense; the detection convolution pads its rows to a multiple of 4)
+    unsigned* status;        // numeric status (byolo_status): status[0] |= 2 when a raw value is not finite; null = not tracked
 };
 hipError_t launch_decode(int kind, const DecodeParams& p, hipStream_t st);
 // decode_epistemic's dict entries outside the box row: ev_loc [B,lh,lw,3,4], covar [B,lh,lw,3,4,4], obj / cls samples

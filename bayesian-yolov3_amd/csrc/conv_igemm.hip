@@ -76,6 +76,9 @@ template <int BM, int BN, int WM, int WN, bool SPLIT>
 __device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                             const uint32_t tile_m, const uint32_t tile_n, const TileShare sh) {
     constexpr int NT = 64 * WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+    // injected dropout masks (ConvParams::mask_bits): every build but the fp32 128 x 128 tile, which sits at exactly 256
+    // registers and would spill -- byolo_api.hip plans the 64-wide tile for such a call in the fp32 mode
+    constexpr bool INJECT = SPLIT || BN < 128;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
     const uint32_t hw = (uint32_t)(p.Hout * p.Wout);
@@ -178,6 +181,7 @@ __device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f3
     }
     uint32_t row_m[TM], row_img[TM], row_pix[TM];
     const float* add_row[TM];
+    float vmax = 0.f;                                          // SPLIT: largest |value| this lane stores
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         row_m[i] = tile_m * BM + wm * TM * 32 + i * 32 + li;
@@ -244,8 +248,16 @@ __device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f3
                         const uint64_t idx0 = idx_row[i] + (uint64_t)dn;
                         bool keep[4] = {true, true, true, true};
                         if (do_drop) {
-                            if constexpr (VEC) epi::keep4(drow, dn, p.k0, p.thr, keep);
-                            else {
+                            if constexpr (VEC) {
+                                if (INJECT && p.mask_bits) {                            // injected masks: bit i of the layer = element i of this call's tensor
+                                    // (idx_base is 0 on such a call, the tensor has < 2^32 elements, cout % 4 == 0: byolo_forward checks;
+                                    //  element index % 4 == 0: the group's bits sit in one word)
+                                    const uint32_t el = 2u * drow.gp_lo + (uint32_t)dn;
+                                    const uint32_t w = p.mask_bits[el >> 5] >> (el & 31u);
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) keep[q] = (w >> q) & 1u;
+                                } else epi::keep4(drow, dn, p.k0, p.thr, keep);
+                            } else {
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) keep[q] = byolo_keep(idx0 + q, p.k0, p.k1, p.thr);
                             }
@@ -259,6 +271,7 @@ __device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f3
                                 const f32x4 r4 = p.addend ? *reinterpret_cast<const f32x4*>(res_row[i] + dn) : extra[j * 4 + g];
                                 v += SPLIT ? epi::split_decode4(r4) : r4;
                             }
+                            if constexpr (SPLIT) vmax = epi::absmax4(vmax, v);      // range check of the hi/lo encoding (below)
                             *reinterpret_cast<f32x4*>(d) = (SPLIT && split_out) ? epi::split_encode4(v) : v;
                         } else {
 #pragma unroll
@@ -272,6 +285,15 @@ __device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f3
     };
     if (((p.N | p.ldc) & 3) == 0) epilogue(std::true_type{});
     else epilogue(std::false_type{});
+    // Split-f16 storage ends at |x| = 65504 (epilogue.h): an output beyond it would be stored as infinity where the reference's
+    // float32 tensor (lib_yolo/layers.py:550-574) holds a number.  The lane's largest stored magnitude costs one v_max3 per two
+    // values; a hit raises the handle's sticky status word, which byolo_forward / byolo_status turn into BYOLO_ERR_RANGE.
+    if constexpr (SPLIT) {
+        if (split_out && p.status && vmax >= 65520.f) {
+            atomicOr(p.status, 1u);
+            atomicMin(p.status + 1, (unsigned)p.layer_idx);
+        }
+    }
 }
 
 // SPLIT: split-f16 operands and activations (mfma_pipe.h): sources, weights and residual are [4 hi | 4 lo] groups, three

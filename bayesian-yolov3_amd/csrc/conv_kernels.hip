@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
         for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(x[k], w[k * NOUT + n], acc[n]);
     const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
     float* d = p.dst + (size_t)m * p.ldc;
+    float vmax = 0.f;
 #pragma unroll
     for (int n = 0; n < NOUT; n += 4) {
         f32x4 v;
@@ -55,8 +56,10 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
             const float y = acc[n + q] * p.scale[n + q] + p.shift[n + q];
             v[q] = fmaxf(y, slope * y);
         }
+        vmax = epi::absmax4(vmax, v);
         *reinterpret_cast<f32x4*>(d + n) = (p.split & 2) ? epi::split_encode4(v) : v;    // split precision: [4 hi | 4 lo]
     }
+    if ((p.split & 2) && p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }   // conv_igemm.hip finish_tile
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -122,7 +125,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, co
             const int n = g * 8 + o;
             float v = acc[o] * p.scale[n];                     // scale includes 1 / (1 - p) when the masks are on
             if (p.flags & EPI_DROPOUT) {
-                if (!byolo_keep(p.idx_base + (uint64_t)m * (uint64_t)N + (uint64_t)n, p.k0, p.k1, p.thr)) v = 0.f;
+                const uint64_t el = (uint64_t)m * (uint64_t)N + (uint64_t)n;
+                const bool keep = p.mask_bits ? ((p.mask_bits[el >> 5] >> (uint32_t)(el & 31u)) & 1u)
+                                              : byolo_keep(p.idx_base + el, p.k0, p.k1, p.thr);
+                if (!keep) v = 0.f;
             }
             v += p.shift[n];
             if (p.flags & EPI_LEAKY) v = fmaxf(v, 0.1f * v);
@@ -130,8 +136,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, co
             res[o] = v;
         }
         if (out_split) {
-            for (int o = 0; o < nv; o += 4)
-                *reinterpret_cast<f32x4*>(d + o) = epi::split_encode4(f32x4{res[o], res[o + 1], res[o + 2], res[o + 3]});
+            float vmax = 0.f;
+            for (int o = 0; o < nv; o += 4) {
+                const f32x4 v{res[o], res[o + 1], res[o + 2], res[o + 3]};
+                vmax = epi::absmax4(vmax, v);
+                *reinterpret_cast<f32x4*>(d + o) = epi::split_encode4(v);
+            }
+            if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
         } else {
             for (int o = 0; o < nv; ++o) d[o] = res[o];
         }
@@ -178,13 +189,23 @@ __global__ __launch_bounds__(256) void view_gather_kernel(const ConvParams p) {
 __global__ __launch_bounds__(256) void tensor_add_kernel(const float* a, const float* b, float* d, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = a[i] + b[i];
 }
-__global__ __launch_bounds__(256) void tensor_add_split_kernel(const f32x4* a, const f32x4* b, f32x4* d, int64_t n4) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
-        d[i] = epi::split_encode4(epi::split_decode4(a[i]) + epi::split_decode4(b[i]));
+__global__ __launch_bounds__(256) void tensor_add_split_kernel(const f32x4* a, const f32x4* b, f32x4* d, int64_t n4, unsigned* status, int layer) {
+    float vmax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = epi::split_decode4(a[i]) + epi::split_decode4(b[i]);
+        vmax = epi::absmax4(vmax, v);
+        d[i] = epi::split_encode4(v);
+    }
+    if (status && vmax >= 65520.f) { atomicOr(status, 1u); atomicMin(status + 1, (unsigned)layer); }
 }
-__global__ __launch_bounds__(256) void f32_to_split_kernel(const f32x4* s, f32x4* d, int64_t n4, float mul) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
-        d[i] = epi::split_encode4(s[i] * mul);
+__global__ __launch_bounds__(256) void f32_to_split_kernel(const f32x4* s, f32x4* d, int64_t n4, float mul, unsigned* status) {
+    float vmax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = s[i] * mul;
+        vmax = epi::absmax4(vmax, v);
+        d[i] = epi::split_encode4(v);
+    }
+    if (status && vmax >= 65520.f) { atomicOr(status, 1u); atomicMin(status + 1, 0u); }   // the image itself: reported as layer 0's input
 }
 __global__ __launch_bounds__(256) void split_to_f32_kernel(const f32x4* s, f32x4* d, int64_t n4, float mul) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
@@ -195,18 +216,18 @@ hipError_t launch_view_gather(const ConvParams& p, hipStream_t st) {
     hipLaunchKernelGGL(view_gather_kernel, dim3(grid_for((int64_t)p.M * (p.C0 + p.C1))), dim3(256), 0, st, p);
     return hipGetLastError();
 }
-hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, bool split, hipStream_t st) {
+hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, bool split, hipStream_t st, unsigned* status, int layer) {
     if (split) {
         if (n & 3) return hipErrorInvalidValue;
         hipLaunchKernelGGL(tensor_add_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(a),
-                           reinterpret_cast<const f32x4*>(b), reinterpret_cast<f32x4*>(dst), n / 4);
+                           reinterpret_cast<const f32x4*>(b), reinterpret_cast<f32x4*>(dst), n / 4, status, layer);
     } else hipLaunchKernelGGL(tensor_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, b, dst, n);
     return hipGetLastError();
 }
-hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mul, hipStream_t st) {
+hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mul, hipStream_t st, unsigned* status) {
     if (n & 3) return hipErrorInvalidValue;
     hipLaunchKernelGGL(f32_to_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src),
-                       reinterpret_cast<f32x4*>(dst), n / 4, mul);
+                       reinterpret_cast<f32x4*>(dst), n / 4, mul, status);
     return hipGetLastError();
 }
 hipError_t launch_split_to_f32(const float* src, float* dst, int64_t n, float mul, hipStream_t st) {

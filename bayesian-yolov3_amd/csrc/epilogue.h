@@ -49,6 +49,12 @@ __device__ __forceinline__ f32x4 bn_act4(const f32x4 a, const f32x4 sc, const f3
 }
 
 
+// max(m, |v0|, .., |v3|): two v_max3_f32 with |.| source modifiers (a NaN operand is ignored, as maxNum does)
+__device__ __forceinline__ float absmax4(float m, const f32x4 v) {
+    m = fmaxf(fmaxf(m, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+    return fmaxf(fmaxf(m, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+}
+
 // Split-f16 storage of 4 consecutive channels (mfma_pipe.h): 16 bytes = [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3],
 // hi = RNE_f16(x), lo = RNE_f16(x - hi).  x is in the tensor's pre-scaled domain (byolo_api.hip folds the powers of two
 // into scale / shift); |x| >= 65520 overflows to infinity like any fp16.

@@ -59,6 +59,7 @@ template <int CM, bool EXACT>
 __global__ __launch_bounds__(256) void decode_std_kernel(const DecodeParams p) {
     const int C = EXACT ? CM : p.C;
     const int BLK = 5 + C, D = 5 + C;
+    const int LDC = p.ld ? p.ld : 3 * BLK;
     const int cells = p.lh * p.lw;
     const int64_t total = (int64_t)p.B * cells * 3;
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
@@ -66,10 +67,12 @@ __global__ __launch_bounds__(256) void decode_std_kernel(const DecodeParams p) {
         const int pr = (int)(gid % 3);
         const int64_t bc = gid / 3;
         const int cell = (int)(bc % cells), b = (int)(bc / cells);
-        const float* d = p.raw + (size_t)bc * (3 * BLK) + pr * BLK;
+        const float* d = p.raw + (size_t)bc * LDC + pr * BLK;
         float v[5 + CM];
+        float chk = 0.f;                                        // stays 0 unless a raw value is inf / NaN (x * 0 is NaN then)
 #pragma unroll
-        for (int i = 0; i < 5 + CM; ++i) if (EXACT || i < BLK) v[i] = d[i];
+        for (int i = 0; i < 5 + CM; ++i) if (EXACT || i < BLK) { v[i] = d[i]; chk = fmaf(v[i], 0.f, chk); }
+        if (chk != 0.f && p.status) atomicOr(p.status, 2u);
         float out[5 + CM];
         corners_(v[0], v[1], v[2], v[3], cell % p.lw, cell / p.lw, p.lw, p.lh, p.pw[pr], p.ph[pr], out);
         out[4] = sigmoidf_(v[4]);
@@ -84,6 +87,7 @@ template <int CM, bool EXACT>
 __global__ __launch_bounds__(256) void decode_ale_kernel(const DecodeParams p) {
     const int C = EXACT ? CM : p.C;
     const int BLK = 2 * (5 + C), D = 14 + C;
+    const int LDC = p.ld ? p.ld : 3 * BLK;
     const int cells = p.lh * p.lw;
     const int64_t total = (int64_t)p.B * cells * 3;
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
@@ -91,11 +95,13 @@ __global__ __launch_bounds__(256) void decode_ale_kernel(const DecodeParams p) {
         const int pr = (int)(gid % 3);
         const int64_t bc = gid / 3;
         const int cell = (int)(bc % cells), b = (int)(bc / cells);
-        const float* d = p.raw + (size_t)bc * (3 * BLK) + pr * BLK;
+        const float* d = p.raw + (size_t)bc * LDC + pr * BLK;
         // [x,y,w,h, logvar x4, obj, log_obj_std, cls xC, log_cls_std xC]   (layers.py:41-84); the stds are not decoded
         float v[10 + CM];
+        float chk = 0.f;
 #pragma unroll
-        for (int i = 0; i < 10 + CM; ++i) if (EXACT || i < 10 + C) v[i] = d[i];
+        for (int i = 0; i < 10 + CM; ++i) if (EXACT || i < 10 + C) { v[i] = d[i]; chk = fmaf(v[i], 0.f, chk); }
+        if (chk != 0.f && p.status) atomicOr(p.status, 2u);
         float out[11 + CM];
         corners_(v[0], v[1], v[2], v[3], cell % p.lw, cell / p.lw, p.lw, p.lh, p.pw[pr], p.ph[pr], out);
         float prod = 1.f;
@@ -157,25 +163,27 @@ template <int CM, bool EXACT>
 __global__ __launch_bounds__(256) void decode_epi_kernel(const DecodeParams p) {
     const int C = EXACT ? CM : p.C;
     const int BLK = 2 * (5 + C), D = 21 + C;
+    const int LDC = p.ld ? p.ld : 3 * BLK;
     const int cells = p.lh * p.lw;
     const int64_t total = (int64_t)p.B * cells * 3;
-    const size_t sample_stride = (size_t)cells * 3 * BLK;
+    const size_t sample_stride = (size_t)cells * LDC;
     const float invT = 1.0f / (float)p.T;
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
          gid += (int64_t)gridDim.x * blockDim.x) {
         const int pr = (int)(gid % 3);
         const int64_t bc = gid / 3;
         const int cell = (int)(bc % cells), b = (int)(bc / cells);
-        const float* d0 = p.raw + ((size_t)b * p.T) * sample_stride + (size_t)cell * (3 * BLK) + pr * BLK;
+        const float* d0 = p.raw + ((size_t)b * p.T) * sample_stride + (size_t)cell * LDC + pr * BLK;
         float s_loc[4] = {0, 0, 0, 0}, s_ll[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s_var[4] = {0, 0, 0, 0};
         float s_obj = 0.f, s_objH = 0.f, s_cls[CM], s_clsH = 0.f;
+        float chk = 0.f;                                        // stays 0 unless a raw value is inf / NaN
 #pragma unroll
         for (int c = 0; c < CM; ++c) s_cls[c] = 0.f;
         for (int t = 0; t < p.T; ++t) {
             const float* d = d0 + (size_t)t * sample_stride;
             float v[10 + CM];                                   // the two std logit groups are not decoded
 #pragma unroll
-            for (int i = 0; i < 10 + CM; ++i) if (EXACT || i < 10 + C) v[i] = d[i];
+            for (int i = 0; i < 10 + CM; ++i) if (EXACT || i < 10 + C) { v[i] = d[i]; chk = fmaf(v[i], 0.f, chk); }
             int q = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -193,6 +201,7 @@ __global__ __launch_bounds__(256) void decode_epi_kernel(const DecodeParams p) {
             for (int c = 0; c < CM; ++c) if (EXACT || c < C) s_cls[c] += pc[c];
             s_clsH += softmax_entropy_<CM, EXACT>(pc, C);
         }
+        if (chk != 0.f && p.status) atomicOr(p.status, 2u);
         float ev[4], cov[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) ev[i] = s_loc[i] * invT;
@@ -244,16 +253,17 @@ template <int CM, bool EXACT>
 __global__ __launch_bounds__(256) void epi_stats_kernel(const DecodeParams p, float* ev_loc, float* covar, float* obj_s, float* cls_s) {
     const int C = EXACT ? CM : p.C;
     const int BLK = 2 * (5 + C);
+    const int LDC = p.ld ? p.ld : 3 * BLK;
     const int cells = p.lh * p.lw;
     const int64_t total = (int64_t)p.B * cells * 3;
-    const size_t sample_stride = (size_t)cells * 3 * BLK;
+    const size_t sample_stride = (size_t)cells * LDC;
     const float invT = 1.0f / (float)p.T;
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
          gid += (int64_t)gridDim.x * blockDim.x) {
         const int pr = (int)(gid % 3);
         const int64_t bc = gid / 3;
         const int cell = (int)(bc % cells), b = (int)(bc / cells);
-        const float* d0 = p.raw + ((size_t)b * p.T) * sample_stride + (size_t)cell * (3 * BLK) + pr * BLK;
+        const float* d0 = p.raw + ((size_t)b * p.T) * sample_stride + (size_t)cell * LDC + pr * BLK;
         float s_loc[4] = {0, 0, 0, 0}, s_ll[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int t = 0; t < p.T; ++t) {
             const float* d = d0 + (size_t)t * sample_stride;

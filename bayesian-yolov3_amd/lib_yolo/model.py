@@ -9,6 +9,7 @@ compatibility and rejected when they ask for training (out of scope: inference p
 import contextlib
 
 from byolo import Engine, NORM_BN, NORM_DROPOUT, DET_STANDARD, DET_ALEATORIC, DET_EPISTEMIC, NMS_AGNOSTIC
+from byolo._lib import ByoloError, ERR_RANGE
 
 from lib_yolo import data
 
@@ -248,14 +249,30 @@ class Model:
         self.engine.finalize()
         return self
 
-    def run(self, img, seed=0, dropout_on=True, want_boxes=True, want_nms=True, first_image=0, out=None):
+    def run(self, img, seed=0, dropout_on=True, want_boxes=True, want_nms=True, first_image=0, out=None, mask_bits=None):
         """img: float32 CUDA tensor [B,H,W,C] in [0,1).  Returns the dict of Engine.forward and keeps
         it as `self.last`, which the DetLayer accessors read.  `first_image`: position of img[0] in the logical
-        (multi-GPU / split) batch; `out`: preallocated rows / kept / count tensors."""
+        (multi-GPU / split) batch; `out`: preallocated rows / kept / count tensors; `mask_bits`: injected dropout
+        masks (Engine.pack_masks) instead of the build-defined stream.
+
+        The reference computes in float32 (`lib_yolo/layers.py:550`), which holds any activation a trained checkpoint
+        produces.  The default split-f16 arithmetic holds |activation| <= 16376: the library detects anything beyond
+        (BYOLO_ERR_RANGE), and this wrapper then re-runs the batch -- and everything after it -- in the fp32 mode, with
+        a warning, instead of handing out rows the reference would not produce."""
         if not self.engine.finalized:
             self.engine.finalize()
-        self.last = self.engine.forward(img, T=self.T, seed=seed, dropout_on=dropout_on, want_boxes=want_boxes,
-                                        want_nms=want_nms, first_image=first_image, out=out)
+        kw = dict(T=self.T, seed=seed, dropout_on=dropout_on, want_boxes=want_boxes, want_nms=want_nms,
+                  first_image=first_image, out=out, mask_bits=mask_bits)
+        try:
+            self.last = self.engine.forward(img, **kw)
+        except ByoloError as e:
+            if e.code != ERR_RANGE or self.engine.precision != 'split' or getattr(self.engine, '_async', False):
+                raise
+            import logging
+            logging.warning('%s -- switching this model to the fp32 mode', e)
+            self.engine.set_precision('f32')
+            self.engine.finalize()
+            self.last = self.engine.forward(img, **kw)
         return self.last
 
     def matches_blueprint(self, blueprint):

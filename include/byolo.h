@@ -36,6 +36,8 @@ extern "C" {
 #define BYOLO_ERR_STATE (-2)    /* call order violated (e.g. forward before finalize)             */
 #define BYOLO_ERR_HIP (-3)      /* HIP runtime error                                              */
 #define BYOLO_ERR_NOMEM (-4)    /* workspace too small                                            */
+#define BYOLO_ERR_RANGE (-5)    /* split-f16 only: a value the reference's float32 tensors hold does not fit the
+                                   hi/lo fp16 storage (|activation| > 16376), or a raw detection output is inf / NaN   */
 
 typedef struct byolo byolo_t;
 
@@ -64,13 +66,19 @@ BYOLO_API int32_t byolo_destroy(byolo_t* h);
  *   BYOLO_PREC_F32        fp32 operands on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32), Winograd F(2x2,3x3)
  *                         for the large 3x3 convolutions;
  *   BYOLO_PREC_SPLIT_F16  every activation / weight as hi + lo, two fp16 values (~23 significant bits), three fp16
- *                         matrix products per fp32 product into fp32 accumulators (v_mfma_f32_32x32x16_f16); an
- *                         activation beyond +-16376 overflows (fp16 range / 4).
+ *                         matrix products per fp32 product into fp32 accumulators (v_mfma_f32_32x32x16_f16).  Weights
+ *                         carry one exact power-of-two scale per OUTPUT CHANNEL (folded into the BN scale), so a filter
+ *                         far smaller than its neighbours keeps its bits.  Activations are stored as 4 * value: one
+ *                         beyond +-16376 does not fit -- that is DETECTED (byolo_status), never stored silently: see
+ *                         BYOLO_ERR_RANGE and byolo_set_async below.
  * Default: environment BYOLO_PRECISION = f32 | split, else BYOLO_PREC_SPLIT_F16.  Call before byolo_finalize (a finalized
- * handle must be finalized again). */
+ * handle must be finalized again).  byolo_finalize itself falls back to BYOLO_PREC_F32 for a graph split storage cannot
+ * express (a convolution whose output channels are not a multiple of 4 -- no reference model has one):
+ * byolo_get_precision reports the mode in effect, byolo_precision_note why ("" if the request stands). */
 enum { BYOLO_PREC_F32 = 0, BYOLO_PREC_SPLIT_F16 = 1 };
 BYOLO_API int32_t byolo_set_precision(byolo_t* h, int32_t precision);
 BYOLO_API int32_t byolo_get_precision(const byolo_t* h);
+BYOLO_API const char* byolo_precision_note(const byolo_t* h);
 BYOLO_API const char* byolo_last_error(const byolo_t* h);
 BYOLO_API const char* byolo_version(void);
 
@@ -137,10 +145,31 @@ BYOLO_API int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t
  *   d_kept    [B,max_out*(1|2)]     int32 global box indices of the kept rows
  *   d_count   [B,2]                 int32 {total kept, kept in first class (== total if agnostic)}
  * seed: dropout stream (see csrc/byolo_rng.h); dropout is active iff the layer has
- * BYOLO_NORM_DROPOUT and `dropout_on` != 0 (standard_test_dropout=True quirk, layers.py:567-568). */
+ * BYOLO_NORM_DROPOUT and `dropout_on` != 0 (standard_test_dropout=True quirk, layers.py:567-568).
+ * d_mask_bits (nullable): INJECTED dropout masks instead of the library's counter stream -- tf.layers.dropout draws
+ *   its Bernoulli noise from an unseeded op (layers.py:521-524), so a caller that wants the reference's masks (or its
+ *   own) passes them: one bit per element of each dropout layer's input [S,h,w,cout] of THIS call (S = B*T in the
+ *   stacked part of the graph), 1 = keep, layer after layer at the bit offsets of byolo_mask_layout.
+ * Numeric status (split precision): unless byolo_set_async(h, 1), the call waits for the stream and returns
+ *   BYOLO_ERR_RANGE -- never rows of inf / NaN -- when an activation left the split-f16 range; outputs are then undefined. */
 BYOLO_API int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
-                      void* d_workspace, size_t workspace_bytes,
+                      const uint32_t* d_mask_bits, void* d_workspace, size_t workspace_bytes,
                       float* d_boxes, float* d_rows, int32_t* d_kept, int32_t* d_count, void* stream);
+/* Dropout layers of the graph (creation order = the `ordinal` of csrc/byolo_rng.h), and where layer `ordinal`'s bits sit in
+ * d_mask_bits for a (B, T) call: bit_offset (a multiple of 32) and element count S*h*w*cout; ordinal == byolo_num_dropout
+ * returns the total length in bits (a multiple of 32) in bit_offset. */
+BYOLO_API int32_t byolo_num_dropout(const byolo_t* h);
+BYOLO_API int32_t byolo_mask_layout(byolo_t* h, int32_t B, int32_t T, int32_t ordinal, int64_t* bit_offset, int64_t* elements);
+/* Numeric status of the handle's forwards in BYOLO_PREC_SPLIT_F16.  Every epilogue that encodes an activation tracks the
+ * largest magnitude it stores, every decode launch checks the raw detection outputs; a hit raises a sticky device word:
+ *   flags bit 0  an activation beyond the split-f16 range in layer `layer` (the first such layer; -1 otherwise)
+ *   flags bit 1  a raw detection output is inf / NaN
+ * byolo_status WAITS for `stream`, returns BYOLO_OK or BYOLO_ERR_RANGE (message: the layer's scope) and leaves the words
+ * set; byolo_clear_status resets them (asynchronously, on `stream`).  byolo_set_async(h, 1): byolo_forward no longer waits
+ * and checks -- a caller that synchronises anyway (to copy rows to the host) asks byolo_status once there.  Default 0. */
+BYOLO_API int32_t byolo_set_async(byolo_t* h, int32_t on);
+BYOLO_API int32_t byolo_status(byolo_t* h, void* stream, uint32_t* flags, int32_t* layer);
+BYOLO_API int32_t byolo_clear_status(byolo_t* h, void* stream);
 /* The dropout stream is indexed by the element index in the [S,h,w,c] tensor, S = images*T.  When one logical
  * batch is processed in several calls (sub-batches that respect byolo_max_images, or one shard per GPU), tell
  * every call where its first image sits in the logical batch: image j of the call then draws the masks of image
