@@ -47,3 +47,51 @@ def synthetic_images(B, H, W, C=3, seed=1234, first_index=0):
     for b in range(B):
         imgs[b] = np.random.default_rng(seed + first_index + b).random((H, W, C), dtype=np.float32)
     return imgs
+
+
+ADVERSARIAL_KINDS = ("scales", "tails")
+
+
+def adversarial_params(shapes, variant, cls_cnt, kind, seed=7):
+    """Weights a TRAINED checkpoint may hold and the friendly recipe above never does (tests/test_robustness.py).  Still a
+    sane network once its BN statistics are calibrated on data -- what changes is the dynamic range INSIDE a layer:
+
+      'scales'  every output channel's filter is multiplied by 2^U(-10, 10): the conv output's variance spans 1e-6 .. 1e6
+                across the channels of one layer (BN's moving variance absorbs it), gamma is log-uniform in [0.05, 50],
+                beta ~ N(0, 1);
+      'tails'   Student-t (3 degrees of freedom) filters -- a few weights 10..50 sigma out -- and gamma = 250 on every
+                fourth BN'd layer, which drives activations to 1e3 .. 1e4 (the split-f16 storage ends at 16376).
+
+    The layer in front of a detection head keeps gamma 1 / beta 0 and the detection kernels / biases keep the friendly
+    recipe, so logits stay in a range where float32 evaluations agree.  Returns {name: float32}."""
+    assert kind in ADVERSARIAL_KINDS, kind
+    out = base_params(shapes, variant, cls_cnt, seed=seed)
+    names = list(shapes)
+    kernels = [n for n in names if n.endswith("/conv2d/kernel") and "/detection/" not in n]
+    # a conv layer feeds a detection head iff its scope is the last BN'd one of its det_net_* scope
+    last_of_head = set()
+    for head in ("det_net_1", "det_net_2", "det_net_3"):
+        hk = [n for n in kernels if n.startswith(head + "/")]
+        if hk:
+            last_of_head.add(hk[-1].rsplit("/conv2d/kernel", 1)[0])
+    for li, kn in enumerate(kernels):
+        scope = kn.rsplit("/conv2d/kernel", 1)[0]
+        g = np.random.default_rng([int(seed), zlib.crc32(("adv:" + kn).encode())])
+        k, _, cin, cout = shapes[kn]
+        w = out[kn].astype(np.float64)
+        gam = np.ones(cout)
+        bet = np.zeros(cout)
+        if kind == "scales":
+            w = w * np.exp2(g.uniform(-10.0, 10.0, size=cout))[None, None, None, :]
+            if scope not in last_of_head:
+                gam = np.exp(g.uniform(np.log(0.05), np.log(50.0), size=cout))
+                bet = g.standard_normal(cout)
+        else:
+            t = g.standard_t(3.0, size=w.shape) / np.sqrt(3.0)            # unit variance
+            w = t * np.sqrt(1.0 / (k * k * cin))
+            if scope not in last_of_head and li % 4 == 1:
+                gam = np.full(cout, 250.0)
+        out[kn] = w.astype(np.float32)
+        out[scope + "/batch_normalization/gamma"] = gam.astype(np.float32)
+        out[scope + "/batch_normalization/beta"] = bet.astype(np.float32)
+    return out

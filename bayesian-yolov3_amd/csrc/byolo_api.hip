@@ -227,6 +227,7 @@ extern "C" int32_t byolo_set_precision(byolo_t* h, int32_t precision) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_set_precision: null handle");
     if (precision != BYOLO_PREC_F32 && precision != BYOLO_PREC_SPLIT_F16) return fail(h, BYOLO_ERR_ARG, "byolo_set_precision: unknown precision %d", precision);
     h->prec_requested = precision;
+    if (precision == BYOLO_PREC_F32) h->prec_note.clear();          // asked for, not fallen back to
     if (precision != h->precision) { h->precision = precision; h->prec_note.clear(); h->finalized = false; h->plan.B = -1; h->plan.T = -1; }
     return BYOLO_OK;
 }
@@ -724,7 +725,14 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
                 for (size_t r = 0; r < rows; ++r) mx = std::max(mx, std::fabs(k.data[r * N + n]));
                 int e = 0;
                 if (mx > 0.f) (void)std::frexp(mx, &e);            // mx = m * 2^e, m in [0.5, 1)
-                l.wshift[n] = mx > 0.f ? std::min(100, std::max(-100, 14 - e)) : 0;
+                l.wshift[n] = mx > 0.f ? std::min(126, std::max(-126, 14 - e)) : 0;      // 2^shift and 2^-shift are normal floats
+            }
+            // BYOLO_WSHIFT_PER_LAYER=1 (A/B in tests/test_robustness.py): one shift per layer, from the layer's largest weight
+            const char* ple = getenv("BYOLO_WSHIFT_PER_LAYER");
+            if (ple && atoi(ple)) {
+                int lo = 127;
+                for (int n = 0; n < N; ++n) { bool any = false; for (size_t r = 0; r < rows && !any; ++r) any = k.data[r * N + n] != 0.f; if (any) lo = std::min(lo, l.wshift[n]); }
+                l.wshift.assign((size_t)N, lo == 127 ? 0 : lo);
             }
         }
     }

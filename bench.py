@@ -10,28 +10,27 @@ Darknet-53 once per image, the three heads on B*T MC samples (dropout masks from
 per-box T-reduction + decode, sort + NMS, and (N > 1) ONE RCCL all-gather of the padded box lists.
 Weights are random-init with BN statistics calibrated on the device (no checkpoints, no network).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel = the matrix-pipe kernel with the most
-device time in the timed region (`by_kernel` lists all of them): in the default precision (split-f16: every operand as
-hi + lo fp16 pairs, three fp16 matrix products per fp32 product, fp32 accumulation -- DESIGN.md section 5) the
-shared-tap 3x3 kernel conv_igemm_kernel<128,128,1,4,kx3>, priced against the fp16 matrix peak / 3; under
-BYOLO_PRECISION=f32 the fused Winograd-domain GEMM, priced against the fp32 matrix peak.  Its
-launches timed with hipEvents recorded around every launch on the launch stream (byolo_step_profile; the records of
-all K steps are read AFTER the timed region -- no host synchronisation inside it).  One definition:
+Prints ONE JSON line on rank 0.  `roofline` follows SURVEY.md section 8(d) for the dominant kernel = the matrix-pipe
+kernel with the most device time in the timed region (`by_kernel` lists all of them):
 
-  achieved / frac        USEFUL matrix-pipe FLOP/s of those launches / the fp32 MFMA peak.  Useful = the multiplies the
-                         algorithm needs for the outputs it delivers: 2*M*N*K of a direct convolution launch; for a
-                         Winograd-domain GEMM launch the direct-convolution FLOPs of its samples / 2.25 (F(2x2,3x3):
-                         16 multiplies per 2x2 outputs instead of 36) -- tile padding (19x19 -> 20x20, rows to 128) is
-                         NOT counted as work;
-  frac_executed_padded   what the matrix pipe executed (2*M*N*K of the padded extents) / peak;
-  achieved_algorithmic   the same launches priced by the direct-convolution FLOPs they stand for (SURVEY.md 8d's
-                         per-image figure is made of these); `end_to_end_frac` = img/s * F(H,W,T) / peak is 8d's formula
-                         for the whole step.  Both exceed 1 where Winograd runs: they are not utilisations;
-  traffic                L2<->fabric bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes over
-                         this command (tools/pmc_traffic.py -> profiles/traffic_cfgN.json, stamped with the commit it
-                         was measured at: `traffic_measured_at`), `traffic_vs_algorithmic` = that / (V once + output
-                         once + weights once).
-`cpu_baseline` is the oracle's CPU restatement (PyTorch/oneDNN, NOT TensorFlow) on a bounded sample.
+  achieved               USEFUL fp32-equivalent FLOP/s of its launches: 2*M*N*K of a direct convolution launch (for a
+                         Winograd-domain GEMM launch of the fp32 mode the direct-convolution FLOPs of its samples / 2.25);
+                         tile padding is not work.  Time = hipEvents recorded around every launch ON THE LAUNCH STREAM
+                         (byolo_step_profile; the records of all K steps are read AFTER the timed region);
+  peak / frac            the dense peak of the matrix instruction the kernel issues, every useful FLOP counted ONCE: 2500
+                         TFLOP/s (v_mfma_f32_32x32x16_f16) for the split-f16 kernels of the default precision -- which
+                         execute three fp16 products per fp32 product, so a split kernel cannot exceed frac 1/3 -- and 157.3
+                         (v_mfma_f32_32x32x2_f32) for the fp32 mode;
+  frac_executed_vs_fp16_peak   (split kernels) the executed fp16 products / 2500: the utilisation of the pipe itself;
+  traffic                L2<->fabric bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE /
+                         WRITE_SIZE passes over this command (tools/profile_round.sh, tools/pmc_traffic.py ->
+                         profiles/traffic_cfgN.json, stamped with the commit they were measured at), reads and writes
+                         separately, each beside its algorithmic byte count (`read_amplification`, `write_amplification`).
+
+`fp32_mode`: the same workload timed in the same run under BYOLO_PREC_F32 (the reference's own arithmetic, lib_yolo/layers.py:550)
+on a second handle: a few steps after the headline region.  `cpu_baseline` is the oracle's CPU restatement (PyTorch/oneDNN, NOT
+TensorFlow) on a bounded sample; the same oracle rows give `parity_note`: the device's distance from the float32 oracle per
+column group, in units of the bound 1e-4 * max(1, |ref|), on image 0 of the benchmark's own batch.
 """
 import argparse
 import json
@@ -59,7 +58,7 @@ PEAK_F16_MFMA = 2500e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, d
 SUSTAINED_F16_MFMA = 1756e12
 
 
-def build(cfg, device):
+def build(cfg, device, precision=None):
     from lib_yolo import yolov3, model
     from byolo import synth
     import torch
@@ -69,6 +68,8 @@ def build(cfg, device):
     yolo = getattr(yolov3, cfg["variant"])(config)
     m = yolo.init_model(inputs=model.Placeholder((None, cfg["H"], cfg["W"], 3)), training=False).get_model()
     eng = m.engine
+    if precision is not None:
+        eng.set_precision(precision)
     eng.set_params(synth.base_params(eng.param_shapes(), cfg["variant"], 2, seed=7))
     eng.finalize()
     calib = torch.from_numpy(synth.synthetic_images(2, cfg["H"], cfg["W"], seed=999)).to("cuda:%d" % device)
@@ -92,11 +93,58 @@ def cpu_baseline(cfg, params, n_img=1):
     t0 = time.time()
     with torch.no_grad():
         boxes, _ = cpu_ref.detect_boxes(tp, imgs, cfg["variant"], T=cfg["T"], seed=42)
-        cpu_ref.nms_batch(boxes, cfg["variant"], two_class=bool(cfg["nms"]))
+        kept = cpu_ref.nms_batch(boxes, cfg["variant"], two_class=bool(cfg["nms"]))
     dt = time.time() - t0
     return {"value": n_img / dt, "unit": "img/s", "cores": cores, "kind": "port",
             "sample": "%d image(s) %dx%d T=%d, CPU restatement (PyTorch/oneDNN fp32, not TensorFlow), %.1f s"
-                      % (n_img, cfg["H"], cfg["W"], cfg["T"], dt)}
+                      % (n_img, cfg["H"], cfg["W"], cfg["T"], dt)}, boxes.numpy(), kept
+
+
+def parity_note(cfg, eng, x, oracle_rows, oracle_kept):
+    """The oracle rows of the cpu_baseline leg (image 0 of the benchmark batch, dropout seed 42) against one more device
+    forward of the SAME batch with that seed: worst distance per column group in units of the bound, kept indices."""
+    import numpy as np
+    from oracle import report
+    r = eng.forward(x, T=cfg["T"], seed=42, want_boxes=True, want_nms=True, first_image=0)
+    got = r["boxes"][:1].cpu().numpy()
+    n = int(r["count"][0, 0])
+    rep = report.rows_report(got, oracle_rows[:1], cfg["variant"])
+    return {"compared": "image 0 of the benchmark batch, all %d pre-NMS rows, dropout seed 42; device (%s) vs the float32 oracle"
+                        % (got.shape[1], eng.precision),
+            "bound": "1e-4 * max(1, |ref|)", "worst_in_bounds": {k: round(v["worst_in_bounds"], 3) for k, v in rep.items()},
+            "max_abs_err": {k: float("%.3g" % v["max_abs_err"]) for k, v in rep.items()},
+            "nan_inf_pattern_equal": bool(np.array_equal(np.isfinite(got), np.isfinite(oracle_rows[:1]))),
+            "kept_indices_equal_oracle_nms_of_oracle_rows": bool(n == len(oracle_kept[0][1]) and
+                                                                 np.array_equal(r["kept"][0, :n].cpu().numpy(), oracle_kept[0][1]))}
+
+
+def time_steps(eng, x, cfg, steps, warmup, first_image=0):
+    """warmup + `steps` forwards of the batch on the current stream with per-launch hipEvents; returns (seconds, {variant: [useful
+    flops, ms, launches]}).  Used for the fp32_mode leg."""
+    import torch
+    eng.set_async(True)
+    eng.set_profiling(2)
+    for i in range(warmup):
+        eng.forward(x, T=cfg["T"], seed=2000 + i, want_boxes=False, want_nms=True, first_image=first_image)
+    n_sub = -(-int(x.shape[0]) // eng.max_images(cfg["T"]))
+    eng.set_profile_depth(steps * n_sub)
+    eng.set_profiling(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.forward(x, T=cfg["T"], seed=2000 + warmup + i, want_boxes=False, want_nms=True, first_image=first_image)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    acc = {}
+    for age in range(steps * n_sub):
+        eng.select_profile(age)
+        for s in eng.step_profile():
+            a = acc.setdefault(s["variant"], [0.0, 0.0, 0])
+            a[0] += s["flops"] / 2.25 if s["variant"] in (129, 130) else s["flops"]
+            a[1] += s["ms"]; a[2] += 1
+    eng.select_profile(0)
+    eng.set_profiling(0)
+    return dt, acc
 
 
 def main():
@@ -113,7 +161,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch hipEvents in the timed region")
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many concurrent HIP streams")
-    ap.add_argument("--pipeline", type=int, default=1, help="[experiment] alternate whole steps over this many HIP streams")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="alternate whole steps over this many HIP streams (own workspace and output buffers each): the latency-bound "
+                         "tail of step i (decode, sort, NMS) overlaps the convolutions of step i+1.  1 = one stream")
+    ap.add_argument("--fp32-steps", type=int, default=5, help="timed steps of the fp32_mode leg (0 = skip it)")
     ap.add_argument("--no-dropout", action="store_true",
                     help="[experiment, not the metric] skip the dropout masks: isolates the epilogue's RNG cost")
     ap.add_argument("--dump-steps", default=None, help="write the per-launch table (layer, variant, M, N, K, ms, TF/s) here")
@@ -126,7 +177,12 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (MI355X); there is no CPU path in the product")
     rank, local, world = bdist.init()
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % args.gpus
+    if world != args.gpus:        # a mis-launch must not produce a line that looks like an N-GPU number
+        sys.exit("bench.py --gpus %d, but WORLD_SIZE=%d: launch N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                 "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...` (one rank per GPU), N = 1 as plain `python bench.py`"
+                 % (args.gpus, world, args.gpus, args.gpus))
+    if world > 1 and local >= torch.cuda.device_count():
+        sys.exit("rank %d: LOCAL_RANK=%d but only %d GPUs are visible" % (rank, local, torch.cuda.device_count()))
     device = local if world > 1 else 0
     pg = dist.is_initialized()         # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
     torch.cuda.set_device(device)
@@ -139,6 +195,9 @@ def main():
         cfg["B"] = args.global_batch // world
     m = build(cfg, device)
     eng = m.engine
+    # the timed region must not wait inside byolo_forward: the split-f16 range status (include/byolo.h: byolo_status) is
+    # read ONCE, after the run, and a raised status invalidates the line
+    eng.set_async(True)
     B, T = cfg["B"], cfg["T"]
     x = torch.from_numpy(synth.synthetic_images(B, cfg["H"], cfg["W"], seed=1234, first_index=rank * B)).to("cuda:%d" % device)
     N, D = eng.num_boxes()
@@ -188,7 +247,10 @@ def main():
             return bdist.allgather_boxes(r["rows"], r["kept"], r["count"], world)
         return r["rows"], r["kept"], r["count"]
 
-    prof = not args.no_profile and nstreams == 1 and npipe == 1    # the handle's event set belongs to one forward at a time
+    # per-launch hipEvents: every forward owns one record slot of the handle's ring (byolo_set_profile_depth) and records its
+    # events on ITS stream, so pipelined steps keep their own timings (a launch's time then includes what it shares with the
+    # other stream's tail kernels)
+    prof = not args.no_profile and nstreams == 1
     eng.set_profiling(2 if prof else 0)          # on during the warm-up as well: the event pools exist before the timed region
     for i in range(args.warmup):
         step(i)
@@ -196,7 +258,7 @@ def main():
     if prof:
         eng.set_profile_depth(args.steps * n_sub)   # every step's launch records stay readable until after the run
     eng.set_profiling(2 if prof else 0)
-    acc = {}                      # variant -> [algorithmic flops, ms, launches, executed flops, useful flops, algorithmic bytes]
+    acc = {}                      # variant -> [algorithmic flops, ms, launches, executed flops, useful flops, algorithmic read bytes, algorithmic write bytes]
     per_launch = {}
     stage = {"backbone": 0.0, "heads": 0.0, "decode": 0.0, "sort_nms": 0.0}
     if pg:
@@ -220,20 +282,37 @@ def main():
         for age in range(args.steps * n_sub - 1, -1, -1):
             eng.select_profile(age)
             for j, s in enumerate(eng.step_profile()):
-                a = acc.setdefault(s["variant"], [0.0, 0.0, 0, 0.0, 0.0, 0.0])
+                a = acc.setdefault(s["variant"], [0.0, 0.0, 0, 0.0, 0.0, 0.0, 0.0])
                 wino = s["variant"] in WINO
                 a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1; a[3] += s["flops_executed"]
                 a[4] += s["flops"] / 2.25 if wino else s["flops"]
                 # algorithmic bytes of the launch: A operand once + result once + weights once
                 # (a shared-tap 3x3 launch reads its input once: M * K / 9 elements, not the im2col matrix)
-                a[5] += 4.0 * ((s["M"] * s["K"] + (s["M"] // 4) * s["N"] + 16 * s["K"] * s["N"]) if s["variant"] == 130 else
-                               (s["M"] * s["K"] // 9 + s["M"] * s["N"] + s["K"] * s["N"]) if s["variant"] in (3128, 3064) else
-                               (s["M"] * s["K"] + s["M"] * s["N"] + (16 if wino else 1) * s["K"] * s["N"]))
+                # (input once + weights once | result once)
+                a[5] += 4.0 * ((s["M"] * s["K"] + 16 * s["K"] * s["N"]) if s["variant"] == 130 else
+                               (s["M"] * s["K"] // 9 + s["K"] * s["N"]) if s["variant"] in (3128, 3064) else
+                               (s["M"] * s["K"] + (16 if wino else 1) * s["K"] * s["N"]))
+                a[6] += 4.0 * ((s["M"] // 4) * s["N"] if s["variant"] == 130 else s["M"] * s["N"])
                 if args.dump_steps:
                     per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / args.steps
             for k, v in eng.stage_ms().items():
                 stage[k] += v
         eng.select_profile(0)
+    # per-rank diagnostics for the N > 1 line: which device ran which block of the global batch, and a checksum of the last
+    # step's kept indices (a wrong shard or a rank on the wrong GPU shows up as a duplicate / missing first_image or checksum)
+    last = step(args.warmup + args.steps)
+    torch.cuda.synchronize()
+    g_kept, g_count = last[1], last[2]
+    cs = [int((g_kept[b].to(torch.int64).clamp(min=0) * torch.arange(1, g_kept.shape[1] + 1, device=g_kept.device)).sum().item() % 1000003)
+          for b in range(g_kept.shape[0])]
+    mine = {"rank": rank, "device": "cuda:%d (%s)" % (device, torch.cuda.get_device_name(device)), "first_image": rank * B, "images": B}
+    ranks = [None] * world
+    if pg:
+        dist.all_gather_object(ranks, mine)
+    else:
+        ranks = [mine]
+    range_flags, range_layer = eng.status()
+    assert range_flags == 0, "an activation left the split-f16 range during the benchmark (layer %d): the number would be invalid" % range_layer
     if rank == 0:
         imgs = world * B * args.steps
         flops_img = eng.flops(1, T)
@@ -241,6 +320,7 @@ def main():
             "metric": "img/s at T=%d MC-dropout, %dx%d" % (T, cfg["H"], cfg["W"]),
             "value": imgs / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "ranks": ranks, "kept_checksum_per_image_of_one_more_step": cs,
             "vs_baseline": None, "dtype": "f32" if eng.precision == "f32" else "f32 via split-f16 (hi+lo fp16 pairs, 3 fp16 MFMA products, fp32 accumulate)", "data": "synthetic" + (" [EXPERIMENT: dropout off, invalid]" if args.no_dropout else ""),
             "config": {"workload": "%s: %s %dx%d T=%d, %d images/GPU (global batch %d), "
                                    "class-%s NMS max_out=1000, random-init weights with device-calibrated BN"
@@ -249,12 +329,15 @@ def main():
                                       "wise 2-class" if cfg["nms"] else "agnostic"),
                        "images_per_gpu": B, "T": T, "img_size": [cfg["H"], cfg["W"]], "parallelism": "dp%d" % world,
                        "gflop_per_image": flops_img / 1e9, "precision": eng.precision,
-                       "precision_note": ("split-f16: every activation / weight as hi + lo fp16 (23 significant bits, half an fp32 ulp of "
-                                          "representation error), products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 into fp32 "
-                                          "accumulators (the instruction sums its 16 products before one rounding); on the device closer to the "
-                                          "float64 oracle than the float32 oracle is, 1e-4 contract held in every parity test (DESIGN.md "
-                                          "sections 0, 5; tests/test_gpu_bench_shapes.py); BYOLO_PRECISION=f32 runs the fp32 matrix "
-                                          "instruction instead (181.8 img/s at this config)") if eng.precision == "split" else
+                       "precision_note": ("split-f16: every activation / weight as hi + lo fp16 (23 significant bits; fp32 has 24), one exact "
+                                          "power-of-two scale per output channel of every filter bank, products hi*hi + hi*lo + lo*hi on "
+                                          "v_mfma_f32_32x32x16_f16 into fp32 accumulators.  Narrower than the reference's float32 in RANGE: an "
+                                          "activation beyond +-16376 is detected and reported as BYOLO_ERR_RANGE (`range_status`; the entry points "
+                                          "then re-run in the fp32 mode), never stored.  Accuracy: output rows within the 1e-4 bound of the float32 "
+                                          "oracle at this shape (`parity_note`, measured in this run); deep intermediate taps of small networks sit "
+                                          "at 0.97 - 1.08 of that bound from the float32 fixtures while being closer to the float64 oracle than those "
+                                          "fixtures are (tests/test_gpu_parity.py, DESIGN.md section 5).  `fp32_mode` times the reference's own "
+                                          "arithmetic in this run") if eng.precision == "split" else
                                          "fp32 operands on v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) on the large 3x3 layers"},
         }
         SPLIT = (3128, 3064, 1128, 1064, 1032)
@@ -275,61 +358,90 @@ def main():
             # a Winograd-domain GEMM launch executes 1/2.25 of the direct-convolution FLOPs it stands for (x tile padding),
             # and its transforms are separate, HBM-bound launches.
             dom = max(mm, key=lambda v: acc[v][1])
-            f, ms, n, fx, fu, ab = acc[dom]
+            f, ms, n, fx, fu, abr, abw = acc[dom]
             tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for a in acc.values())
             ach = fu / (ms * 1e-3)
             split = dom in SPLIT
-            peak = PEAK_F16_MFMA / 3.0 if split else PEAK_FP32_MFMA
+            # peak of the matrix instruction actually issued, useful FLOPs counted once
+            peak = PEAK_F16_MFMA if split else PEAK_FP32_MFMA
             wino_ms = sum(acc[v][1] for v in (-2, -3) if v in acc)
-            # HBM/fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes
-            # over this same command (tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent
-            traffic = measured_at = None
+            # fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same command
+            # (tools/profile_round.sh + tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent / another kernel
+            traffic = tr_read = tr_write = measured_at = None
             tpath = os.path.join(REPO, "profiles", "traffic_cfg%d.json" % args.config)
             if os.path.exists(tpath) and not args.batch and args.scaling == "weak":
                 tj = json.load(open(tpath))
-                # the counter passes must be of THIS kernel (template arguments as rocprofv3 prints them)
                 want = {3128: "conv_igemm_kernel<128, 128, 1, 4, true, true, true>", 3064: "conv_igemm_kernel<128, 64, 2, 2, true, true, true>",
                         130: "wino_fused_kernel", 129: "gemm_stream_kernel", 128: "conv_igemm_kernel<128, 128, 2, 2"}.get(dom)
                 if want and tj.get("kernel", "").startswith(want.split(",")[0]) and (want in tj.get("kernel", "") or tj.get("kernel", "") in want):
                     traffic = tj.get("traffic_bytes_per_launch")
+                    tr_read, tr_write = tj.get("read_bytes_per_launch"), tj.get("write_bytes_per_launch")
                     measured_at = tj.get("measured_at")
+            ab_r, ab_w = abr / n, abw / n
             line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                                "frac": ach / peak, "traffic": traffic, "traffic_measured_at": measured_at,
-                                "algorithmic_bytes_per_launch": ab / n,
-                                "traffic_vs_algorithmic": (traffic / (ab / n)) if traffic else None,
+                                "frac": ach / peak,
+                                "traffic": traffic, "traffic_read": tr_read, "traffic_write": tr_write, "traffic_measured_at": measured_at,
+                                "algorithmic_bytes_per_launch": ab_r + ab_w,
+                                "algorithmic_read_bytes_per_launch": ab_r, "algorithmic_write_bytes_per_launch": ab_w,
+                                "traffic_vs_algorithmic": (traffic / (ab_r + ab_w)) if traffic else None,
+                                "read_amplification": (tr_read / ab_r) if tr_read else None,
+                                "write_amplification": (tr_write / ab_w) if tr_write else None,
                                 "kernel": KERNELS[dom],
                                 "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
-                                "definition": "achieved = useful fp32-equivalent FLOPs (direct: 2MNK; Winograd-domain GEMM: direct-convolution "
-                                              "FLOPs of its samples / 2.25, tile padding not counted) / hipEvent time of the launches; peak = "
-                                              + ("fp16 MFMA dense peak 2500 / 3 (three fp16 products per fp32 product)" if split else "fp32 MFMA dense peak"),
+                                "definition": "SURVEY.md 8(d): achieved = useful fp32-equivalent FLOPs (direct launch: 2MNK; Winograd-domain GEMM of "
+                                              "the fp32 mode: direct-convolution FLOPs of its samples / 2.25; tile padding not counted), each counted ONCE, "
+                                              "/ hipEvent time of the launches on their launch stream; peak = dense peak of the matrix instruction issued ("
+                                              + ("v_mfma_f32_32x32x16_f16, 2500: a split-f16 kernel executes three fp16 products per useful product, so its "
+                                                 "frac cannot exceed 1/3" if split else "v_mfma_f32_32x32x2_f32, 157.3") + ")",
                                 "achieved_executed_padded": fx / (ms * 1e-3) / 1e12,
-                                "frac_executed_padded": fx / (ms * 1e-3) / peak,
-                                # the same launches priced by the direct-convolution FLOPs they stand for (SURVEY 8d's
-                                # per-image figure is made of these): not a matrix-pipe utilisation where Winograd runs
-                                "achieved_algorithmic": f / (ms * 1e-3) / 1e12,
                                 "share_of_conv_time": ms / tot_ms, "winograd_transform_share_of_conv_time": wino_ms / tot_ms,
-                                # algorithmic (direct-convolution) FLOPs of the whole conv stack / its time, transforms
-                                # included: exceeds what the matrix pipe executes where Winograd F(2x2,3x3) is used
+                                # algorithmic (direct-convolution) FLOPs of the whole conv stack / its time, transforms included
                                 "all_conv_algorithmic": tot_f / (tot_ms * 1e-3) / 1e12,
                                 "by_kernel": {KERNELS[v].split(" ")[0]: {"launches": acc[v][2], "ms": acc[v][1],
                                                                           "useful_tflops": acc[v][4] / (acc[v][1] * 1e-3) / 1e12,
                                                                           "executed_tflops": acc[v][3] / (acc[v][1] * 1e-3) / 1e12}
                                               for v in sorted(mm, key=lambda v: -acc[v][1])},
+                                # 8(d)'s formula for the whole step: img/s * F(H,W,T) / (n_gpu * peak); and against the fp32 MFMA peak the
+                                # reference's own arithmetic would be priced at (> 1 = beyond that instruction's ceiling)
                                 "end_to_end_frac": (imgs / dt) * flops_img / (world * peak),
                                 "end_to_end_vs_fp32_mfma_peak": (imgs / dt) * flops_img / (world * PEAK_FP32_MFMA)}
             if split:
-                line["roofline"].update({"fp16_executed_tflops": 3.0 * fx / (ms * 1e-3) / 1e12, "fp16_peak_tflops": PEAK_F16_MFMA / 1e12,
+                line["roofline"].update({"frac_executed_vs_fp16_peak": 3.0 * fx / (ms * 1e-3) / PEAK_F16_MFMA,
+                                         "fp16_executed_tflops": 3.0 * fx / (ms * 1e-3) / 1e12,
                                          "fp16_sustained_under_power_cap_tflops": SUSTAINED_F16_MFMA / 1e12,
-                                         "frac_of_sustained": 3.0 * fu / (ms * 1e-3) / SUSTAINED_F16_MFMA,
-                                         # BASELINE.md section 3's strictest reading: fp32-equivalent FLOPs counted ONCE against the fp16 peak
-                                         "frac_counted_once_vs_fp16_peak": ach / PEAK_F16_MFMA})
+                                         "frac_executed_of_sustained": 3.0 * fu / (ms * 1e-3) / SUSTAINED_F16_MFMA})
+            if npipe > 1:
+                line["roofline"]["note"] = ("steps alternate over %d HIP streams: a launch's hipEvent time includes what it shares with the other "
+                                            "stream's tail kernels (decode, sort, NMS)" % npipe)
             line["stage_ms_per_step"] = {k: v / args.steps for k, v in stage.items()}
+        # the reference's own arithmetic (float32, lib_yolo/layers.py:550) timed in the SAME run: a second handle in BYOLO_PREC_F32
+        # on the same batch, a few steps on one stream after the headline region (the headline engine stays alive: its weights)
+        if world == 1 and args.fp32_steps > 0 and eng.precision != "f32" and not args.batch and args.scaling == "weak":
+            try:
+                m32 = build(cfg, device, precision="f32")
+                dt32, acc32 = time_steps(m32.engine, x, cfg, args.fp32_steps, 2)
+                d32 = max((v for v in acc32 if v in KERNELS), key=lambda v: acc32[v][1])
+                a32 = acc32[d32][0] / (acc32[d32][1] * 1e-3)
+                line["fp32_mode"] = {"value": B * args.fp32_steps / dt32, "unit": "img/s", "ms_per_step": 1e3 * dt32 / args.fp32_steps,
+                                     "steps": args.fp32_steps, "warmup": 2, "streams": 1, "precision": m32.engine.precision,
+                                     "dtype": "f32 (v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) on the large 3x3 layers)",
+                                     "dominant_kernel": KERNELS[d32], "launches": acc32[d32][2],
+                                     "achieved": a32 / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "frac": a32 / PEAK_FP32_MFMA,
+                                     "headline_speedup_over_fp32_mode": (imgs / dt) / (B * args.fp32_steps / dt32)}
+                m32.engine.close()
+                del m32
+            except Exception as e:
+                line["fp32_mode"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(cfg, eng.get_params())
+                line["cpu_baseline"], o_rows, o_kept = cpu_baseline(cfg, eng.get_params())
+                eng.set_profiling(0)
+                line["parity_note"] = parity_note(cfg, eng, x, o_rows, o_kept)
             except Exception as e:          # the CPU leg must never cost the GPU number
-                line["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
-                                        "sample": "failed: %r" % (e,)}
+                line.setdefault("cpu_baseline", {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
+                                                 "sample": "failed: %r" % (e,)})
+                line["parity_note"] = {"error": repr(e)}
+        line["range_status"] = "ok (byolo_status after the timed region: no activation left the split-f16 range)" if eng.precision == "split" else "n/a (fp32 mode)"
         print(json.dumps(line))
         if args.dump_steps and per_launch:
             with open(args.dump_steps, "w") as f:

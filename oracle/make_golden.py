@@ -121,10 +121,11 @@ def params_for(variant, stats):
     return p
 
 
-def run_reference(variant, params, imgs, dtype, seed=SEED_DROP, sample_offset=0, T=T_EPI):
-    """Execute the reference's model class + concat_bbox + nms under the shim."""
+def run_reference(variant, params, imgs, dtype, seed=SEED_DROP, sample_offset=0, T=T_EPI, masks=None):
+    """Execute the reference's model class + concat_bbox + nms under the shim.  `masks`: keep-masks handed to the
+    reference's tf.layers.dropout calls in call order (instead of the build-defined stream)."""
     shim.install(dtype=dtype, param_provider=lambda name, shape: params[name], seed=seed,
-                 sample_offset=sample_offset)
+                 sample_offset=sample_offset, masks=masks)
     ryolo, rutils, repi, rale, rstd, rdetect = import_reference()
     cls = getattr(ryolo, variant)
     yolo = cls(ref_config(ryolo, variant, T))

@@ -1,0 +1,54 @@
+"""Oracle-side reporting (test infrastructure): distance of a set of pre-NMS rows from reference rows, per column group,
+in units of the north_star's bound taken literally -- |err| <= 1e-4 * max(1, |ref|) per value.  Used by tests/conftest.py
+and by bench.py's cpu_baseline leg (`parity_note`)."""
+import numpy as np
+
+RTOL = ATOL = 1e-4      # BASELINE.json north_star: coords / scores / sigma within 1e-4 fp32
+
+
+def _literal_tol(ref, atol, rtol):
+    """north_star: "within 1e-4 fp32" -- absolute 1e-4 for |v| <= 1, relative 1e-4 beyond (an fp32 value of
+    magnitude 10 has an ulp of 1e-6 and a 75-layer fp32 network a relative error of ~1e-5: no fp32 evaluation can
+    hold an ABSOLUTE 1e-4 on it).  One bound, not the sum of the two."""
+    return np.maximum(atol, rtol * np.abs(ref))
+
+
+def column_groups(variant, C=2):
+    """Columns of a pre-NMS row by meaning (lib_yolo/layers.py:250-258, :330-346, :480-499).
+    `(exp)`: exp(logvar) of network outputs (layers.py:309-313, :465-468) -- unbounded, the only columns beyond 1."""
+    if variant == "yolov3":
+        return {"coords": list(range(0, 4)), "scores": list(range(4, 5 + C))}
+    if variant == "yolov3_aleatoric":
+        return {"coords": list(range(0, 4)), "sigma_ale(exp)": [4, 5, 6, 7, 8],
+                "scores": [9] + list(range(11, 11 + C)), "entropy": [10, 11 + C], "ids": [12 + C, 13 + C]}
+    return {"coords": list(range(0, 4)), "sigma_epi": [4, 5, 6, 7, 12], "sigma_ale(exp)": [8, 9, 10, 11, 13],
+            "scores": [14] + list(range(17, 17 + C)), "mutual_info/entropy": [15, 16, 17 + C, 18 + C],
+            "ids": [19 + C, 20 + C]}
+
+
+def rows_report(got, ref, variant, C=2):
+    """Per column group: max |err|, max |ref|, max relative err over |ref| > 1, and the worst error in units of the
+    north_star's bound taken literally, 1e-4 * max(1, |ref|)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    rep = {}
+    for name, cols in column_groups(variant, C).items():
+        g, r = got[..., cols], ref[..., cols]
+        ok = np.isfinite(r) & np.isfinite(g)
+        r0 = np.where(ok, r, 0)
+        err = np.where(ok, np.abs(g - r), 0.0)
+        big = ok & (np.abs(r) > 1)
+        units = err / _literal_tol(r0, ATOL, RTOL)
+        rep[name] = dict(max_abs_err=float(err.max()), max_ref=float(np.abs(r0).max()),
+                         max_rel_err_over_1=float((err[big] / np.abs(r[big])).max()) if big.any() else 0.0,
+                         worst_in_bounds=float(units.max()), ref_at_worst=float(r0.reshape(-1)[int(units.argmax())]),
+                         nonfinite=int((~ok).sum()))
+    return rep
+
+
+def format_report(rep):
+    return "; ".join("%s: |err| %.2e (|ref| <= %.3g, rel>1 %.1e, %.2f of bound at ref %.3g)"
+                     % (k, v["max_abs_err"], v["max_ref"], v["max_rel_err_over_1"], v["worst_in_bounds"], v["ref_at_worst"])
+                     for k, v in rep.items())
+
+

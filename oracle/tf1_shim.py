@@ -48,6 +48,7 @@ class _State:
         self.drop_form = drop_form  # 'div': (x / keep) * mask (TF<=1.12) | 'mul': x * (1/keep) * mask
         self.taps = []             # (name, tensor) of every op output worth recording
         self.sample_offset = 0     # first MC-sample index of this run (batch-1 loops over images)
+        self.masks = None          # injected keep-masks, one per dropout call (None: the build-defined stream)
 
 
 STATE = _State()
@@ -293,7 +294,10 @@ def _dropout(inputs, rate=0.5, training=False, **kw):
     ordinal = len(STATE.dropout_calls)
     STATE.dropout_calls.append((ordinal, tuple(x.shape)))
     off = STATE.sample_offset * int(np.prod(x.shape[1:]))
-    keep = _rng.keep_mask(STATE.seed, ordinal, tuple(x.shape), drop_prob=rate, offset=off)
+    if STATE.masks is not None:
+        keep = np.asarray(STATE.masks[ordinal], dtype=bool).reshape(tuple(x.shape))
+    else:
+        keep = _rng.keep_mask(STATE.seed, ordinal, tuple(x.shape), drop_prob=rate, offset=off)
     m = torch.as_tensor(keep).to(STATE.dtype)
     keep_prob = torch.tensor(1.0 - rate, dtype=STATE.dtype)
     if STATE.drop_form == "div":
@@ -554,11 +558,12 @@ def build_module():
     return tf
 
 
-def install(dtype=torch.float32, param_provider=None, seed=0, drop_form="div", sample_offset=0):
+def install(dtype=torch.float32, param_provider=None, seed=0, drop_form="div", sample_offset=0, masks=None):
     """(Re)initialise the shim state and register it as ``tensorflow`` (plus a bare ``cv2`` stub
     for detect.py).  Returns the module."""
     STATE.reset(dtype=dtype, param_provider=param_provider, seed=seed, drop_form=drop_form)
     STATE.sample_offset = sample_offset
+    STATE.masks = masks
     tf = sys.modules.get("tensorflow")
     if tf is None or getattr(tf, "__version__", "") != "1.12-shim":
         tf = build_module()

@@ -37,7 +37,7 @@ def pytest_collection_modifyitems(config, items):
 # ---------------------------------------------------------------------------------------------
 # shared helpers
 # ---------------------------------------------------------------------------------------------
-RTOL = ATOL = 1e-4      # BASELINE.json north_star: coords / scores / sigma within 1e-4 fp32
+from oracle.report import RTOL, ATOL, _literal_tol, column_groups, rows_report, format_report      # noqa: E402,F401  (one definition, shared with bench.py's parity_note)
 
 
 def golden(name):
@@ -88,13 +88,6 @@ def build_model(variant, H, W, T=3, params=None, engine_options=None, B=None, **
     return yolo, m
 
 
-def _literal_tol(ref, atol, rtol):
-    """north_star: "within 1e-4 fp32" -- absolute 1e-4 for |v| <= 1, relative 1e-4 beyond (an fp32 value of
-    magnitude 10 has an ulp of 1e-6 and a 75-layer fp32 network a relative error of ~1e-5: no fp32 evaluation can
-    hold an ABSOLUTE 1e-4 on it).  One bound, not the sum of the two."""
-    return np.maximum(atol, rtol * np.abs(ref))
-
-
 def assert_close(a, b, what, rtol=RTOL, atol=ATOL):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -111,46 +104,21 @@ def assert_close(a, b, what, rtol=RTOL, atol=ATOL):
     return float(np.nanmax(err)) if err.size else 0.0
 
 
-def column_groups(variant, C=2):
-    """Columns of a pre-NMS row by meaning (lib_yolo/layers.py:250-258, :330-346, :480-499).
-    `(exp)`: exp(logvar) of network outputs (layers.py:309-313, :465-468) -- unbounded, the only columns beyond 1."""
-    if variant == "yolov3":
-        return {"coords": list(range(0, 4)), "scores": list(range(4, 5 + C))}
-    if variant == "yolov3_aleatoric":
-        return {"coords": list(range(0, 4)), "sigma_ale(exp)": [4, 5, 6, 7, 8],
-                "scores": [9] + list(range(11, 11 + C)), "entropy": [10, 11 + C], "ids": [12 + C, 13 + C]}
-    return {"coords": list(range(0, 4)), "sigma_epi": [4, 5, 6, 7, 12], "sigma_ale(exp)": [8, 9, 10, 11, 13],
-            "scores": [14] + list(range(17, 17 + C)), "mutual_info/entropy": [15, 16, 17 + C, 18 + C],
-            "ids": [19 + C, 20 + C]}
-
-
-def rows_report(got, ref, variant, C=2):
-    """Per column group: max |err|, max |ref|, max relative err over |ref| > 1, and the worst error in units of the
-    north_star's bound taken literally, 1e-4 * max(1, |ref|)."""
-    got = np.asarray(got, dtype=np.float64)
-    ref = np.asarray(ref, dtype=np.float64)
-    rep = {}
-    for name, cols in column_groups(variant, C).items():
-        g, r = got[..., cols], ref[..., cols]
-        ok = np.isfinite(r) & np.isfinite(g)
-        r0 = np.where(ok, r, 0)
-        err = np.where(ok, np.abs(g - r), 0.0)
-        big = ok & (np.abs(r) > 1)
-        units = err / _literal_tol(r0, ATOL, RTOL)
-        rep[name] = dict(max_abs_err=float(err.max()), max_ref=float(np.abs(r0).max()),
-                         max_rel_err_over_1=float((err[big] / np.abs(r[big])).max()) if big.any() else 0.0,
-                         worst_in_bounds=float(units.max()), ref_at_worst=float(r0.reshape(-1)[int(units.argmax())]),
-                         nonfinite=int((~ok).sum()))
-    return rep
+# Device vs the FLOAT32 oracle (north_star's comparator is the reference's float32 CPU path), in units of the bound
+# 1e-4 * max(1, |ref|), for comparisons at FEW MC samples (T <= 3) or a single pass, where two float32-grade evaluations of the
+# same network differ from EACH OTHER by about one bound on the ill-conditioned columns -- variances over two or three samples and
+# exp(logvar) (float32 vs split-f16 emulation 0.67 / 1.04 / 1.05 at 608^2 / 416^2 / 320^2; at the
+# benchmark's T >= 10 every group is held to 1.0, tests/test_gpu_bench_shapes.py).  Bounded columns stay literal.
+VS_FLOAT32_BOUNDS = {"coords": 1.0, "scores": 1.0, "entropy": 1.0, "mutual_info/entropy": 1.0, "ids": 0.0,
+                     "sigma_epi": 1.5, "sigma_ale(exp)": 1.5}
 
 
 def assert_rows_close_vs_oracle(got, params, imgs, variant, what, T=1, seed=0, cls_cnt=2, **kw):
     """Pre-NMS rows against the oracle run in FLOAT64 (the exact value of the reference's graph), at the literal bound --
     or, on a column group where the oracle's own float32 run does not reach it (variances over two or three MC samples,
-    exp(logvar) of a single pass), no further from the float64 result than that float32 run (x 1.1).  Two float32-grade
-    evaluations may differ from EACH OTHER by about the bound there, so the float32 run is the
-    yardstick, not the reference, on such groups.  Also checks the device against the float32 run loosely (2 bounds: a
-    wrong result is off by orders of magnitude).  Returns the report against float64."""
+    exp(logvar) of a single pass), no further from the float64 result than that float32 run (x 1.1) -- AND against the
+    float32 oracle at the per-group constants VS_FLOAT32_BOUNDS above.  Prints all three distances per group.  Returns the
+    report against float64."""
     import torch
     from oracle import cpu_ref
     with torch.no_grad():
@@ -160,15 +128,11 @@ def assert_rows_close_vs_oracle(got, params, imgs, variant, what, T=1, seed=0, c
     floor = rows_report(ref32.numpy(), ref64.numpy(), variant, cls_cnt)
     rep = assert_rows_close(got, ref64.numpy(), variant, what + " vs the float64 oracle", C=cls_cnt, floor=floor)
     loose = rows_report(got, ref32.numpy(), variant, cls_cnt)
-    assert all(v["worst_in_bounds"] <= 2.0 for v in loose.values()), "%s vs the float32 oracle: %s" % (what, format_report(loose))
-    print("%s: vs float64 %s | float32 oracle vs float64 %s" % (what, format_report(rep), format_report(floor)))
+    bad = {k: v for k, v in loose.items() if v["worst_in_bounds"] > VS_FLOAT32_BOUNDS.get(k, 1.0)}
+    assert not bad, "%s vs the float32 oracle, beyond %s: %s" % (what, {k: VS_FLOAT32_BOUNDS.get(k, 1.0) for k in bad}, format_report(bad))
+    print("%s: device vs float64 %s | device vs float32 %s | float32 oracle vs float64 %s"
+          % (what, format_report(rep), format_report(loose), format_report(floor)))
     return rep
-
-
-def format_report(rep):
-    return "; ".join("%s: |err| %.2e (|ref| <= %.3g, rel>1 %.1e, %.2f of bound at ref %.3g)"
-                     % (k, v["max_abs_err"], v["max_ref"], v["max_rel_err_over_1"], v["worst_in_bounds"], v["ref_at_worst"])
-                     for k, v in rep.items())
 
 
 def assert_rows_close(got, ref, variant, what, C=2, floor=None):

@@ -218,6 +218,59 @@ def test_detect_do_it(tmp_path):
             assert boxes and all(0 <= b["y0"] <= 64 and 0 <= b["x1"] <= 96 for b in boxes)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_detect_do_it_boxes_equal_the_oracle(variant, tmp_path):
+    """`detect.do_it` (detect.py:112-135) on two PNGs with the golden weights: EVERY returned box against the oracle's
+    forward + NMS on the same pixels, passed through the oracle's `filter_boxes` / `preproces_boxes` -- the restatement of
+    detect.py:36-63 that tests/golden/detect_post.json pins to the reference's own functions."""
+    import torch
+    import detect
+    from lib_yolo import yolov3
+    from oracle import cpu_ref
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    files, pix = [], []
+    for i in range(2):
+        p = str(tmp_path / ("frame%d.png" % i))
+        a = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+        Image.fromarray(a).save(p)
+        files.append(p)
+        pix.append(a.astype(np.float32) / np.float32(255.0))          # plt.imread of a PNG: float32 in [0, 1] (detect.py:77)
+    ck = tmp_path / "checkpoints" / "run"
+    ck.mkdir(parents=True)
+    params = golden_params(variant)
+    np.savez(str(ck / "model-77.npz"), **params)
+    ibc = variant != "yolov3"         # 7-column rows + implicit background class -> the reference's IndexError (detect.py:51)
+    cfg = make_config(variant, 64, 96, T=3, checkpoint_path=str(tmp_path / "checkpoints"), run_id="run", step="last", seed=5,
+                      crop_img_size=[64, 96, 3], implicit_background_class=ibc)
+    mapping = {1: "ped", 2: "rider"} if ibc else None
+    thresh = 0.05
+    res = detect.do_it(files, thresh, cfg, getattr(yolov3, variant), mapping)
+    assert list(res) == files
+    tp = cpu_ref.to_torch_params(params)
+    D, obj, cs = cpu_ref.row_layout(variant, 2)
+    total = 0
+    for f, img in zip(files, pix):
+        with torch.no_grad():
+            boxes, _ = cpu_ref.detect_boxes(tp, img[None], variant, T=3, seed=5)
+        rows, keep = cpu_ref.nms_batch(boxes, variant)[0]
+        want = cpu_ref.preproces_boxes([64, 96, 3], cpu_ref.filter_boxes(rows, obj, thresh), obj, cs, 2, ibc, cls_mapping=mapping)
+        got = res[f]
+        assert len(got) == len(want) and len(want) > 0, "%s %s: %d boxes, the oracle %d" % (variant, os.path.basename(f), len(got), len(want))
+        total += len(want)
+        for k, (g, w) in enumerate(zip(got, want)):      # same boxes in the same (score) order
+            assert set(g) == set(w)
+            for key in ("y0", "x0", "y1", "x1"):
+                assert abs(float(g[key]) - float(w[key])) <= 1e-4 * 96, (variant, k, key, g[key], w[key])
+            for key in ("score", "obj_score", "cls_score"):
+                assert abs(float(g[key]) - float(w[key])) <= 1e-4, (variant, k, key, g[key], w[key])
+            # the winning class is rounding-stable unless the two class scores are within the bound of each other
+            if abs(float(rows[k][cs]) - float(rows[k][cs + 1])) > 1e-3 or not ibc:
+                assert g["cls"] == w["cls"], (variant, k)
+    print("%s: %d boxes over 2 frames equal the oracle's" % (variant, total))
+
+
 @pytest.mark.parametrize("name,stride", [("s32", 32), ("s8", 8)])
 def test_uncertainty_colour_maps_match_reference(name, stride):
     """vis_uncertainty.colorize / color_map vs the reference's functions (fixture made by running them)."""

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = ("yolov3", "yolov3_aleatoric", "bayesian_yolov3_aleatoric")
 TAPS = (0, 1, 4, 36, 61, 74)
+SPLIT_TAP_BOUND = 1.25      # backbone taps of the default precision vs the float32 fixtures, in units of 1e-4 * max(1, |ref|)
 
 
 def _torch():
@@ -80,12 +81,14 @@ def test_forward_vs_golden(variant, precision):
         got = _sub(i, m.engine.layer_output(i).cpu().numpy())
         ref64 = _sub(i, f64["layers"][i].numpy())
         e64 = assert_close(got, ref64, "%s layer %d vs the float64 oracle" % (variant, i))
-        if precision == "f32":
-            assert_close(got, g["layer_%d" % i], "%s layer %d" % (variant, i))
-        else:
-            fix = g["layer_%d" % i].astype(np.float64)
-            print("%s layer %d: |err| vs float64 %.2e; vs the float32 fixture %.2e (the fixture vs float64: %.2e)"
-                  % (variant, i, e64, np.abs(got - fix).max(), np.abs(fix - ref64).max()))
+        fix = g["layer_%d" % i].astype(np.float64)
+        # vs the float32 fixture (the reference's own graph code, shim-executed): literal in the fp32 mode; the default
+        # precision is held to SPLIT_TAP_BOUND x the bound -- two float32-grade evaluations of the deepest taps differ from
+        # each other by about one bound (the fixture itself sits 0.7 - 0.8 from float64), measured 0.97 - 1.08
+        tol = (1.0 if precision == "f32" else SPLIT_TAP_BOUND) * ATOL
+        efix = assert_close(got, fix, "%s layer %d vs the float32 fixture (%s)" % (variant, i, precision), rtol=tol, atol=tol)
+        print("%s layer %d (%s): |err| vs float64 %.2e; vs the float32 fixture %.2e (the fixture vs float64: %.2e)"
+              % (variant, i, precision, e64, efix, np.abs(fix - ref64).max()))
     for k, dl in enumerate(m.det_layers):
         assert_close(dl.raw_output.cpu().numpy(), g["raw_%d" % k], "%s raw det output %d" % (variant, k))
     boxes = out["boxes"].cpu().numpy()

@@ -65,3 +65,34 @@ def test_restatement_equals_reference_graph_code(variant, monkeypatch):
     # structure: variables in creation order, layer count, row layout
     assert ref["var_names"] == list(cpu_ref.variable_shapes(variant, 2))
     assert (ref["obj_idx"], ref["cls_start_idx"]) == cpu_ref.row_layout(variant, 2)[1:]
+
+
+def test_injected_masks_mean_the_same_in_the_reference_graph_and_the_restatement(monkeypatch):
+    """byolo_forward's d_mask_bits hands the product one keep-bit per element of every dropout input, in the order the
+    reference CALLS tf.layers.dropout (lib_yolo/layers.py:521-524; yolov3.py:544-548, :575-579, :606-610).  The same
+    numpy-drawn arrays given to the reference's own graph code (under the shim) and to the CPU restatement must give
+    the same rows: that pins call order and element order of the injection, independently of oracle/rng.py."""
+    from oracle import cpu_ref, make_golden as mg
+    from byolo import synth
+    monkeypatch.setattr(mg, "H", H)
+    monkeypatch.setattr(mg, "W", W)
+    variant = "bayesian_yolov3_aleatoric"
+    params = _params(variant)
+    imgs = synth.synthetic_images(1, H, W, seed=33)
+    # shapes of the 15 dropout inputs: from a run of the reference itself
+    probe = mg.run_reference(variant, params, imgs, torch.float32, seed=1, T=T)
+    shapes = [s for _, s in probe["dropout_calls"]]
+    assert len(shapes) == 15
+    g = np.random.default_rng(2024)
+    masks = [g.random(s) < 0.9 for s in shapes]
+    ref = mg.run_reference(variant, params, imgs, torch.float32, seed=999, T=T, masks=masks)
+    with torch.no_grad():
+        boxes, f = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params), imgs, variant, T=T, seed=555, masks=masks)
+    for k in range(3):
+        assert_close(f["raw"][k].numpy(), ref["raw"][k], "raw detection output %d under injected masks" % k, rtol=1e-5, atol=1e-5)
+    assert_close(boxes.numpy(), ref["bbox"][None], "pre-NMS rows under injected masks", rtol=1e-5, atol=1e-5)
+    # and the masks matter: another draw gives other rows
+    other = [g.random(s) < 0.9 for s in shapes]
+    with torch.no_grad():
+        b2, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params), imgs, variant, T=T, seed=555, masks=other)
+    assert np.abs(b2.numpy() - boxes.numpy()).max() > 1e-3
