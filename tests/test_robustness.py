@@ -245,7 +245,8 @@ def test_an_activation_beyond_the_split_range_is_an_error_not_inf_rows(monkeypat
     for k, dl in enumerate(m.det_layers):                            # raw detection outputs of ~1e5: finite, and the oracle's
         r = dl.raw_output.cpu().numpy()
         assert np.isfinite(r).all() and np.abs(r).max() > 1e3
-        np.testing.assert_allclose(r, f["raw"][k].numpy(), rtol=2e-3, atol=1.0)
+        want = f["raw"][k].numpy()                                       # sums of ~1e6-sized terms: float32 agreement relative to the tensor's scale
+        assert np.abs(r - want).max() <= 1e-4 * np.abs(want).max()
     # Model.run: the reference-shaped entry point re-runs the batch in the fp32 mode by itself
     yolo2, m2 = build_model(VARIANT, 64, 96, T=3, params=params)
     m2.finalize()

@@ -41,7 +41,32 @@ def _split(a, scale):
     return hi / scale, lo / scale
 
 
-def _run(H, W, T):
+def _wino_split_conv(x, w):
+    """One 3x3 / stride-1 convolution as Winograd F(2x2,3x3) in split-f16 arithmetic, as a fused device kernel would run it:
+    V = B^T d B in fp32 from the decoded hi + lo input, stored as hi/lo pairs (scale 1: |V| <= 4 |d|, the same fp16 range as the
+    activations' 4 * value); U = G g G^T in double, rounded once, one power-of-two scale per output channel, hi/lo pairs; the 16
+    transform-domain products x_hi u_hi + x_hi u_lo + x_lo u_hi accumulated in fp32 over the input channels; Y = A^T M A in fp32."""
+    import torch
+    import torch.nn.functional as F
+    S, H, W, C = x.shape
+    N = w.shape[3]
+    th, tw = (H + 1) // 2, (W + 1) // 2
+    xp = F.pad(x.permute(0, 3, 1, 2), (1, 1 + 2 * tw - W, 1, 1 + 2 * th - H))
+    p = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                   # [S, C, th, tw, 4, 4]
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+    V = torch.einsum("ij,sctujk,lk->sctuil", Bt, p, Bt)                      # fp32 adds of exactly representable inputs
+    U = torch.einsum("ij,jkcn,lk->ilcn", G, w.double(), G).float()           # [4, 4, C, N]
+    ws = torch.exp2(13 - torch.floor(torch.log2(U.abs().amax(dim=(0, 1, 2)).clamp(min=1e-30))))
+    Vh, Vl = _split(V, 1.0)
+    Uh, Ul = _split(U, ws)
+    M = (torch.einsum("sctuil,ilcn->sntuil", Vh, Uh) + (torch.einsum("sctuil,ilcn->sntuil", Vh, Ul) + torch.einsum("sctuil,ilcn->sntuil", Vl, Uh)))
+    Y = torch.einsum("ai,sntuil,bl->sntaub", At, M, At)                      # [S, N, th, 2, tw, 2]
+    return Y.reshape(S, N, 2 * th, 2 * tw)[:, :, :H, :W].permute(0, 2, 3, 1).contiguous()
+
+
+def _run(H, W, T, wino=False):
     import torch
     from oracle import cpu_ref
     from byolo import synth
@@ -58,10 +83,13 @@ def _run(H, W, T):
     def conv(x, w, stride):
         if x.dtype != torch.float32 or not mode["split"]:
             return orig_conv(x, w, stride)
-        ws = 2.0 ** (13 - math.floor(math.log2(float(w.abs().max()))))
-        xh, xl = _split(x, 1.0 if x.shape[3] == 3 else ACT_SCALE)     # the stem reads the fp32 image as it is
         if x.shape[3] == 3:
-            return orig_conv(x, w, stride)
+            return orig_conv(x, w, stride)                             # the stem reads the fp32 image as it is
+        if wino and w.shape[0] == 3 and stride == 1 and x.shape[3] >= 64:
+            return _wino_split_conv(x, w)
+        # one power of two per output channel (byolo_finalize): the channel's largest |w'| in [2^13, 2^14)
+        ws = torch.exp2(13 - torch.floor(torch.log2(w.abs().amax(dim=(0, 1, 2)).clamp(min=1e-30))))
+        xh, xl = _split(x, ACT_SCALE)
         wh, wl = _split(w, ws)
         return orig_conv(xh, wh, stride) + (orig_conv(xh, wl, stride) + orig_conv(xl, wh, stride))
 
@@ -98,3 +126,15 @@ def test_split_f16_is_float32_grade():
     assert r["split_vs_f64"] < 1.0                                         # inside the contract's bound of the exact result
     assert r["split_vs_f64"] < 1.3 * r["f32_vs_f64"] + 0.05               # and no further from it than float32 is
     assert r["split_vs_f32"] <= r["split_vs_f64"] + r["f32_vs_f64"] + 1e-6  # (the two float32-grade runs: triangle inequality)
+
+
+def test_winograd_in_split_arithmetic_is_float32_grade_too():
+    """VERDICT r2 item 4 asks for this BEFORE any kernel: F(2x2,3x3) on every 3x3 / stride-1 convolution with >= 64 input
+    channels, in split-f16 arithmetic, against float64 and float32 -- only worth building if the rows stay inside the bound."""
+    size = int(os.environ.get("BYOLO_EMU_SIZE", "320"))
+    T = int(os.environ.get("BYOLO_EMU_T", "2"))
+    r = _run(size, size, T, wino=True)
+    print("\nWinograd F(2x2,3x3) in split-f16, %dx%d, T=%d, worst value in units of the bound: float32 vs float64 %.3f | split-f16 + Winograd vs "
+          "float64 %.3f | vs float32 %.3f" % (size, size, T, r["f32_vs_f64"], r["split_vs_f64"], r["split_vs_f32"]))
+    assert r["split_vs_f64"] < 1.0
+    assert r["split_vs_f64"] < 1.3 * r["f32_vs_f64"] + 0.05
