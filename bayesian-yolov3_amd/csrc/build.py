@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "..", "byolo", "libbyolo.so")
-SRCS = ["byolo_api.hip", "conv_igemm.hip", "conv_kernels.hip", "winograd.hip", "gemm_stream.hip", "wino_fused.hip","tail_kernels.hip"]
+SRCS = ["byolo_api.hip", "conv_igemm.hip", "conv_kernels.hip", "winograd.hip", "gemm_stream.hip", "wino_fused.hip", "wino_split.hip", "tail_kernels.hip"]
 DEPS = SRCS + ["byolo_kernels.h", "byolo_rng.h", "mfma_pipe.h", "epilogue.h", os.path.join("..", "..", "include", "byolo.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-result"]

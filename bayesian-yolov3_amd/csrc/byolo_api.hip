@@ -154,6 +154,11 @@ struct byolo {
     unsigned* d_status = nullptr; unsigned* h_status = nullptr;
     bool async_status = false;     // byolo_set_async: byolo_forward does not wait for the status words
     bool plan_inject = false;      // the current plan was made for injected dropout masks (fp32 mode: conv_igemm launches only)
+    // Forwards of ONE handle alternating over several streams (a caller pipelining whole steps: bench.py --pipeline): the
+    // convolution stacks run one after the other -- two of them sharing the chip gain nothing and blur every per-launch timing
+    // -- while a step's latency-bound tail (decode, sort, NMS) overlaps the next step's convolutions.  ev_convs is recorded
+    // behind the last convolution launch of a forward; a forward on ANOTHER stream waits for it before its first launch.
+    hipEvent_t ev_convs = nullptr; hipStream_t convs_stream = nullptr; bool ev_convs_valid = false;
     std::vector<int> last_use;     // per tensor id: index of the last step reading it
     float* d_blob = nullptr;       // packed weights + scale/shift
     size_t blob_floats = 0;
@@ -242,6 +247,7 @@ extern "C" int32_t byolo_destroy(byolo_t* h) {
         if (h->d_blob) (void)hipFree(h->d_blob);
         if (h->d_ones) (void)hipFree(h->d_ones);
         if (h->d_zeros) (void)hipFree(h->d_zeros);
+        if (h->ev_convs) (void)hipEventDestroy(h->ev_convs);
         if (h->d_status) (void)hipFree(h->d_status);
         if (h->h_status) (void)hipHostFree(h->h_status);
         for (auto& ps : h->prof) {
@@ -1313,6 +1319,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
     }
     const bool per_step = h->profiling >= 2;
     bool backbone_marked = false;
+    if (h->ev_convs_valid && h->convs_stream != st) HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0));   // (see ev_convs)
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     if (h->precision == 1 && h->img_split)
         HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st, h->d_status));
@@ -1390,6 +1397,8 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         ps.step_valid = true;
     }
     if (h->profiling) { if (!backbone_marked) HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); HIPCHK(h, hipEventRecord(h->wslot().ev[2], st)); }
+    if (!h->ev_convs) HIPCHK(h, hipEventCreateWithFlags(&h->ev_convs, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->ev_convs, st)); h->convs_stream = st; h->ev_convs_valid = true;
     float* boxes = d_boxes ? d_boxes : reinterpret_cast<float*>(ws + h->plan.boxes_off);
     if (d_boxes || d_rows) { rc = run_decode(h, ws, boxes, B, T, st); if (rc) return rc; }
     if (h->profiling) HIPCHK(h, hipEventRecord(h->wslot().ev[3], st));

@@ -111,7 +111,26 @@ struct WinoParams {
     int P, P_pad;                     // tiles of the chunk (samples * th * tw), rounded up to 128
     int flags; uint32_t k0, k1, thr; uint64_t idx_base;
     FastDiv d_tt, d_tw, d_c4, d_n4;   // th*tw, tw, C/4, N/4
+    float vmul;                       // split precision (wino_split.hip): V = vmul * (B^T d B) of the stored hi + lo values
 };
+// Winograd F(2x2,3x3) in split-f16 arithmetic (wino_split.hip): V [16][P_pad][C] as hi/lo groups -> output [S,H,W,N] as hi/lo
+// groups, GEMM + output transform + epilogue in one launch of P_pad / 128 * N / 128 workgroups
+struct WinoSplitParams {
+    const float* v; uint32_t v_bytes;     // V of this chunk; rows beyond v_bytes read 0
+    uint32_t xi_stride;                   // bytes between consecutive transform points in V (P_pad * C * 4)
+    const float* w; uint32_t w_bytes;     // U: 16 * C / 32 K-tiles in (point, chunk) order, split-f16 fragment order (mfma_pipe.h)
+    float* y;                             // output [S,H,W,N], hi/lo groups
+    const float* scale; const float* shift;
+    int C, N, KT, n_tiles;                // KT = C / 32 (even), n_tiles = N / 128
+    int H, W, th, tw, s0, P, P_pad;       // as WinoParams
+    int units;                            // P_pad / 128 * n_tiles workgroups
+    int flags; uint32_t k0, k1, thr; uint64_t idx_base; const uint32_t* mask_bits;
+    unsigned* status; int layer_idx;
+    FastDiv d_ntiles, d_tt, d_tw;
+};
+bool wino_split_ok(int C, int N);
+hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st);
+hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st);
 // Row-streaming persistent GEMM (gemm_stream.hip): the Winograd-domain GEMM (epi 0: 16 row blocks of RT row tiles, one
 // weight matrix each, raw accumulators out), a 1x1 / stride-1 convolution with its fused epilogue (epi 1), or a
 // detection head (epi 2: + bias, any cout)

@@ -1,0 +1,260 @@
+// wino_split.hip -- Winograd F(2x2, 3x3) in split-f16 arithmetic for the large 3x3 / stride-1 convolutions of the heads
+// (lib_yolo/layers.py:545-575 with kernel_size 3; lib_yolo/yolov3.py:543-622: the nine 3x3 convolutions of the three
+// detection heads are 62 % of the step at BASELINE configs[3]).
+//
+// The default precision computes x * w as three fp16 matrix products (mfma_pipe.h), and the matrix pipe runs against the
+// socket's power cap: the only way to a faster convolution is FEWER PRODUCTS.  F(2x2, 3x3) spends 16 multiplies per 2x2 output
+// tile and channel pair instead of 36:
+//
+//   V[xi][p][c] = (B^T d B)[xi]        wino_split_input_kernel: one 4x4 input patch per output tile p, fp32 arithmetic on the
+//                                      decoded hi + lo values, V stored as hi/lo pairs again (scale 1: |V| <= 4 |d| sits in
+//                                      the fp16 range the activations' 4 * value occupies)
+//   M[xi]       = V[xi] . U[xi]        wino_split_kernel: per transform point a 128 x 128 x C GEMM on
+//                                      v_mfma_f32_32x32x16_f16 (x_hi u_hi + x_hi u_lo + x_lo u_hi, fp32 accumulation) ...
+//   Y           = A^T M A              ... whose accumulators are folded, point after point, into the four 2x2-output
+//                                      accumulators with the coefficients of A^T . A (0, +-1); after point 15 the lanes hold
+//                                      pre-activation outputs and run the convolution's epilogue (dropout mask, BN, leaky,
+//                                      hi/lo encoding, range check).  M never exists in memory.
+//   U[xi][c][n] = (G g G^T)[xi]        once, on the host, in double (byolo_finalize); one power-of-two scale per output channel;
+//                                      packed per transform point like a 1x1 convolution's weights (fragment order)
+//
+// B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
+//
+// A workgroup (4 waves side by side along N, each 128 x 32) owns 128 output tiles x 128 channels and keeps 4 x 64 output
+// accumulators + 64 product accumulators per lane: a 512-register kernel, one wave per SIMD.  Numerics: emulated around
+// the oracle before it was built (tests/test_split_numerics.py: 0.62 of the bound from float64 where float32 sits at 0.98).
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "byolo_kernels.h"
+#include "byolo_rng.h"
+#include "mfma_pipe.h"
+#include "epilogue.h"
+
+namespace byk {
+
+using namespace pipe;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// input transform: thread = (tile p, 4 channels): 16 x 16-byte loads, 16 x 16-byte stores; hi/lo groups in and out
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_split_input_kernel(const WinoParams p) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t c4n = (uint32_t)p.C >> 2;
+    const uint32_t t = fdiv(gid, p.d_c4), c4 = gid - t * c4n;
+    if (t >= (uint32_t)p.P_pad) return;
+    float* v = p.v + (size_t)t * p.C + c4 * 4;
+    const size_t xi_stride = (size_t)p.P_pad * p.C;
+    if (t >= (uint32_t)p.P) {                        // rows that pad the last row tile: zeros (they are multiplied, never stored)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(v + (size_t)k * xi_stride) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const uint32_t tt = (uint32_t)(p.th * p.tw);
+    const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
+    const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
+    const float* img = p.x + ((size_t)(p.s0 + s) * p.H * p.W) * p.C + c4 * 4;
+    const int y0 = 2 * (int)ty - 1, x0 = 2 * (int)tx - 1;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + i, x = x0 + j;
+            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            const f32x4 raw = ok ? *reinterpret_cast<const f32x4*>(img + ((size_t)y * p.W + x) * p.C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[i][j] = epi::split_decode4(raw);       // ACT_SCALE * value, exact
+        }
+    f32x4 u[4][4];                                   // B^T d
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u[0][j] = d[0][j] - d[2][j];
+        u[1][j] = d[1][j] + d[2][j];
+        u[2][j] = d[2][j] - d[1][j];
+        u[3][j] = d[1][j] - d[3][j];
+    }
+    // (B^T d) B, times 1 / ACT_SCALE (p.vmul, a power of two): |V| <= 4 |d| stays inside the range the inputs occupied
+    const float m = p.vmul;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 0) * xi_stride) = epi::split_encode4((u[i][0] - u[i][2]) * m);
+        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 1) * xi_stride) = epi::split_encode4((u[i][1] + u[i][2]) * m);
+        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 2) * xi_stride) = epi::split_encode4((u[i][2] - u[i][1]) * m);
+        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 3) * xi_stride) = epi::split_encode4((u[i][1] - u[i][3]) * m);
+    }
+}
+
+hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st) {
+    const uint64_t total = (uint64_t)p.P_pad * (p.C >> 2);
+    hipLaunchKernelGGL(wino_split_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fused GEMM + output transform + epilogue
+// ---------------------------------------------------------------------------------------------------------------------
+// Y[a][b] += cA(a, i) * cA(b, j) * M   for transform point xi = (i, j),  cA = A^T = [1 1 1 0; 0 1 -1 -1]
+template <int XI, int TM>
+__device__ __forceinline__ void wino_fold(f32x16 (&Y)[4][TM], const f32x16 (&M)[TM]) {
+    constexpr int I = XI >> 2, J = XI & 3;
+    constexpr int CA[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = CA[a][I] * CA[b][J];
+            if (c == 0) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (c > 0) Y[a * 2 + b][i] += M[i];
+                else Y[a * 2 + b][i] -= M[i];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256, 1) void wino_split_kernel(const WinoSplitParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using BT = SplitTile<128, 128, 1, 4>;
+    constexpr int TM = BT::TM, A_LD = BT::A_LD;            // 4 row blocks of 32 per wave; 4 staging rows per thread
+    static_assert(BT::TN == 1, "one 32-column block per wave");
+    const BT bt(smem);
+
+    // unit -> (row tile, column tile): the column tiles of a row tile are neighbours on one XCD (V rows shared in its L2)
+    const int nwg = (int)gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const uint32_t unit = (uint32_t)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bi);
+    const uint32_t n_tiles = (uint32_t)p.n_tiles;
+    const uint32_t rt = fdiv(unit, p.d_ntiles), ct = unit - rt * n_tiles;
+
+    // ---- staging rows (V row = output tile index inside the chunk; every row of the padded extent exists) -------------
+    uint32_t a_voff[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const uint32_t m = rt * 128u + (uint32_t)bt.a_r + 32u * j;
+        a_voff[j] = (m * (uint32_t)p.C + (uint32_t)bt.a_q * 4u) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.v, p.v_bytes);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, p.w_bytes);
+    // K-tile sequence: (xi, chunk); scalar offsets
+    const uint32_t KT = (uint32_t)p.KT;
+    const uint32_t w_step = (uint32_t)p.N * BK * 4;                        // one K-tile of all column blocks (N / 32 blocks of 4 KB)
+    uint32_t a_soff = 0, a_kt = 0, a_xi_base = 0;                          // the NEXT tile to load
+    uint32_t w_soff = ct * (128 / 32) * SPLIT_WBLOCK;
+    f32x4 a_reg[A_LD];
+    f16x8 bfr[2][2][1][2];
+    auto next_tile = [&]() {
+        a_soff = a_xi_base + a_kt * (BK * 4);
+        if (++a_kt == KT) { a_kt = 0; a_xi_base += p.xi_stride; }          // past point 15: beyond v_bytes -> zeros
+    };
+    auto load_a = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) a_reg[j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
+    };
+    auto load_b = [&](auto set_tag) { bt.load_b(bfr[decltype(set_tag)::value], w_rsrc, w_soff); w_soff += w_step; };
+
+    f32x16 Y[4][TM], M[TM][1];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[o][i][r] = 0.f;
+
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    f16x8 af0[TM][2], af1[TM][2];
+    next_tile(); load_a(); load_b(c0{});
+    bt.template store_a<0>(a_reg);
+    next_tile(); load_a();
+    __syncthreads();
+    bt.template read_frags<0, 0>(af0);
+
+    // one K-tile in LDS buffer BUF: the uniform body of the split pipeline (mfma_pipe.h tile_body_split) -- stage tile t+1,
+    // fetch tile t+2 and the weight fragments of t+1; past the end the loads read zeros and what they stage is never used
+    auto ktile = [&](auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        pipe::tile_body_split<BUF, true, BT::NBF, A_LD, A_LD, 0>(
+            bt, M, af0, af1, bfr[BUF], [&] { load_b(std::integral_constant<int, BUF ^ 1>{}); },
+            [&] { next_tile(); load_a(); }, [&] { bt.template store_a<BUF ^ 1>(a_reg); });
+    };
+    auto run_point = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) M[i][0][r] = 0.f;
+        for (uint32_t kt = 0; kt < KT; kt += 2) { ktile(c0{}); ktile(c1{}); }
+    };
+    auto fold = [&](auto xi_tag) {
+        f32x16 Mv[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) Mv[i] = M[i][0];
+        wino_fold<decltype(xi_tag)::value, TM>(Y, Mv);
+    };
+#define BYOLO_WINO_POINT(X) run_point(); fold(std::integral_constant<int, X>{});
+    BYOLO_WINO_POINT(0)  BYOLO_WINO_POINT(1)  BYOLO_WINO_POINT(2)  BYOLO_WINO_POINT(3)
+    BYOLO_WINO_POINT(4)  BYOLO_WINO_POINT(5)  BYOLO_WINO_POINT(6)  BYOLO_WINO_POINT(7)
+    BYOLO_WINO_POINT(8)  BYOLO_WINO_POINT(9)  BYOLO_WINO_POINT(10) BYOLO_WINO_POINT(11)
+    BYOLO_WINO_POINT(12) BYOLO_WINO_POINT(13) BYOLO_WINO_POINT(14) BYOLO_WINO_POINT(15)
+#undef BYOLO_WINO_POINT
+
+    // ---- epilogue: lane = output tile li (+32 per block), 4 groups of 4 consecutive channels from 4 * lh (mfma_pipe.h) ----
+    const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT;
+    const float slope = do_leaky ? 0.1f : 1.f;
+    const uint32_t tt = (uint32_t)(p.th * p.tw);
+    const int nb = (int)(ct * 128) + bt.wn * 32 + 4 * bt.lh;
+    float vmax = 0.f;
+    f32x4 sc4[4], sf4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        sc4[g] = *reinterpret_cast<const f32x4*>(p.scale + nb + 8 * g);
+        sf4[g] = *reinterpret_cast<const f32x4*>(p.shift + nb + 8 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const uint32_t t = rt * 128u + (uint32_t)i * 32u + (uint32_t)bt.li;
+        if (t >= (uint32_t)p.P) continue;
+        const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
+        const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const uint32_t oy = 2 * ty + (o >> 1), ox = 2 * tx + (o & 1);
+            if (oy >= (uint32_t)p.H || ox >= (uint32_t)p.W) continue;
+            const uint64_t pix = ((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox;
+            const uint64_t idx_row = p.idx_base + pix * (uint64_t)p.N + (uint64_t)nb;
+            const epi::DropRow drow(idx_row, p.k1);
+            float* d = p.y + (size_t)pix * p.N + nb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dn = 8 * g;
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = Y[o][i][4 * g + q];
+                bool keep[4] = {true, true, true, true};
+                if (do_drop) {
+                    if (p.mask_bits) {                                  // injected masks (conv_igemm.hip finish_tile)
+                        const uint32_t el = 2u * drow.gp_lo + (uint32_t)dn;
+                        const uint32_t w = p.mask_bits[el >> 5] >> (el & 31u);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) keep[q] = (w >> q) & 1u;
+                    } else epi::keep4(drow, dn, p.k0, p.thr, keep);
+                }
+                const f32x4 v = epi::bn_act4(a4, sc4[g], sf4[g], keep, slope);
+                vmax = epi::absmax4(vmax, v);
+                *reinterpret_cast<f32x4*>(d + dn) = epi::split_encode4(v);
+            }
+        }
+    }
+    if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
+}
+
+bool wino_split_ok(int C, int N) { return C >= 64 && (C % 64) == 0 && N >= 128 && (N % 128) == 0; }
+
+hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st) {
+    using BT = SplitTile<128, 128, 1, 4>;
+    auto k = wino_split_kernel;
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), BT::LDS_BYTES, attr_done); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)p.units), dim3(256), BT::LDS_BYTES, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace byk

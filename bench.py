@@ -105,17 +105,25 @@ def parity_note(cfg, eng, x, oracle_rows, oracle_kept):
     forward of the SAME batch with that seed: worst distance per column group in units of the bound, kept indices."""
     import numpy as np
     from oracle import report
+    import torch
+    from oracle import cpu_ref
     r = eng.forward(x, T=cfg["T"], seed=42, want_boxes=True, want_nms=True, first_image=0)
     got = r["boxes"][:1].cpu().numpy()
     n = int(r["count"][0, 0])
+    kept = r["kept"][0, :n].cpu().numpy()
     rep = report.rows_report(got, oracle_rows[:1], cfg["variant"])
+    # tail: the oracle's NMS on the DEVICE's rows must keep exactly what the device kept; against the oracle's NMS of the ORACLE's
+    # rows the greedy visiting order may flip between near-tied scores, so that comparison is a count of differing boxes
+    tail = cpu_ref.nms_batch(torch.from_numpy(got), cfg["variant"], two_class=bool(cfg["nms"]))[0][1]
+    ok = oracle_kept[0][1]
     return {"compared": "image 0 of the benchmark batch, all %d pre-NMS rows, dropout seed 42; device (%s) vs the float32 oracle"
                         % (got.shape[1], eng.precision),
             "bound": "1e-4 * max(1, |ref|)", "worst_in_bounds": {k: round(v["worst_in_bounds"], 3) for k, v in rep.items()},
             "max_abs_err": {k: float("%.3g" % v["max_abs_err"]) for k, v in rep.items()},
             "nan_inf_pattern_equal": bool(np.array_equal(np.isfinite(got), np.isfinite(oracle_rows[:1]))),
-            "kept_indices_equal_oracle_nms_of_oracle_rows": bool(n == len(oracle_kept[0][1]) and
-                                                                 np.array_equal(r["kept"][0, :n].cpu().numpy(), oracle_kept[0][1]))}
+            "kept_indices_bit_exact_vs_oracle_nms_on_device_rows": bool(n == len(tail) and np.array_equal(kept, tail)),
+            "kept_boxes": n, "kept_boxes_oracle_rows": int(len(ok)),
+            "kept_set_symmetric_difference_vs_oracle_rows": int(len(set(kept.tolist()) ^ set(np.asarray(ok).tolist())))}
 
 
 def time_steps(eng, x, cfg, steps, warmup, first_image=0):
@@ -411,8 +419,9 @@ def main():
                                          "fp16_sustained_under_power_cap_tflops": SUSTAINED_F16_MFMA / 1e12,
                                          "frac_executed_of_sustained": 3.0 * fu / (ms * 1e-3) / SUSTAINED_F16_MFMA})
             if npipe > 1:
-                line["roofline"]["note"] = ("steps alternate over %d HIP streams: a launch's hipEvent time includes what it shares with the other "
-                                            "stream's tail kernels (decode, sort, NMS)" % npipe)
+                line["roofline"]["note"] = ("steps alternate over %d HIP streams; the library runs a handle's convolution stacks one after the other "
+                                            "(byolo_api.hip ev_convs), so a convolution launch shares the chip only with the previous step's tail "
+                                            "kernels (decode, sort, NMS: a few hundred microseconds of small launches)" % npipe)
             line["stage_ms_per_step"] = {k: v / args.steps for k, v in stage.items()}
         # the reference's own arithmetic (float32, lib_yolo/layers.py:550) timed in the SAME run: a second handle in BYOLO_PREC_F32
         # on the same batch, a few steps on one stream after the headline region (the headline engine stays alive: its weights)
