@@ -68,6 +68,8 @@ struct Layer {
     int tile = 0, Npad = 0;
     bool direct = false;
     std::vector<int> wshift;       // split precision, per OUTPUT CHANNEL n: the packed weights hold w[.][n] * 2^wshift[n] (the channel's largest |w'| in [2^13, 2^14)); folded into scale[n]
+    std::vector<int> wshift_u;     // split precision, Winograd (wino_split.hip): per output channel, for U = G g G^T
+    size_t wscale_off = 0, wscalek_off = 0;    // ... and the per-channel scale arrays that go with it (the shift is the layer's)
     float in_scale = 1.f;          // split precision: scale of the layer's input (ACT_SCALE for activations, 1 for the fp32 image of a direct convolution)
     int64_t box_base = 0;
 };
@@ -101,7 +103,7 @@ struct Step {
     bool kx3 = false;              // split precision: 3x3 / stride 1 over one plain source -- shared-tap stages (conv_tile_kx3), weights in (ky, chunk, kx) order
 };
 // per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
-struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; };
+struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; int bm = 0; /* split precision: output tiles per workgroup */ };
 struct AuxTensor { int H, W, C; };
 
 struct Plan {
@@ -658,6 +660,16 @@ static void scale_keep(const byolo_t* h, std::vector<float>& scale) {
     for (float& v : scale) v *= inv_keep;
 }
 
+// split precision, Winograd launches of layer l: V holds B^T d B of the VALUES (the transform multiplies the stored 4 * value by
+// 1/4), U holds 2^wshift_u * (G g G^T): the accumulators are 2^wshift_u * conv, the output tensor holds ACT_SCALE * value
+static void wino_scales(const byolo_t* h, const Layer& l, std::vector<float>& sc, std::vector<float>& sk) {
+    std::vector<float> sf;
+    fold_layer(h, l, sc, sf);
+    for (size_t c = 0; c < sc.size(); ++c) sc[c] *= ACT_SCALE / ldexpf(1.f, l.wshift_u[c]);
+    sk = sc;
+    scale_keep(h, sk);
+}
+
 extern "C" int32_t byolo_finalize(byolo_t* h) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_finalize: null handle");
     if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
@@ -709,6 +721,10 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         l.scale_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);   // readable (zeros) up to Npad
         l.shift_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
         if (l.drop_ordinal >= 0) { l.scalek_off = off; off += align_up((size_t)std::max(N, st.Npad), 64); }
+        if (st.wino_ok) {                                       // split precision: the scales that go with U's own power-of-two shifts
+            l.wscale_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
+            l.wscalek_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
+        }
     }
     std::vector<float> blob(off, 0.f);
     std::vector<float> sc, sf;
@@ -726,6 +742,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
             const int N = l.filters;
             const size_t rows = k.data.size() / (size_t)N;          // HWIO == [K][N]
             l.wshift.assign((size_t)N, 0);
+            l.wshift_u.clear();
             for (int n = 0; n < N; ++n) {
                 float mx = 0.f;
                 for (size_t r = 0; r < rows; ++r) mx = std::max(mx, std::fabs(k.data[r * N + n]));
@@ -785,6 +802,44 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
                     for (int nn = 0; nn < N; ++nn) d[(size_t)nn * 32] = wr[nn];
                 }
         }
+        if (st.wino_ok && h->precision == 1 && wino_split_ok(Cs, N) && st.Npad == N) {
+            // Winograd in split arithmetic (wino_split.hip): U[xi][c][n] = (G g G^T)[xi] in double, rounded once; one power of two per
+            // output channel over all 16 points; hi/lo pairs in fragment order, K-tile order (point, chunk)
+            std::vector<float> U((size_t)16 * Cs * N);
+            float g9[9], u16[16];
+            for (int c = 0; c < Cs; ++c)
+                for (int nn = 0; nn < N; ++nn) {
+                    for (int tap = 0; tap < 9; ++tap) g9[tap] = w[((size_t)tap * l.Cin + st.c_lo + c) * N + nn];
+                    wino_weight_transform(g9, u16);
+                    for (int xi = 0; xi < 16; ++xi) U[((size_t)xi * Cs + c) * N + nn] = u16[xi];
+                }
+            Layer& lw = h->layers[st.layer];
+            lw.wshift_u.assign((size_t)N, 0);
+            std::vector<float> wsu((size_t)N);
+            for (int nn = 0; nn < N; ++nn) {
+                float mx = 0.f;
+                for (size_t r = 0; r < (size_t)16 * Cs; ++r) mx = std::max(mx, std::fabs(U[r * N + nn]));
+                int e = 0;
+                if (mx > 0.f) (void)std::frexp(mx, &e);
+                lw.wshift_u[nn] = mx > 0.f ? std::min(126, std::max(-126, 14 - e)) : 0;
+                wsu[nn] = ldexpf(1.f, lw.wshift_u[nn]);
+            }
+            _Float16* d16 = reinterpret_cast<_Float16*>(blob.data() + st.wino_off);
+            const size_t blocks = N / 32;
+            const int cts = Cs / 32;
+            for (int xi = 0; xi < 16; ++xi)
+                for (int c = 0; c < Cs; ++c) {
+                    const int kk = c & 31, step = kk >> 4, half = (kk >> 3) & 1, e = kk & 7;
+                    const int kt = xi * cts + (c >> 5);
+                    const float* ur = U.data() + ((size_t)xi * Cs + c) * N;
+                    for (int nn = 0; nn < N; ++nn) {
+                        const float v = ur[nn] * wsu[nn];
+                        const _Float16 hi = (_Float16)v;
+                        _Float16* d = d16 + (((size_t)kt * blocks + (nn >> 5)) * 4 + step * 2) * 512 + (half * 32 + (nn & 31)) * 8 + e;
+                        d[0] = hi; d[512] = (_Float16)(v - (float)hi);
+                    }
+                }
+        }
         if (st.wino_ok && h->precision == 0) {                  // U[xi][c][n] = (G g G^T)[xi], each xi packed like a 1x1 conv
             float* u = blob.data() + st.wino_off;
             const size_t xi_stride = (size_t)(Cs / 32) * st.Npad * 32;
@@ -806,6 +861,12 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
             scale_keep(h, sc);
             memcpy(blob.data() + l.scalek_off, sc.data(), sizeof(float) * N);
         }
+        if (h->precision == 1 && st.wino_ok && !l.wshift_u.empty()) {
+            std::vector<float> wsc, wsk;
+            wino_scales(h, l, wsc, wsk);
+            memcpy(blob.data() + l.wscale_off, wsc.data(), sizeof(float) * N);
+            memcpy(blob.data() + l.wscalek_off, wsk.data(), sizeof(float) * N);
+        }
     }
     if (h->d_blob && h->blob_floats != off) { HIPCHK(h, hipFree(h->d_blob)); h->d_blob = nullptr; }
     if (!h->d_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, sizeof(float) * off));
@@ -819,12 +880,18 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         HIPCHK(h, hipMemset(h->d_zeros, 0, sizeof(float) * maxC));
     }
     h->finalized = true;
+    h->plan.B = -1; h->plan.T = -1;                             // kernel choices depend on what was packed: plan again
     return BYOLO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // workspace planning (liveness-based first-fit; 288 GB HBM is not a reason to thrash the caches)
 // ------------------------------------------------------------------------------------------------
+// Floats per pixel of a layer's tensor.  A matrix-pipe detection head pads its 3 * (5 + C) or 3 * 2 * (5 + C) channels (21, 42, ..)
+// to a multiple of 4: the epilogue then stores 16-byte vectors like every other convolution (the two padding channels come out
+// as zeros: zero weight columns, zero bias); decode reads with that pitch, byolo_copy_layer_output hands out the dense tensor.
+static int layer_pitch(const Layer& l) { return (l.op == OP_DETECTION && !l.direct) ? (l.C + 3) / 4 * 4 : l.C; }
+
 static int64_t tensor_bytes(const byolo_t* h, int id, int B, int T) {
     const int n = (int)h->layers.size();
     if (id >= n) {                                                // auxiliary: one row per IMAGE pixel
@@ -833,7 +900,7 @@ static int64_t tensor_bytes(const byolo_t* h, int id, int B, int T) {
     }
     const Layer& l = h->layers[id];
     const int64_t S = l.stacked ? (int64_t)B * T : B;
-    return (int64_t)align_up((size_t)(S * l.H * l.W * l.C) * sizeof(float), 256);
+    return (int64_t)align_up((size_t)(S * l.H * l.W * layer_pitch(l)) * sizeof(float), 256);
 }
 
 // rows (M) and K-tiles of one launch -- the same arithmetic as fill_conv
@@ -922,6 +989,42 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
     // BYOLO_WINOGRAD=0 keeps every convolution direct.
     p.wino.assign(h->steps.size(), WinoPlan{});
     size_t wino_scratch = 0;
+    // Split precision: Winograd F(2x2,3x3) in split arithmetic (wino_split.hip) for the LARGE 3x3 / stride-1 convolutions -- the
+    // nine 3x3 convolutions of the heads at T >= ~10 samples.  The transform streams 5x the input through HBM, so small layers keep
+    // the shared-tap direct kernel.  BYOLO_WINO_SPLIT: 0 never, 1 layers of >= BYOLO_WINO_SPLIT_MIN_GFLOP (default 200), 2 every
+    // eligible layer (tests); BYOLO_WINO_SPLIT_BM: 64 | 128 output tiles per workgroup; BYOLO_WINO_SPLIT_CHUNK_MB: V bytes of a chunk.
+    if (h->precision == 1) {
+        const char* e = getenv("BYOLO_WINO_SPLIT");
+        const int on = e ? atoi(e) : 1;
+        const char* mf = getenv("BYOLO_WINO_SPLIT_MIN_GFLOP");
+        const char* cb = getenv("BYOLO_WINO_SPLIT_CHUNK_MB");
+        const char* be = getenv("BYOLO_WINO_SPLIT_BM");
+        const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 200.0) * 1e9, budget = (cb ? atof(cb) : 1500.0) * 1e6;
+        const int bm = be && atoi(be) == 128 ? 128 : 64;
+        for (size_t si = 0; on && si < h->steps.size(); ++si) {
+            const Step& s = h->steps[si];
+            const Layer& l = h->layers[s.layer];
+            if (!s.wino_ok || !s.kx3 || s.mode != STEP_NORMAL || l.wshift_u.empty() || l.fused_residual >= 0) continue;
+            int M, KT; step_geometry(h, s, B, T, &M, &KT);
+            if (2.0 * M * l.filters * 9.0 * l.Cin < min_flops) continue;
+            // per transform point the K loop is only Cin / 32 tiles long, and the fold + the 5x input stream are paid per point:
+            // measured at config 4 (direct -> transform + fused): Cin 512 2.00 -> 0.19 + 1.36 ms, 256 2.02 -> 0.35 + 1.37,
+            // 128 2.15 -> 2 x (0.36 + 0.80) -- the 128-channel layers stay direct (BYOLO_WINO_SPLIT_MIN_C)
+            static const int min_c = [] { const char* e = getenv("BYOLO_WINO_SPLIT_MIN_C"); return e ? atoi(e) : 256; }();
+            if (on < 2 && l.Cin < min_c) continue;
+            WinoPlan& w = p.wino[si];
+            w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2; w.bm = bm; w.fused = true;
+            const int S = M / (l.H * l.W);
+            const double per_sample = 16.0 * w.th * w.tw * l.Cin * 4.0;
+            const int nchunks = std::max(1, (int)std::ceil(S * per_sample / budget));          // equal chunks
+            w.chunk = (S + nchunks - 1) / nchunks;
+            const size_t P_pad = align_up((size_t)w.chunk * w.th * w.tw, 128);
+            w.v_bytes = align_up((size_t)16 * P_pad * l.Cin * 4, 256);
+            if (w.v_bytes > CONV_MAX_SRC_BYTES) { w = WinoPlan{}; continue; }                 // 32-bit buffer offsets
+            w.m_bytes = 0;
+            wino_scratch = std::max(wino_scratch, w.v_bytes);
+        }
+    }
     { const char* e = getenv("BYOLO_WINOGRAD");
       const int on = (h->precision == 1 || inject) ? 0 : (e ? atoi(e) : 1);   // split precision: direct convolutions only (memory-bound transforms do not pay there); injected masks: conv_igemm's epilogue reads them
       const char* mf = getenv("BYOLO_WINO_MIN_GFLOP");                     // tuning knob: smallest layer (direct GFLOP) to transform
@@ -1066,7 +1169,7 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     const bool per_image = st.mode == STEP_REP || st.mode == STEP_PARTIAL;
     const int64_t S = (l.stacked && !per_image) ? (int64_t)B * T : B;
     p.M = (int)(S * l.H * l.W);
-    p.N = l.filters; p.Npad = st.Npad; p.ldc = l.filters;
+    p.N = layer_pitch(l); p.Npad = st.Npad; p.ldc = layer_pitch(l);      // (a detection head: padded to a multiple of 4, <= Npad)
     p.cin_tiles = (st.c_hi - st.c_lo) / 32; p.KT = l.ksize * l.ksize * p.cin_tiles;
     p.wpk = dptr(h, st.w_off);
     if (st.mode == STEP_PARTIAL) { p.scale = h->d_ones; p.shift = h->d_zeros; }      // raw accumulators
@@ -1206,13 +1309,51 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
     return BYOLO_OK;
 }
 
+// One 3x3 / stride-1 convolution as Winograd F(2x2,3x3) in split-f16 arithmetic (wino_split.hip): per chunk of samples the input
+// transform and ONE launch of GEMM + output transform + epilogue.  `c` = the ConvParams of the direct launch.
+// Profile variants: -4 the transform, 140 the fused launch (carries the direct-convolution FLOPs of its samples).
+static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const ConvParams& c, const WinoPlan& wp, double algo_flops,
+                              char* ws, hipStream_t st) {
+    const bool prof = h->profiling >= 2;
+    int32_t rc;
+    const int S = c.M / (l.H * l.W), tt = wp.th * wp.tw;
+    float* V = reinterpret_cast<float*>(ws + h->plan.wino_off);
+    const bool drop = c.flags & EPI_DROPOUT;
+    for (int s0 = 0; s0 < S; s0 += wp.chunk) {
+        const int ns = std::min(wp.chunk, S - s0);
+        WinoParams w; memset(&w, 0, sizeof w);
+        w.x = c.src0; w.v = V;
+        w.H = l.H; w.W = l.W; w.C = c.C0; w.N = c.N; w.th = wp.th; w.tw = wp.tw;
+        w.s0 = s0; w.P = ns * tt; w.P_pad = (int)align_up((size_t)w.P, 128);
+        w.d_tt = make_fastdiv((uint32_t)tt); w.d_tw = make_fastdiv((uint32_t)wp.tw);
+        w.d_c4 = make_fastdiv((uint32_t)(c.C0 / 4)); w.d_n4 = make_fastdiv((uint32_t)(c.N / 4));
+        w.vmul = 1.f / ACT_SCALE;
+        if (prof && (rc = mark_launch(h, s.layer, -4, w.P, c.C0, 0, 0.0, st))) return rc;
+        HIPCHK(h, launch_wino_split_input(w, st));
+        WinoSplitParams f; memset(&f, 0, sizeof f);
+        const uint64_t rows = (uint64_t)16 * w.P_pad;
+        f.v = V; f.v_bytes = (uint32_t)(rows * c.C0 * 4); f.xi_stride = (uint32_t)((uint64_t)w.P_pad * c.C0 * 4);
+        f.w = dptr(h, s.wino_off); f.w_bytes = (uint32_t)((size_t)16 * c.C0 * c.N * 4);
+        f.y = c.dst; f.scale = dptr(h, drop ? l.wscalek_off : l.wscale_off); f.shift = c.shift;
+        f.C = c.C0; f.N = c.N; f.KT = c.C0 / 32; f.n_tiles = c.N / 128;
+        f.H = l.H; f.W = l.W; f.th = wp.th; f.tw = wp.tw; f.s0 = s0; f.P = w.P; f.P_pad = w.P_pad;
+        f.bm = wp.bm; f.units = (w.P_pad / wp.bm) * f.n_tiles;
+        f.flags = c.flags; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base; f.mask_bits = c.mask_bits;
+        f.status = c.status; f.layer_idx = c.layer_idx;
+        f.d_ntiles = make_fastdiv((uint32_t)f.n_tiles); f.d_tt = w.d_tt; f.d_tw = w.d_tw;
+        if (prof && (rc = mark_launch(h, s.layer, 140, (int64_t)rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
+        HIPCHK(h, launch_wino_split(f, st));
+    }
+    return BYOLO_OK;
+}
+
 static int32_t run_decode(byolo_t* h, char* ws, float* boxes, int B, int T, hipStream_t st) {
     for (const auto& l : h->layers) {
         if (l.op != OP_DETECTION) continue;
         DecodeParams d; memset(&d, 0, sizeof d);
         d.raw = reinterpret_cast<const float*>(ws + h->plan.off[l.out_tensor]);
         d.boxes = boxes; d.lh = l.H; d.lw = l.W; d.C = h->cfg.cls_cnt;
-        d.n_total = h->n_boxes; d.box_base = l.box_base; d.layer_id = l.det_id;
+        d.n_total = h->n_boxes; d.box_base = l.box_base; d.layer_id = l.det_id; d.ld = layer_pitch(l);
         d.status = h->precision == 1 ? h->d_status : nullptr;
         for (int k = 0; k < 3; ++k) { d.ph[k] = l.priors[2 * k]; d.pw[k] = l.priors[2 * k + 1]; }
         if (l.det_kind == BYOLO_DET_EPISTEMIC) { d.B = B; d.T = l.stacked ? T : 1; }
@@ -1368,6 +1509,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         // samples for a de-duplicated launch, nothing for the auxiliary partial launch
         const int64_t S_all = l.stacked ? (int64_t)B * T : B;
         const double algo = s.mode == STEP_PARTIAL ? 0.0 : 2.0 * (double)(S_all * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);
+        if (h->plan.wino[si].chunk > 0 && h->precision == 1) { rc = run_wino_split(h, s, l, p, h->plan.wino[si], algo, ws, st); if (rc) return rc; continue; }
         if (h->plan.wino[si].chunk > 0) { rc = run_winograd(h, s, l, p, h->plan.wino[si], tile, algo, ws, st); if (rc) return rc; continue; }
         if (h->plan.stream1x1[si]) {                            // row-streaming 1x1 convolution / detection head
             const int bn = h->plan.stream1x1[si];
@@ -1445,7 +1587,10 @@ extern "C" int32_t byolo_copy_layer_output(const byolo_t* h, int32_t idx, float*
     if (!d_dst || count != n) return fail(hh, BYOLO_ERR_ARG, "byolo_copy_layer_output: destination of %lld floats, the layer has %lld", (long long)count, (long long)n);
     HIPCHK(hh, hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (h->precision == 1 && h->layers[idx].op != OP_DETECTION) HIPCHK(hh, launch_split_to_f32(src, d_dst, n, 1.f / ACT_SCALE, st));
+    const Layer& l = h->layers[idx];
+    if (h->precision == 1 && l.op != OP_DETECTION) HIPCHK(hh, launch_split_to_f32(src, d_dst, n, 1.f / ACT_SCALE, st));
+    else if (layer_pitch(l) != l.C)                               // a detection head's rows are padded: dense copy
+        HIPCHK(hh, hipMemcpy2DAsync(d_dst, (size_t)l.C * 4, src, (size_t)layer_pitch(l) * 4, (size_t)l.C * 4, (size_t)(n / l.C), hipMemcpyDeviceToDevice, st));
     else HIPCHK(hh, hipMemcpyAsync(d_dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     return BYOLO_OK;
 }
@@ -1549,6 +1694,13 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         if (l.drop_ordinal >= 0) {
             std::vector<float> sk = sc; scale_keep(h, sk);
             HIPCHK(h, hipMemcpyAsync(dptr(h, l.scalek_off), sk.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+        }
+        if (split && s.wino_ok && !l.wshift_u.empty()) {
+            std::vector<float> wsc, wsk;
+            wino_scales(h, l, wsc, wsk);
+            HIPCHK(h, hipMemcpyAsync(dptr(h, l.wscale_off), wsc.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(dptr(h, l.wscalek_off), wsk.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));
             HIPCHK(h, hipStreamSynchronize(st));
         }
         const float* res = l.fused_residual >= 0

@@ -123,7 +123,8 @@ struct WinoSplitParams {
     const float* scale; const float* shift;
     int C, N, KT, n_tiles;                // KT = C / 32 (even), n_tiles = N / 128
     int H, W, th, tw, s0, P, P_pad;       // as WinoParams
-    int units;                            // P_pad / 128 * n_tiles workgroups
+    int bm;                               // output tiles per workgroup: 64 | 128 (P_pad is a multiple of it)
+    int units;                            // P_pad / bm * n_tiles workgroups
     int flags; uint32_t k0, k1, thr; uint64_t idx_base; const uint32_t* mask_bits;
     unsigned* status; int layer_idx;
     FastDiv d_ntiles, d_tt, d_tw;

@@ -20,10 +20,16 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umul
 // ---------------------------------------------------------------------------------------------
 template <int NOUT>
 __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
-    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
-    if (m >= (uint32_t)p.M) return;
+    // The 256 pixels of a block are consecutive rows of the [M][NOUT] output: 256 * NOUT * 4 contiguous bytes.  A thread that
+    // stored its own NOUT * 4 = 128 bytes would touch 64 different lines per wave-store (0.9 TB/s measured); the rows go through
+    // LDS instead (row stride NOUT * 4 + 16: conflict-free 16-byte accesses) and leave as whole lines, 1 KB per wave-store.
+    constexpr int ROWB = NOUT * 4 + 16, PIECES = NOUT / 4;
+    __shared__ __attribute__((aligned(16))) char lds[256 * ROWB];
+    const uint32_t m0 = blockIdx.x * 256u, m = m0 + threadIdx.x;
+    const bool live = m < (uint32_t)p.M;
     const uint32_t hw = (uint32_t)(p.Hout * p.Wout);
-    const uint32_t s = fdiv(m, p.d_hw), rem = m - s * hw;
+    const uint32_t mm = live ? m : 0u;
+    const uint32_t s = fdiv(mm, p.d_hw), rem = mm - s * hw;
     const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * (uint32_t)p.Wout;
     const float* img = p.src0 + (size_t)fdiv(s, p.d_sdiv0) * p.Hs0 * p.Ws0 * 3;
     float x[27];
@@ -46,7 +52,6 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
 #pragma unroll
         for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(x[k], w[k * NOUT + n], acc[n]);
     const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
-    float* d = p.dst + (size_t)m * p.ldc;
     float vmax = 0.f;
 #pragma unroll
     for (int n = 0; n < NOUT; n += 4) {
@@ -57,9 +62,17 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
             v[q] = fmaxf(y, slope * y);
         }
         vmax = epi::absmax4(vmax, v);
-        *reinterpret_cast<f32x4*>(d + n) = (p.split & 2) ? epi::split_encode4(v) : v;    // split precision: [4 hi | 4 lo]
+        *reinterpret_cast<f32x4*>(lds + threadIdx.x * ROWB + n * 4) = (p.split & 2) ? epi::split_encode4(v) : v;    // split precision: [4 hi | 4 lo]
     }
-    if ((p.split & 2) && p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }   // conv_igemm.hip finish_tile
+    if (live && (p.split & 2) && p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }   // conv_igemm.hip finish_tile
+    __syncthreads();
+    float* d = p.dst + (size_t)m0 * p.ldc;          // ldc == NOUT (launcher)
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) {
+        const uint32_t q = k * 256u + threadIdx.x, row = q / PIECES, pc = q % PIECES;
+        if (m0 + row < (uint32_t)p.M)
+            *reinterpret_cast<f32x4*>(d + (size_t)q * 4) = *reinterpret_cast<const f32x4*>(lds + row * ROWB + pc * 16);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, co
 
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st) {
     if (p.ksize == 3 && p.C0 == 3 && p.C1 == 0 && p.sh0 == 0 && p.N == 32 && (p.flags & ~EPI_LEAKY) == 0 && !(p.split & 1) &&
-        (p.ldc & 3) == 0 && p.rep == 1 && !p.addend) {
+        p.ldc == 32 && p.rep == 1 && !p.addend) {
         hipLaunchKernelGGL(conv_stem3x3_kernel<32>, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st, p);
         return hipGetLastError();
     }

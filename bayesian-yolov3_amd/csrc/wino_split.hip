@@ -34,6 +34,8 @@ namespace byk {
 
 using namespace pipe;
 
+// output tiles per workgroup (rows of the transform-domain GEMM)
+
 // ---------------------------------------------------------------------------------------------------------------------
 // input transform: thread = (tile p, 4 channels): 16 x 16-byte loads, 16 x 16-byte stores; hi/lo groups in and out
 // ---------------------------------------------------------------------------------------------------------------------
@@ -92,28 +94,12 @@ hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------------
 // fused GEMM + output transform + epilogue
 // ---------------------------------------------------------------------------------------------------------------------
-// Y[a][b] += cA(a, i) * cA(b, j) * M   for transform point xi = (i, j),  cA = A^T = [1 1 1 0; 0 1 -1 -1]
-template <int XI, int TM>
-__device__ __forceinline__ void wino_fold(f32x16 (&Y)[4][TM], const f32x16 (&M)[TM]) {
-    constexpr int I = XI >> 2, J = XI & 3;
-    constexpr int CA[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int c = CA[a][I] * CA[b][J];
-            if (c == 0) continue;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (c > 0) Y[a * 2 + b][i] += M[i];
-                else Y[a * 2 + b][i] -= M[i];
-            }
-        }
-}
-
-__global__ __launch_bounds__(256, 1) void wino_split_kernel(const WinoSplitParams p) {
+// WINO_BM = output tiles per workgroup (rows of the transform-domain GEMM): 64 -> 230 registers, two workgroups per CU;
+// 128 -> 473 registers (the outputs in the accumulator file), one workgroup per CU
+template <int WINO_BM>
+__global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(const WinoSplitParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using BT = SplitTile<128, 128, 1, 4>;
+    using BT = SplitTile<WINO_BM, 128, 1, 4>;
     constexpr int TM = BT::TM, A_LD = BT::A_LD;            // 4 row blocks of 32 per wave; 4 staging rows per thread
     static_assert(BT::TN == 1, "one 32-column block per wave");
     const BT bt(smem);
@@ -129,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void wino_split_kernel(const WinoSplitParam
     uint32_t a_voff[A_LD];
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        const uint32_t m = rt * 128u + (uint32_t)bt.a_r + 32u * j;
+        const uint32_t m = rt * (uint32_t)WINO_BM + (uint32_t)bt.a_r + 32u * j;
         a_voff[j] = (m * (uint32_t)p.C + (uint32_t)bt.a_q * 4u) * 4u;
     }
     const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.v, p.v_bytes);
@@ -183,18 +169,23 @@ __global__ __launch_bounds__(256, 1) void wino_split_kernel(const WinoSplitParam
             for (int r = 0; r < 16; ++r) M[i][0][r] = 0.f;
         for (uint32_t kt = 0; kt < KT; kt += 2) { ktile(c0{}); ktile(c1{}); }
     };
-    auto fold = [&](auto xi_tag) {
-        f32x16 Mv[TM];
+    // fold M into the four outputs: Y[a][b] += cA(a, i) * cA(b, j) * M for point xi = (i, j), cA = A^T = [1 1 1 0; 0 1 -1 -1].
+    // The coefficients (0, +-1) are block-uniform scalars and every point runs the SAME 4 x 32 fused multiply-adds: a switch
+    // over 16 specialised folds (36 of the 64 (point, output) pairs are non-zero) made the register allocator copy the output
+    // accumulators at the join and spill.
+    auto cA = [](int a, int i) -> float { return a == 0 ? (i < 3 ? 1.f : 0.f) : (i == 0 ? 0.f : (i == 1 ? 1.f : -1.f)); };
+    for (int xi = 0; xi < 16; ++xi) {
+        run_point();
+        const int I = xi >> 2, J = xi & 3;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) Mv[i] = M[i][0];
-        wino_fold<decltype(xi_tag)::value, TM>(Y, Mv);
-    };
-#define BYOLO_WINO_POINT(X) run_point(); fold(std::integral_constant<int, X>{});
-    BYOLO_WINO_POINT(0)  BYOLO_WINO_POINT(1)  BYOLO_WINO_POINT(2)  BYOLO_WINO_POINT(3)
-    BYOLO_WINO_POINT(4)  BYOLO_WINO_POINT(5)  BYOLO_WINO_POINT(6)  BYOLO_WINO_POINT(7)
-    BYOLO_WINO_POINT(8)  BYOLO_WINO_POINT(9)  BYOLO_WINO_POINT(10) BYOLO_WINO_POINT(11)
-    BYOLO_WINO_POINT(12) BYOLO_WINO_POINT(13) BYOLO_WINO_POINT(14) BYOLO_WINO_POINT(15)
-#undef BYOLO_WINO_POINT
+        for (int o = 0; o < 4; ++o) {
+            const float c = cA(o >> 1, I) * cA(o & 1, J);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[o][i][r] = __builtin_fmaf(c, M[i][0][r], Y[o][i][r]);
+        }
+    }
 
     // ---- epilogue: lane = output tile li (+32 per block), 4 groups of 4 consecutive channels from 4 * lh (mfma_pipe.h) ----
     const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT;
@@ -210,7 +201,7 @@ __global__ __launch_bounds__(256, 1) void wino_split_kernel(const WinoSplitParam
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const uint32_t t = rt * 128u + (uint32_t)i * 32u + (uint32_t)bt.li;
+        const uint32_t t = rt * (uint32_t)WINO_BM + (uint32_t)i * 32u + (uint32_t)bt.li;
         if (t >= (uint32_t)p.P) continue;
         const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
         const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
@@ -248,13 +239,17 @@ __global__ __launch_bounds__(256, 1) void wino_split_kernel(const WinoSplitParam
 
 bool wino_split_ok(int C, int N) { return C >= 64 && (C % 64) == 0 && N >= 128 && (N % 128) == 0; }
 
-hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st) {
-    using BT = SplitTile<128, 128, 1, 4>;
-    auto k = wino_split_kernel;
+template <int WINO_BM>
+static hipError_t launch_wino_split_bm(const WinoSplitParams& p, hipStream_t st) {
+    using BT = SplitTile<WINO_BM, 128, 1, 4>;
+    auto k = wino_split_kernel<WINO_BM>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), BT::LDS_BYTES, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)p.units), dim3(256), BT::LDS_BYTES, st, p);
     return hipGetLastError();
+}
+hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st) {
+    return p.bm == 64 ? launch_wino_split_bm<64>(p, st) : launch_wino_split_bm<128>(p, st);
 }
 
 }  // namespace byk

@@ -13,10 +13,11 @@ Weights are random-init with BN statistics calibrated on the device (no checkpoi
 Prints ONE JSON line on rank 0.  `roofline` follows SURVEY.md section 8(d) for the dominant kernel = the matrix-pipe
 kernel with the most device time in the timed region (`by_kernel` lists all of them):
 
-  achieved               USEFUL fp32-equivalent FLOP/s of its launches: 2*M*N*K of a direct convolution launch (for a
-                         Winograd-domain GEMM launch of the fp32 mode the direct-convolution FLOPs of its samples / 2.25);
-                         tile padding is not work.  Time = hipEvents recorded around every launch ON THE LAUNCH STREAM
-                         (byolo_step_profile; the records of all K steps are read AFTER the timed region);
+  achieved               ALGORITHMIC fp32-equivalent FLOP/s of its launches: 2*M*N*K of the convolution as written (SURVEY 8(d)'s
+                         F(H,W,T) is made of these); a Winograd launch stands for the direct-convolution FLOPs of its samples
+                         although its matrix pipe executes 1 / 2.25 of them (`achieved_executed_padded`); tile padding is not
+                         work.  Time = hipEvents recorded around every launch ON THE LAUNCH STREAM (byolo_step_profile; the
+                         records of all K steps are read AFTER the timed region);
   peak / frac            the dense peak of the matrix instruction the kernel issues, every useful FLOP counted ONCE: 2500
                          TFLOP/s (v_mfma_f32_32x32x16_f16) for the split-f16 kernels of the default precision -- which
                          execute three fp16 products per fp32 product, so a split kernel cannot exceed frac 1/3 -- and 157.3
@@ -147,9 +148,10 @@ def time_steps(eng, x, cfg, steps, warmup, first_image=0):
     for age in range(steps * n_sub):
         eng.select_profile(age)
         for s in eng.step_profile():
-            a = acc.setdefault(s["variant"], [0.0, 0.0, 0])
-            a[0] += s["flops"] / 2.25 if s["variant"] in (129, 130) else s["flops"]
+            a = acc.setdefault(s["variant"], [0.0, 0.0, 0, 0.0])
+            a[0] += s["flops"]                                                             # algorithmic (direct-convolution) FLOPs
             a[1] += s["ms"]; a[2] += 1
+            a[3] += s["flops"] / 2.25 if s["variant"] in (129, 130, 140) else s["flops"]   # what the matrix pipe needs for them
     eng.select_profile(0)
     eng.set_profiling(0)
     return dt, acc
@@ -286,7 +288,7 @@ def main():
 
     if prof and rank == 0:
         # the timed region is over: read the K steps' records (age K-1 = the first timed step)
-        WINO = (129, 130)
+        WINO = (129, 130, 140)
         for age in range(args.steps * n_sub - 1, -1, -1):
             eng.select_profile(age)
             for j, s in enumerate(eng.step_profile()):
@@ -297,10 +299,10 @@ def main():
                 # algorithmic bytes of the launch: A operand once + result once + weights once
                 # (a shared-tap 3x3 launch reads its input once: M * K / 9 elements, not the im2col matrix)
                 # (input once + weights once | result once)
-                a[5] += 4.0 * ((s["M"] * s["K"] + 16 * s["K"] * s["N"]) if s["variant"] == 130 else
+                a[5] += 4.0 * ((s["M"] * s["K"] + 16 * s["K"] * s["N"]) if s["variant"] in (130, 140) else
                                (s["M"] * s["K"] // 9 + s["K"] * s["N"]) if s["variant"] in (3128, 3064) else
                                (s["M"] * s["K"] + (16 if wino else 1) * s["K"] * s["N"]))
-                a[6] += 4.0 * ((s["M"] // 4) * s["N"] if s["variant"] == 130 else s["M"] * s["N"])
+                a[6] += 4.0 * ((s["M"] // 4) * s["N"] if s["variant"] in (130, 140) else s["M"] * s["N"])
                 if args.dump_steps:
                     per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / args.steps
             for k, v in eng.stage_ms().items():
@@ -348,11 +350,12 @@ def main():
                                           "arithmetic in this run") if eng.precision == "split" else
                                          "fp32 operands on v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) on the large 3x3 layers"},
         }
-        SPLIT = (3128, 3064, 1128, 1064, 1032)
+        SPLIT = (3128, 3064, 1128, 1064, 1032, 140)
         KERNELS = {3128: "conv_igemm_kernel<128,128,1,4,kx3> (split-f16 3x3/stride-1 on shared-tap stages, v_mfma_f32_32x32x16_f16 x3)",
                    3064: "conv_igemm_kernel<128,64,2,2,kx3> (split-f16 3x3/stride-1 on shared-tap stages)",
                    1128: "conv_igemm_kernel<128,128,1,4,split> (split-f16 1x1 / stride-2 / two-source convolutions)",
                    1064: "conv_igemm_kernel<128,64,2,2,split>", 1032: "conv_igemm_kernel<128,32,4,1,split>",
+                   140: "wino_split_kernel (Winograd F(2x2,3x3) in split-f16: transform-domain GEMM + output transform + epilogue, v_mfma_f32_32x32x16_f16 x3)",
                    130: "wino_fused_kernel (Winograd-domain GEMM + output transform + epilogue, fp32 v_mfma_f32_32x32x2_f32)",
                    129: "gemm_stream_kernel<128,0> (Winograd-domain GEMM, fp32 v_mfma_f32_32x32x2_f32)",
                    131: "gemm_stream_kernel<128,1> (row-streaming 1x1 convolution)",
@@ -368,11 +371,13 @@ def main():
             dom = max(mm, key=lambda v: acc[v][1])
             f, ms, n, fx, fu, abr, abw = acc[dom]
             tot_f = sum(a[0] for a in acc.values()); tot_ms = sum(a[1] for a in acc.values())
-            ach = fu / (ms * 1e-3)
+            # achieved: the ALGORITHMIC FLOPs the launches stand for (direct-convolution 2*M*N*K per layer; a Winograd
+            # launch carries the direct-convolution FLOPs of its samples, although its matrix pipe executes 1 / 2.25 of them)
+            ach = f / (ms * 1e-3)
             split = dom in SPLIT
             # peak of the matrix instruction actually issued, useful FLOPs counted once
             peak = PEAK_F16_MFMA if split else PEAK_FP32_MFMA
-            wino_ms = sum(acc[v][1] for v in (-2, -3) if v in acc)
+            wino_ms = sum(acc[v][1] for v in (-2, -3, -4) if v in acc)
             # fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same command
             # (tools/profile_round.sh + tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent / another kernel
             traffic = tr_read = tr_write = measured_at = None
@@ -396,19 +401,21 @@ def main():
                                 "write_amplification": (tr_write / ab_w) if tr_write else None,
                                 "kernel": KERNELS[dom],
                                 "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
-                                "definition": "SURVEY.md 8(d): achieved = useful fp32-equivalent FLOPs (direct launch: 2MNK; Winograd-domain GEMM of "
-                                              "the fp32 mode: direct-convolution FLOPs of its samples / 2.25; tile padding not counted), each counted ONCE, "
+                                "definition": "SURVEY.md 8(d): achieved = algorithmic fp32-equivalent FLOPs of the launches (2MNK of the convolution as written; a "
+                                              "Winograd launch stands for the direct-convolution FLOPs of its samples; tile padding not counted), each counted ONCE, "
                                               "/ hipEvent time of the launches on their launch stream; peak = dense peak of the matrix instruction issued ("
                                               + ("v_mfma_f32_32x32x16_f16, 2500: a split-f16 kernel executes three fp16 products per useful product, so its "
                                                  "frac cannot exceed 1/3" if split else "v_mfma_f32_32x32x2_f32, 157.3") + ")",
+                                # what the matrix pipe executed for them (padded extents; Winograd: 16 transform-domain GEMMs = direct / 2.25)
                                 "achieved_executed_padded": fx / (ms * 1e-3) / 1e12,
                                 "share_of_conv_time": ms / tot_ms, "winograd_transform_share_of_conv_time": wino_ms / tot_ms,
                                 # algorithmic (direct-convolution) FLOPs of the whole conv stack / its time, transforms included
                                 "all_conv_algorithmic": tot_f / (tot_ms * 1e-3) / 1e12,
                                 "by_kernel": {KERNELS[v].split(" ")[0]: {"launches": acc[v][2], "ms": acc[v][1],
-                                                                          "useful_tflops": acc[v][4] / (acc[v][1] * 1e-3) / 1e12,
+                                                                          "algorithmic_tflops": acc[v][0] / (acc[v][1] * 1e-3) / 1e12,
                                                                           "executed_tflops": acc[v][3] / (acc[v][1] * 1e-3) / 1e12}
                                               for v in sorted(mm, key=lambda v: -acc[v][1])},
+                                "transform_kernels_ms": {str(v): acc[v][1] for v in (-2, -3, -4) if v in acc},
                                 # 8(d)'s formula for the whole step: img/s * F(H,W,T) / (n_gpu * peak); and against the fp32 MFMA peak the
                                 # reference's own arithmetic would be priced at (> 1 = beyond that instruction's ceiling)
                                 "end_to_end_frac": (imgs / dt) * flops_img / (world * peak),
@@ -436,6 +443,8 @@ def main():
                                      "dtype": "f32 (v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) on the large 3x3 layers)",
                                      "dominant_kernel": KERNELS[d32], "launches": acc32[d32][2],
                                      "achieved": a32 / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "frac": a32 / PEAK_FP32_MFMA,
+                                     "achieved_executed": acc32[d32][3] / (acc32[d32][1] * 1e-3) / 1e12,
+                                     "frac_executed": acc32[d32][3] / (acc32[d32][1] * 1e-3) / PEAK_FP32_MFMA,
                                      "headline_speedup_over_fp32_mode": (imgs / dt) / (B * args.fp32_steps / dt32)}
                 m32.engine.close()
                 del m32

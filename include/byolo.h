@@ -180,7 +180,10 @@ BYOLO_API int32_t byolo_set_first_image(byolo_t* h, int64_t first_image);
 BYOLO_API int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images);
 /* After a forward with keep_all_outputs: device pointer + NHWC shape of layer `idx`'s output
  * (the reference's model.layers[idx], model.py:191); for detection layers the raw conv output
- * (DetLayer.raw_output, model.py:241) -- those are readable on any handle (they are never overwritten). */
+ * (DetLayer.raw_output, model.py:241) -- those are readable on any handle (they are never overwritten).
+ * The pointer addresses the library's own storage: hi/lo pairs under BYOLO_PREC_SPLIT_F16, and a detection head's rows
+ * are padded to a multiple of 4 floats (shape[3] = 21 / 42 / .. is the logical count): read tensors through
+ * byolo_copy_layer_output, which hands out dense float32. */
 BYOLO_API int32_t byolo_layer_output(const byolo_t* h, int32_t idx, const float** d_ptr, int64_t shape[4]);
 /* The same tensor as float32 values, copied into caller-owned device memory d_dst[count] (count = the product of the
  * shape) on `stream`.  Under BYOLO_PREC_SPLIT_F16 the pointer of byolo_layer_output addresses the hi/lo pairs the

@@ -90,7 +90,12 @@ def test_config4_as_benched(precision, monkeypatch):
     if precision == "split":
         kx = [s for s in launches if s["variant"] in (3128, 3064)]
         big = [s for s in kx if s["flops"] > 5e11 and s["variant"] == 3128]     # 817.6 GFLOP each
-        assert len(big) == 9 and {s["K"] for s in big} == {1152, 2304, 4608}, "the nine big head 3x3 convolutions run on the shared-tap kernel: %s" % v
+        wino = [s for s in launches if s["variant"] == 140]                     # Winograd in split arithmetic: carries its layer's direct FLOPs
+        # the nine big head 3x3 convolutions: 19x19 / 38x38 (512 / 256 input channels) as Winograd F(2x2,3x3) in split arithmetic
+        # (csrc/wino_split.hip), 76x76 (128 channels) on the shared-tap direct kernel
+        assert len(big) == 3 and {s["K"] for s in big} == {1152}, "the 76x76 head 3x3 convolutions run on the shared-tap kernel: %s" % v
+        assert {s["K"] for s in wino} == {256, 512} and abs(sum(s["flops"] for s in wino) - 6 * 817.6e9) < 1e10, "six head convolutions as Winograd: %s" % v
+        assert v.get(-4, 0) == len(wino), "one input transform per fused Winograd launch: %s" % v
         assert not any(s["variant"] in (128, 64, 32, 129, 130, 131, 132, -2, -3) for s in launches), "an fp32-mode kernel ran: %s" % v
         _compare(cfg, eng, imgs, out, (0, cfg["B"] - 1), 1000, "config 4 (608x608 T=30 B=8, split-f16)")
         return

@@ -472,6 +472,38 @@ def test_winograd_on_every_eligible_layer(variant, fused, monkeypatch, precision
     assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
 
 
+@pytest.mark.parametrize("bm", ["64", "128"])
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, monkeypatch, precision):
+    """Default precision: the large 3x3 / stride-1 head convolutions as Winograd F(2x2,3x3) in split-f16 arithmetic
+    (csrc/wino_split.hip: hi/lo input transform, then GEMM + output transform + epilogue in one launch).  BYOLO_WINO_SPLIT=2
+    forces it on EVERY eligible layer, both workgroup shapes: odd grids (2x3 ... 8x12 pad to 2x2 tiles), dropout and BN-only
+    layers.  Same rows as the fixtures of the reference's graph at the same bound, close to the direct path, and the launch
+    list shows the fused kernel."""
+    if precision != "split":
+        pytest.skip("Winograd in split arithmetic belongs to the default precision")
+    B = 1 if variant.startswith("bayes") else 2
+    monkeypatch.setenv("BYOLO_WINO_SPLIT", "0")
+    _, direct, _, _ = _run(variant, B, keep_all=False)
+    monkeypatch.setenv("BYOLO_WINO_SPLIT", "2")
+    monkeypatch.setenv("BYOLO_WINO_SPLIT_BM", bm)
+    m, wino, params, imgs = _run(variant, B)
+    m.engine.set_profiling(2)
+    torch = _torch()
+    m.run(torch.from_numpy(imgs).cuda(), seed=42)
+    torch.cuda.synchronize()
+    v = [s["variant"] for s in m.engine.step_profile()]
+    m.engine.set_profiling(0)
+    assert v.count(140) >= 9 and v.count(-4) == v.count(140), "fused Winograd launches: %s" % v
+    g = golden("fwd_%s.npz" % variant)
+    gb = g["bbox"] if g["bbox"].ndim == 3 else g["bbox"][None]
+    for k, dl in enumerate(m.det_layers):
+        assert_close(dl.raw_output.cpu().numpy(), g["raw_%d" % k], "%s raw det output %d (winograd, split)" % (variant, k))
+    assert_close(wino["boxes"].cpu().numpy(), gb, "%s pre-NMS rows (winograd, split)" % variant)
+    assert_close(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy(), "%s winograd vs direct (split)" % variant)
+    assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
+
+
 def test_first_image_makes_shards_equal_the_whole_batch():
     """byolo_set_first_image: image j of a shard / sub-batch draws the dropout masks of image first_image + j of the
     logical batch, so pieces equal the unsplit run (fp32 re-association aside: tile and split-K choices depend on
