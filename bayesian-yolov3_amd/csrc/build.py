@@ -17,17 +17,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvi
          "-Wall", "-Wno-unused-result"]
 
 
-def build(force=False, verbose=False, ablate=0, ablate_wf=0):
+def build(force=False, verbose=False, ablate=0, ablate_wf=0, ablate_ws=0):
     # ablate: timing-ablation build of the convolution K loop (conv_igemm.hip), written next to the product
     # library as libbyolo_abl<N>.so and loaded with BYOLO_LIB=<path>; never the default
     out = os.path.abspath(OUT if not ablate else OUT.replace("libbyolo.so", "libbyolo_abl%d.so" % ablate))
     if ablate_wf:       # same for the fused Winograd kernel (wino_fused.hip): libbyolo_wf<N>.so
         out = os.path.abspath(OUT.replace("libbyolo.so", "libbyolo_wf%d.so" % ablate_wf))
+    if ablate_ws:       # and for the split-arithmetic Winograd kernel (wino_split.hip): libbyolo_ws<N>.so
+        out = os.path.abspath(OUT.replace("libbyolo.so", "libbyolo_ws%d.so" % ablate_ws))
     newest = max(os.path.getmtime(os.path.join(HERE, d)) for d in DEPS)
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + (["-DBYOLO_CONV_ABLATE=%d" % ablate] if ablate else []) + (["-DBYOLO_WF_ABLATE=%d" % ablate_wf] if ablate_wf else []) + [os.path.join(HERE, s) for s in SRCS] + ["-o", out]
+    cmd = [hipcc] + FLAGS + (["-DBYOLO_CONV_ABLATE=%d" % ablate] if ablate else []) + (["-DBYOLO_WF_ABLATE=%d" % ablate_wf] if ablate_wf else []) + (["-DBYOLO_WS_ABLATE=%d" % ablate_ws] if ablate_ws else []) + [os.path.join(HERE, s) for s in SRCS] + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -37,4 +39,5 @@ def build(force=False, verbose=False, ablate=0, ablate_wf=0):
 if __name__ == "__main__":
     abl = int(sys.argv[sys.argv.index("--ablate") + 1]) if "--ablate" in sys.argv else 0
     wf = int(sys.argv[sys.argv.index("--ablate-wf") + 1]) if "--ablate-wf" in sys.argv else 0
-    print(build(force="--force" in sys.argv, verbose=True, ablate=abl, ablate_wf=wf))
+    wsa = int(sys.argv[sys.argv.index("--ablate-ws") + 1]) if "--ablate-ws" in sys.argv else 0
+    print(build(force="--force" in sys.argv, verbose=True, ablate=abl, ablate_wf=wf, ablate_ws=wsa))

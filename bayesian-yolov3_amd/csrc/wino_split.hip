@@ -34,6 +34,13 @@ namespace byk {
 
 using namespace pipe;
 
+// Timing ablations (build.py --ablate-ws N -> libbyolo_ws<N>.so, loaded with BYOLO_LIB=...; results are WRONG by construction):
+// 1 no weight-fragment loads in the loop, 2 no fold, 4 no activation loads / LDS staging in the loop, 8 no accumulator clears.
+#ifndef BYOLO_WS_ABLATE
+#define BYOLO_WS_ABLATE 0
+#endif
+static constexpr int WS_ABL = BYOLO_WS_ABLATE;
+
 // output tiles per workgroup (rows of the transform-domain GEMM)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -125,15 +132,19 @@ __global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(
     const uint32_t w_step = (uint32_t)p.N * BK * 4;                        // one K-tile of all column blocks (N / 32 blocks of 4 KB)
     uint32_t a_soff = 0, a_kt = 0, a_xi_base = 0;                          // the NEXT tile to load
     uint32_t w_soff = ct * (128 / 32) * SPLIT_WBLOCK;
-    f32x4 a_reg[A_LD];
+    // V streams from HBM (a chunk is far larger than the caches) and a K-tile of this tile is short (12 MFMAs per wave): the
+    // activations of tile t + 1 + NSET are fetched while tile t multiplies, into a ring of NSET staging sets (timing ablation
+    // with one set: without the activation path the launch ran 35 % faster -- the loop was waiting for its loads)
+    constexpr int NSET = WINO_BM == 64 ? 4 : 2;
+    f32x4 a_reg[NSET][A_LD];
     f16x8 bfr[2][2][1][2];
     auto next_tile = [&]() {
         a_soff = a_xi_base + a_kt * (BK * 4);
         if (++a_kt == KT) { a_kt = 0; a_xi_base += p.xi_stride; }          // past point 15: beyond v_bytes -> zeros
     };
-    auto load_a = [&]() {
+    auto load_a = [&](auto set_tag) {
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) a_reg[j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
+        for (int j = 0; j < A_LD; ++j) a_reg[decltype(set_tag)::value][j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
     };
     auto load_b = [&](auto set_tag) { bt.load_b(bfr[decltype(set_tag)::value], w_rsrc, w_soff); w_soff += w_step; };
 
@@ -148,26 +159,37 @@ __global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
     f16x8 af0[TM][2], af1[TM][2];
-    next_tile(); load_a(); load_b(c0{});
-    bt.template store_a<0>(a_reg);
-    next_tile(); load_a();
+    next_tile(); load_a(c0{}); load_b(c0{});
+    bt.template store_a<0>(a_reg[0]);
+    {   // tiles 1 .. NSET wait in the sets 1 .. NSET - 1, 0
+        next_tile(); load_a(std::integral_constant<int, 1 % NSET>{});
+        next_tile(); load_a(std::integral_constant<int, 2 % NSET>{});
+        if constexpr (NSET == 4) { next_tile(); load_a(std::integral_constant<int, 3>{}); next_tile(); load_a(c0{}); }
+    }
     __syncthreads();
     bt.template read_frags<0, 0>(af0);
 
     // one K-tile in LDS buffer BUF: the uniform body of the split pipeline (mfma_pipe.h tile_body_split) -- stage tile t+1,
     // fetch tile t+2 and the weight fragments of t+1; past the end the loads read zeros and what they stage is never used
-    auto ktile = [&](auto buf_tag) {
+    // K-tile t: LDS buffer BUF = t & 1; tile t + 1 is staged from set SET = (t + 1) % NSET, which then receives tile t + 1 + NSET
+    auto ktile = [&](auto buf_tag, auto set_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
-        pipe::tile_body_split<BUF, true, BT::NBF, A_LD, A_LD, 0>(
-            bt, M, af0, af1, bfr[BUF], [&] { load_b(std::integral_constant<int, BUF ^ 1>{}); },
-            [&] { next_tile(); load_a(); }, [&] { bt.template store_a<BUF ^ 1>(a_reg); });
+        using ST = decltype(set_tag);
+        pipe::tile_body_split<BUF, true, (WS_ABL & 1) ? 0 : BT::NBF, (WS_ABL & 4) ? 0 : A_LD, (WS_ABL & 4) ? 0 : A_LD, 0>(
+            bt, M, af0, af1, bfr[(WS_ABL & 1) ? 0 : BUF], [&] { load_b(std::integral_constant<int, BUF ^ 1>{}); },
+            [&] { next_tile(); load_a(ST{}); }, [&] { if constexpr (!(WS_ABL & 4)) bt.template store_a<BUF ^ 1>(a_reg[ST::value]); });
     };
     auto run_point = [&]() {
+        if constexpr (!(WS_ABL & 8)) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) M[i][0][r] = 0.f;
-        for (uint32_t kt = 0; kt < KT; kt += 2) { ktile(c0{}); ktile(c1{}); }
+                for (int r = 0; r < 16; ++r) M[i][0][r] = 0.f;
+        }
+        using c2 = std::integral_constant<int, 2>;
+        using c3 = std::integral_constant<int, 3>;
+        if constexpr (NSET == 4) { for (uint32_t kt = 0; kt < KT; kt += 4) { ktile(c0{}, c1{}); ktile(c1{}, c2{}); ktile(c0{}, c3{}); ktile(c1{}, c0{}); } }
+        else { for (uint32_t kt = 0; kt < KT; kt += 2) { ktile(c0{}, c1{}); ktile(c1{}, c0{}); } }
     };
     // fold M into the four outputs: Y[a][b] += cA(a, i) * cA(b, j) * M for point xi = (i, j), cA = A^T = [1 1 1 0; 0 1 -1 -1].
     // The coefficients (0, +-1) are block-uniform scalars and every point runs the SAME 4 x 32 fused multiply-adds: a switch
@@ -177,6 +199,7 @@ __global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(
     for (int xi = 0; xi < 16; ++xi) {
         run_point();
         const int I = xi >> 2, J = xi & 3;
+        if constexpr (WS_ABL & 2) { if (xi != 15) continue; }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const float c = cA(o >> 1, I) * cA(o & 1, J);
@@ -237,7 +260,7 @@ __global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(
     if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
 }
 
-bool wino_split_ok(int C, int N) { return C >= 64 && (C % 64) == 0 && N >= 128 && (N % 128) == 0; }
+bool wino_split_ok(int C, int N) { return C >= 128 && (C % 128) == 0 && N >= 128 && (N % 128) == 0; }     // K-tiles in groups of 4
 
 template <int WINO_BM>
 static hipError_t launch_wino_split_bm(const WinoSplitParams& p, hipStream_t st) {
