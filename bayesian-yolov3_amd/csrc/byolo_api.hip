@@ -100,6 +100,7 @@ struct Step {
     size_t w_off = 0; int Npad = 0, tile = 0;   // packed weights of this launch
     bool wino_ok = false;          // 3x3 / stride 1 over one plain source: Winograd F(2x2,3x3) is possible
     size_t wino_off = 0;           // the 16 transformed weight matrices U[xi], each packed [Cin/32][Npad][32]
+    bool p1 = false;               // split precision: 1x1 / stride 1 over one plain source -- the uniform loop of conv_tile_p1 (BYOLO_P1=0: the general loop)
     bool kx3 = false;              // split precision: 3x3 / stride 1 over one plain source -- shared-tap stages (conv_tile_kx3), weights in (ky, chunk, kx) order
 };
 // per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
@@ -763,7 +764,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         if (!st.is_conv()) continue;
         const Layer& l = h->layers[st.layer];
         const int Cs = st.c_hi - st.c_lo, taps = l.ksize * l.ksize, N = l.filters;
-        st.kx3 = false;
+        st.kx3 = false; st.p1 = false;
         const float* w = h->params[l.p_kernel].data.data();     // HWIO == [K][N], k = (ky*ks + kx)*Cin + c
         float* dst = blob.data() + st.w_off;
         if (l.direct) memcpy(dst, w, sizeof(float) * (size_t)taps * l.Cin * N);
@@ -771,6 +772,8 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
             static const bool kx3_on = [] { const char* e = getenv("BYOLO_KX3"); return !e || atoi(e) != 0; }();
             st.kx3 = kx3_on && l.ksize == 3 && l.stride == 1 && st.in.n == 1 && st.in.s[0].sh == 0 && st.in.s[0].layer >= 0 && st.Npad >= 64 &&
                      (st.mode == STEP_NORMAL || st.mode == STEP_REP);
+            static const bool p1_on = [] { const char* e = getenv("BYOLO_P1"); return !e || atoi(e) != 0; }();
+            st.p1 = p1_on && l.ksize == 1 && l.stride == 1 && st.in.n == 1 && st.in.s[0].layer >= 0 && st.Npad >= 64;
             const int cts = Cs / 32;
             // split-f16 weights (mfma_pipe.h): w' = w * 2^wshift with the layer's largest |w'| in [2^13, 2^14), each
             // element as hi = RNE_f16(w'), lo = RNE_f16(w' - hi), in FRAGMENT ORDER: [K-tile][32-column block][step s]
@@ -976,7 +979,7 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
         // split precision: only the shared-tap 3x3 kernel has a 128-wide tile (the plain kernel would need scratch memory there);
         // the 1x1 / stride-2 / concat convolutions run on the 64-wide tile, which also keeps twice the workgroups in flight per
         // byte streamed for the HBM-latency-bound 76x76 head layers (measured at config 4: 0.83 -> 0.56, 0.77 -> 0.67 ms)
-        if (h->precision == 1) tile = conv_split_tile(tile, s.kx3);
+        if (h->precision == 1) tile = conv_split_tile(tile, s.kx3 || s.p1);
         else if (inject && tile == TILE_128x128) tile = TILE_128x64;      // the fp32 128-wide build has no mask-injection path (conv_igemm.hip)
         p.tile[si] = tile;
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
@@ -1185,6 +1188,7 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     // matrix-pipe launches: 1 = split-f16 operands; direct launches: bit 0 = the sources are hi/lo tensors, bit 1 = so is the output
     p.split = h->precision != 1 ? 0 : (!l.direct ? 1 : ((l.prev >= 0 ? 1 : 0) | (l.op == OP_DETECTION ? 0 : 2)));
     if (p.split && st.kx3) { p.kx3 = 1; p.KT = 3 * p.cin_tiles; }       // scheduling unit = stage (ky, chunk) = 3 K-tiles
+    else if (p.split && st.p1) p.kx3 = 2;
     if (st.mode == STEP_MAIN) {
         p.addend = reinterpret_cast<const float*>(ws + h->plan.off[st.addend_tensor]);
         p.addend_T = l.stacked ? T : 1;
@@ -1529,7 +1533,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
             HIPCHK(h, launch_gemm_stream(q, st));
             continue;
         }
-        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile) + (p.kx3 ? 3000 : (p.split ? 1000 : 0)), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st, l.direct ? 1 : (sp.sk_grid > 0 ? -sp.sk_grid : sp.ksplit), l.direct ? 0 : sp.split_tiles); if (rc) return rc; }
+        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile) + (p.kx3 == 1 ? 3000 : (p.kx3 == 2 ? 2000 : (p.split ? 1000 : 0))), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st, l.direct ? 1 : (sp.sk_grid > 0 ? -sp.sk_grid : sp.ksplit), l.direct ? 0 : sp.split_tiles); if (rc) return rc; }
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, tile, st));
     }
     if (per_step) {
@@ -1671,7 +1675,7 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         ConvParams p; fill_conv(h, s, d_img, ws, B, 1, p);
         if (!s.is_conv()) { int32_t rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
         const bool split = h->precision == 1;
-        const int ctile = split ? conv_split_tile(s.tile, s.kx3) : s.tile;
+        const int ctile = split ? conv_split_tile(s.tile, s.kx3 || s.p1) : s.tile;
         if (l.op == OP_DETECTION) { if (split) p.flags |= EPI_F32OUT; HIPCHK(h, launch_conv_igemm(p, ctile, st)); continue; }
         // raw conv output (+ addend for STEP_MAIN), fp32; split precision: the accumulators, ACT_SCALE * 2^wshift * conv
         p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = split ? (s.mode == STEP_PARTIAL ? EPI_RAW : EPI_F32OUT) : 0;

@@ -70,7 +70,8 @@ struct ConvParams {
     int flags;                        // EPI_*
     int split;                        // matrix-pipe launch: 1 = split-f16 sources / weights / residual / output (mfma_pipe.h), 0 = fp32;
                                       // direct launch: bit 0 = sources and residual are hi/lo tensors, bit 1 = the output is
-    int kx3;                          // split 3x3 / stride-1 launch on shared-tap stages (conv_tile_kx3): weights packed in (ky, chunk, kx) order, KT counts stages
+    int kx3;                          // split launch: 1 = 3x3 / stride 1 on shared-tap stages (conv_tile_kx3): weights packed in (ky, chunk, kx) order, KT counts
+                                      // stages; 2 = 1x1 / stride 1 over one plain source on the uniform loop (conv_tile_p1)
     uint32_t k0, k1, thr;             // dropout keys (byolo_rng.h)
     uint64_t idx_base;                // dropout element index of dst[0] (sub-batch / shard of a logical batch)
     // injected dropout masks (byolo_forward's d_mask_bits; lib_yolo/layers.py:521-524 with the caller's own Bernoulli draw):
@@ -182,7 +183,7 @@ size_t conv_split_slab_bytes(const ConvSplit& sp, int tile);
 enum : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2 };
 int conv_tile_bn(int tile);           // BN of a tile config
 int conv_pick_tile(int N);            // tile config for cout = N
-int conv_split_tile(int tile, bool kx3);   // split precision: 128-wide tiles exist for the shared-tap 3x3 kernel only
+int conv_split_tile(int tile, bool wide);  // split precision: 128-wide tiles exist for the shared-tap 3x3 and the 1x1 kernels only
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st);
 // a route / upsample / stack view copied into a dense [M][C0 + C1] tensor (sources, extents and dst as in ConvParams)
 hipError_t launch_view_gather(const ConvParams& p, hipStream_t st);

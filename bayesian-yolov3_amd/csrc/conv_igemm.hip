@@ -642,6 +642,78 @@ __device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, 
     finish_tile<BM, BN, WM, WN, true>(p, smem, acc, tile_m, tile_n, sh);
 }
 
+// 1x1 / stride-1 convolution over ONE plain source, split-f16: K-tiles [kt_begin, kt_end) of the tile on a UNIFORM, tail-free loop.
+// These launches -- the 1x1 convolutions of the heads, the stacked half of the concat convolutions, the detection heads -- have
+// short K loops (8 .. 32 K-tiles) and stream their input from HBM, and they were waiting: for loads fetched one K-tile ahead
+// and at one barrier per 12 MFMAs on the 64-wide tile.  Here the activations of tile t + 3 are fetched while tile t multiplies
+// (two staging sets), every K-tile stages its successor whether or not it exists (past the end the loads read the next rows'
+// bytes or zeros, staged and never multiplied), and without tail copies of the body the 128 x 128 tile (24 MFMAs per wave and
+// barrier, the input read once for 128 columns) stays inside 256 registers.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_tile_p1(const ConvParams& p, float* smem, const int logical, const int kt_begin,
+                                             const int kt_end, const TileShare sh) {
+    using BT = SplitTile<BM, BN, WM, WN>;
+    constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD;
+    const BT bt(smem);
+    const uint32_t n_tiles = (uint32_t)p.Npad / BN;
+    const uint32_t tile_m = fdiv((uint32_t)logical, p.d_ntiles), tile_n = (uint32_t)logical - tile_m * n_tiles;
+    const uint32_t hw = (uint32_t)(p.Hout * p.Wout);
+    uint32_t a_voff[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const uint32_t m = tile_m * BM + bt.a_r + (NT / 8) * j;
+        const uint32_t mm = m < (uint32_t)p.M ? m : 0u;
+        // the source may be a T-fold tile of an unstacked tensor (sample / T) and / or read through a nearest x2 upsample
+        // ((y >> 1, x >> 1): the stacked half of the heads' concat convolutions, lib_yolo/layers.py:578-580)
+        const uint32_t s = fdiv(mm, p.d_hw), rem = mm - s * hw;
+        const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * (uint32_t)p.Wout;
+        const uint32_t row = (fdiv(s, p.d_sdiv0) * (uint32_t)p.Hs0 + (oy >> p.sh0)) * (uint32_t)p.Ws0 + (ox >> p.sh0);
+        a_voff[j] = m < (uint32_t)p.M ? (row * (uint32_t)p.C0 + (uint32_t)bt.a_q * 4u) * 4u : CONV_OOB_OFFSET;
+    }
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.src0, p.src0_bytes);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wpk, p.w_bytes);
+    const uint32_t w_step = (uint32_t)p.Npad * BK * 4;
+    uint32_t a_soff = (uint32_t)kt_begin * (BK * 4);                      // the NEXT tile to load
+    uint32_t w_soff = (uint32_t)kt_begin * w_step + tile_n * (BN / 32) * SPLIT_WBLOCK;
+    f32x4 a_reg[2][A_LD];
+    f16x8 bfr[2][2][TN][2];
+    auto load_a = [&](auto set_tag) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) a_reg[decltype(set_tag)::value][j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
+        a_soff += BK * 4;
+    };
+    auto load_b = [&](auto set_tag) { bt.load_b(bfr[decltype(set_tag)::value], w_rsrc, w_soff); w_soff += w_step; };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    f16x8 af0[TM][2], af1[TM][2];
+    load_a(c0{}); load_b(c0{});
+    bt.template store_a<0>(a_reg[0]);
+    load_a(c1{}); load_a(c0{});                                           // tiles 1 and 2 wait in the sets 1 and 0
+    __syncthreads();
+    bt.template read_frags<0, 0>(af0);
+    auto ktile = [&](auto buf_tag) {                                      // tile t in LDS buffer BUF = t & 1; set BUF ^ 1 holds tile t + 1, then t + 3
+        constexpr int BUF = decltype(buf_tag)::value;
+        using NX = std::integral_constant<int, BUF ^ 1>;
+        pipe::tile_body_split<BUF, true, BT::NBF, A_LD, A_LD, 0>(
+            bt, acc, af0, af1, bfr[BUF], [&] { load_b(NX{}); }, [&] { load_a(NX{}); }, [&] { bt.template store_a<BUF ^ 1>(a_reg[BUF ^ 1]); });
+    };
+    const int n = kt_end - kt_begin;
+    int t = 0;
+    for (; t + 1 < n; t += 2) { ktile(c0{}); ktile(c1{}); }
+    if (t < n) ktile(c0{});
+    __syncthreads();                              // the trailing LDS traffic of the uniform body is done before LDS is reused
+    finish_tile<BM, BN, WM, WN, true>(p, smem, acc, tile_m, tile_n, sh);
+}
+
 // Workgroups walk the tile list with stride gridDim.x: with gridDim.x == #tiles every workgroup owns one
 // tile; with a smaller (persistent) grid a workgroup runs several tiles back to back.  Either way the
 // tiles that are in flight on one XCD at a time are neighbours.
@@ -650,7 +722,8 @@ __device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, 
 //  number)
 // 2nd launch bound = waves per SIMD: two workgroups per CU (what the LDS allows for the 128x128 tile) must
 // also fit the register file, i.e. VGPRs + AGPRs <= 256 per wave.
-template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT, bool KX3 = false>
+// KX3: 0 the (tap, chunk) loop of conv_tile, 1 shared-tap 3x3 stages (conv_tile_kx3), 2 the 1x1 loop (conv_tile_p1)
+template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT, int KX3 = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // One loop, one inlined conv_tile: the work items of this workgroup are either
@@ -701,7 +774,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kern
                 sh = TileShare{tile_local, tile_local * p.ksplit + slice, p.ksplit, tile_local * p.ksplit, 1, 0};
             }
         }
-        if constexpr (KX3) conv_tile_kx3<BM, BN, WM, WN>(p, smem, logical, kb, ke, sh);    // p.KT, kb, ke count STAGES (3 K-tiles)
+        if constexpr (KX3 == 1) conv_tile_kx3<BM, BN, WM, WN>(p, smem, logical, kb, ke, sh);    // p.KT, kb, ke count STAGES (3 K-tiles)
+        else if constexpr (KX3 == 2) conv_tile_p1<BM, BN, WM, WN>(p, smem, logical, kb, ke, sh);
         else conv_tile<BM, BN, WM, WN, FAST, SPLIT>(p, smem, logical, kb, ke, sh);
     }
 }
@@ -709,7 +783,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kern
 int conv_tile_bn(int tile) { return tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32); }
 
 // split precision: the tile configuration a launch really runs on
-int conv_split_tile(int tile, bool kx3) { return (tile == TILE_128x128 && !kx3) ? TILE_128x64 : tile; }
+int conv_split_tile(int tile, bool wide) { return (tile == TILE_128x128 && !wide) ? TILE_128x64 : tile; }
 
 int conv_pick_tile(int N) {
     if (N > 64) return TILE_128x128;
@@ -717,9 +791,9 @@ int conv_pick_tile(int N) {
     return TILE_128x32;
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT, bool KX3 = false>
+template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT, int KX3 = 0>
 static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
-    constexpr size_t lds = KX3 ? (size_t)SplitTileKx<BM, BN, WM, WN>::LDS_BYTES : (SPLIT ? (size_t)SplitTile<BM, BN, WM, WN>::LDS_BYTES : (size_t)BlockTile<BM, BN, WM, WN>::LDS_BYTES);
+    constexpr size_t lds = KX3 == 1 ? (size_t)SplitTileKx<BM, BN, WM, WN>::LDS_BYTES : (SPLIT ? (size_t)SplitTile<BM, BN, WM, WN>::LDS_BYTES : (size_t)BlockTile<BM, BN, WM, WN>::LDS_BYTES);
     auto k = conv_igemm_kernel<BM, BN, WM, WN, FAST, SPLIT, KX3>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), lds, attr_done); e != hipSuccess) return e;
@@ -817,9 +891,13 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     if (p.split != (SPLITCFG ? 1 : 0)) return hipErrorInvalidValue;
     if constexpr (SPLITCFG) {
         if constexpr (BN >= 64) {
-            if (p.kx3) {
+            if (p.kx3 == 1) {
                 if (!fast || p.ksize != 3 || p.stride != 1) return hipErrorInvalidValue;
-                return launch_one<BM, BN, WM, WN, true, true, true>(q, grid, st);
+                return launch_one<BM, BN, WM, WN, true, true, 1>(q, grid, st);
+            }
+            if (p.kx3 == 2) {
+                if (p.C1 != 0 || p.ksize != 1 || p.stride != 1) return hipErrorInvalidValue;
+                return launch_one<BM, BN, WM, WN, true, true, 2>(q, grid, st);
             }
         }
         // (the plain split kernel is not built for the 128-wide tile: it needs more than 256 registers there, and this

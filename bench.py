@@ -350,9 +350,11 @@ def main():
                                           "arithmetic in this run") if eng.precision == "split" else
                                          "fp32 operands on v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) on the large 3x3 layers"},
         }
-        SPLIT = (3128, 3064, 1128, 1064, 1032, 140)
+        SPLIT = (3128, 3064, 2128, 2064, 1128, 1064, 1032, 140)
         KERNELS = {3128: "conv_igemm_kernel<128,128,1,4,kx3> (split-f16 3x3/stride-1 on shared-tap stages, v_mfma_f32_32x32x16_f16 x3)",
                    3064: "conv_igemm_kernel<128,64,2,2,kx3> (split-f16 3x3/stride-1 on shared-tap stages)",
+                   2128: "conv_igemm_kernel<128,128,1,4,p1> (split-f16 1x1 convolutions on the uniform loop)",
+                   2064: "conv_igemm_kernel<128,64,2,2,p1> (split-f16 1x1 convolutions / detection heads on the uniform loop)",
                    1128: "conv_igemm_kernel<128,128,1,4,split> (split-f16 1x1 / stride-2 / two-source convolutions)",
                    1064: "conv_igemm_kernel<128,64,2,2,split>", 1032: "conv_igemm_kernel<128,32,4,1,split>",
                    140: "wino_split_kernel (Winograd F(2x2,3x3) in split-f16: transform-domain GEMM + output transform + epilogue, v_mfma_f32_32x32x16_f16 x3)",

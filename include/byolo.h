@@ -231,7 +231,9 @@ BYOLO_API int32_t byolo_stage_ms(byolo_t* h, float ms[4]);
 BYOLO_API int32_t byolo_set_profile_depth(byolo_t* h, int32_t depth);
 BYOLO_API int32_t byolo_select_profile(byolo_t* h, int32_t age);
 /* per kernel launch of the convolution stack in the LAST forward (profiling level 2): graph layer, kernel variant --
- *   128 / 64 / 32   conv_igemm_kernel, BN of the tile            -1   the direct small-Cin kernels
+ *   128 / 64 / 32   conv_igemm_kernel, BN of the tile (split precision: + 1000 the general loop, + 2000 the 1x1 loop, + 3000 the
+ *                   shared-tap 3x3 loop; 140 / -4 Winograd in split arithmetic: fused launch / input transform)
+ *                                                                -1   the direct small-Cin kernels
  *   -2 / -3         Winograd input / output transform            129  the row-streaming Winograd-domain GEMM
  *   130             the same with output transform + epilogue    131 / 132  a 1x1 convolution / detection head as a
  *                   fused in (wino_fused_kernel)                            row-streaming launch, 128- / 64-wide tile
