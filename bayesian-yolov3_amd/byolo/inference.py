@@ -196,7 +196,7 @@ class InferenceLoop:
             eng.finalize()
             h, w, c = self.img_size
             # the same calibration frames on every rank -> identical weights
-            eng.calibrate_bn(torch.from_numpy(synth.synthetic_images(2, h, w, c, seed=999)).to('cuda:%d' % self.device))
+            eng.calibrate_bn(torch.from_numpy(synth.synthetic_images(2, h, w, c, seed=999)).to(getattr(eng, 'torch_device', 'cuda:%d' % self.device)))
         else:
             restore(self.model, self.checkpoint)
 
@@ -207,7 +207,7 @@ class InferenceLoop:
         pg = torch.distributed.is_initialized()           # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
         self._load_weights()
         eng = self.model.engine
-        dev = 'cuda:%d' % self.device
+        dev = getattr(eng, 'torch_device', 'cuda:%d' % self.device)      # (a CPU stand-in engine in the gloo tests names its own)
         _, D = eng.num_boxes()
         cap = eng.out_cap
         step = 0

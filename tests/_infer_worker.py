@@ -1,0 +1,90 @@
+"""Worker for tests/test_dist_cpu.py::test_inference_epistemic_world2_*: `inference_epistemic.Inference` -- the driver loop of the
+entry point, unmodified (dataset sharding, first_image, padded blocks, the ONE all-gather, rank-0 JSON writer, error agreement)
+-- as rank `rank` of a gloo job on CPU tensors, with a stand-in for the GPU engine that returns rows which are a pure function
+of (pixels, position of the image in the GLOBAL batch, seed): any mistake in the sharding shows up in the JSON files."""
+import os
+import sys
+
+
+class FakeEngine:
+    torch_device = "cpu"
+    device = 0
+    out_cap = 6
+
+    def num_boxes(self):
+        return 50, 23
+
+    def param_shapes(self):
+        return {}
+
+    def set_params(self, *a, **k):
+        pass
+
+    def finalize(self):
+        pass
+
+    def calibrate_bn(self, x):
+        pass
+
+
+class FakeModel:
+    cls_cnt, obj_idx, cls_start_idx = 2, 14, 17
+
+    def __init__(self):
+        self.engine = FakeEngine()
+        self.calls = []
+
+    def run(self, x, seed=0, want_boxes=True, first_image=0, out=None, **kw):
+        import torch
+        self.calls.append((int(x.shape[0]), int(first_image), int(seed)))
+        for j in range(x.shape[0]):
+            g = first_image + j                                    # position in the global batch
+            k = 1 + (int(x[j].sum().item() * 7) + g) % self.engine.out_cap
+            base = x[j].mean() + 0.001 * seed
+            for b in range(k):
+                out["rows"][j, b] = torch.arange(23, dtype=torch.float32) * 0.01 + base + 0.1 * b + g
+                out["rows"][j, b, 17:19] = torch.tensor([0.7, 0.3]) if (g + b) % 2 else torch.tensor([0.2, 0.8])
+            out["kept"][j, :k] = torch.arange(k, dtype=torch.int32) + 100 * g
+            out["count"][j] = k
+        return out
+
+
+class FakeYolo:
+    def __init__(self):
+        self.model = FakeModel()
+        self.options = {}
+
+    def set_engine_option(self, k, v):
+        self.options[k] = v
+
+    def init_model(self, inputs=None, training=False):
+        return self
+
+    def get_model(self):
+        return self.model
+
+
+def main(rank, world, port, data_dir, out_path):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "bayesian-yolov3_amd"))
+    import torch
+    import inference_epistemic as ie
+    cfg = {"batch_size": 5, "full_img_size": [32, 32, 3], "crop": False, "cls_cnt": 2, "implicit_background_class": True,
+           "weights": "synthetic", "seed": 3, "inference_mode": True, "T": 3, "out_path": out_path, "data": {"file_pattern": os.path.join(data_dir, "val-*")}}
+    yolo = FakeYolo()
+    try:
+        loop = ie.Inference(yolo, cfg)
+    except OSError as e:                                   # rank 0's own failure
+        print("RANK%d OSERROR %s" % (rank, e)); sys.exit(7)
+    except RuntimeError as e:                              # the other ranks learn of it (byolo.dist.agree_on_error)
+        print("RANK%d AGREED %s" % (rank, e)); sys.exit(7)
+    loop.run()
+    import json
+    json.dump({"calls": yolo.model.calls, "options": yolo.options}, open(os.path.join(data_dir, "calls_w%d_r%d.json" % (world, rank)), "w"))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])

@@ -84,6 +84,51 @@ def test_dataset_shards_cover_every_global_batch(tmp_path, world):
         assert pos == len(names)
 
 
+def _run_infer(world, data_dir, out_path, timeout=300):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_infer_worker.py"), str(r), str(world), str(port), str(data_dir), out_path],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=timeout)[0] for p in procs]
+    return [p.returncode for p in procs], outs
+
+
+def test_inference_epistemic_world2_writes_the_single_process_json(tmp_path):
+    """`torchrun --nproc-per-node 2 inference_epistemic.py` end to end up to the engine boundary, on CPU (gloo): the driver loop
+    of the entry point with a stand-in engine whose rows depend on the pixels and on the image's position in the GLOBAL batch.
+    11 images, global batch 5 (so the last batch is short and rank 1's block of it has ONE image): the two-process job must write
+    byte-identical ECP JSON files to the one-process run, rank 1 writes nothing, every rank's engine option `device` is its
+    LOCAL_RANK, and the blocks / first_image values tile every global batch (inference_epistemic.py:56-83 + byolo/dist.py)."""
+    import json
+    _records(tmp_path, 11)
+    rc1, o1 = _run_infer(1, tmp_path, str(tmp_path / "one" / "run"))
+    assert rc1 == [0], o1
+    rc2, o2 = _run_infer(2, tmp_path, str(tmp_path / "two" / "run"))
+    assert rc2 == [0, 0], o2
+    a, b = str(tmp_path / "one" / "run_0"), str(tmp_path / "two" / "run_0")
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == ["f%02d.json" % i for i in range(11)]
+    for f in os.listdir(a):
+        assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+        assert json.load(open(os.path.join(a, f)))["children"]
+    c = [json.load(open(tmp_path / ("calls_w2_r%d.json" % r))) for r in range(2)]
+    assert c[0]["options"] == {"device": 0} and c[1]["options"] == {"device": 1}
+    # (images in the block, first_image, seed) per global batch: 5 = 3 + 2, 5 = 3 + 2, 1 = 1 + 0 (rank 1 skips the call)
+    assert c[0]["calls"] == [[3, 0, 4], [3, 0, 5], [1, 0, 6]] and c[1]["calls"] == [[2, 3, 4], [2, 3, 5]]
+    one = json.load(open(tmp_path / "calls_w1_r0.json"))["calls"]
+    assert one == [[5, 0, 4], [5, 0, 5], [1, 0, 6]]
+
+
+def test_inference_world2_ranks_stop_together_when_the_output_directory_exists(tmp_path):
+    """The reference refuses to overwrite an existing run (os.makedirs, inference_epistemic.py:42).  Under torchrun only rank 0
+    touches the directory -- and tells the others: every rank exits at once instead of waiting in its first collective for a
+    peer that is gone."""
+    _records(tmp_path, 3)
+    os.makedirs(tmp_path / "out" / "run_0")
+    rc, outs = _run_infer(2, tmp_path, str(tmp_path / "out" / "run"), timeout=120)
+    assert rc == [7, 7], (rc, outs)
+    assert "OSERROR" in outs[0] and "AGREED" in outs[1] and "rank 0 failed" in outs[1]
+
+
 def test_shard_range_covers_batch():
     from byolo import dist as bdist
     for n in (1, 7, 8, 64):
