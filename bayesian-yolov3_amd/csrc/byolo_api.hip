@@ -104,7 +104,7 @@ struct Step {
     bool kx3 = false;              // split precision: 3x3 / stride 1 over one plain source -- shared-tap stages (conv_tile_kx3), weights in (ky, chunk, kx) order
 };
 // per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
-struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; int bm = 0; /* split precision: output tiles per workgroup */ };
+struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; int bm = 0, bn = 0; /* split precision: output tiles / channels per workgroup */ };
 struct AuxTensor { int H, W, C; };
 
 struct Plan {
@@ -995,7 +995,7 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
     // Split precision: Winograd F(2x2,3x3) in split arithmetic (wino_split.hip) for the LARGE 3x3 / stride-1 convolutions -- the
     // nine 3x3 convolutions of the heads at T >= ~10 samples.  The transform streams 5x the input through HBM, so small layers keep
     // the shared-tap direct kernel.  BYOLO_WINO_SPLIT: 0 never, 1 layers of >= BYOLO_WINO_SPLIT_MIN_GFLOP (default 200), 2 every
-    // eligible layer (tests); BYOLO_WINO_SPLIT_BM: 64 | 128 output tiles per workgroup; BYOLO_WINO_SPLIT_CHUNK_MB: V bytes of a chunk.
+    // eligible layer (tests); BYOLO_WINO_SPLIT_BM / _BN: 64 | 128 output tiles, 256 | 128 channels per workgroup; BYOLO_WINO_SPLIT_CHUNK_MB: V bytes of a chunk.
     if (h->precision == 1) {
         const char* e = getenv("BYOLO_WINO_SPLIT");
         const int on = e ? atoi(e) : 1;
@@ -1004,6 +1004,8 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
         const char* be = getenv("BYOLO_WINO_SPLIT_BM");
         const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 200.0) * 1e9, budget = (cb ? atof(cb) : 1500.0) * 1e6;
         const int bm = be && atoi(be) == 128 ? 128 : 64;
+        const char* bne = getenv("BYOLO_WINO_SPLIT_BN");
+        const int bn_pref = bne ? atoi(bne) : 256;             // measured at config 4: 1.29 -> 1.19 ms per fused launch
         for (size_t si = 0; on && si < h->steps.size(); ++si) {
             const Step& s = h->steps[si];
             const Layer& l = h->layers[s.layer];
@@ -1017,6 +1019,7 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
             if (on < 2 && l.Cin < min_c) continue;
             WinoPlan& w = p.wino[si];
             w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2; w.bm = bm; w.fused = true;
+            w.bn = (bn_pref == 256 && bm == 64 && (l.filters % 256) == 0) ? 256 : 128;
             const int S = M / (l.H * l.W);
             const double per_sample = 16.0 * w.th * w.tw * l.Cin * 4.0;
             const int nchunks = std::max(1, (int)std::ceil(S * per_sample / budget));          // equal chunks
@@ -1339,7 +1342,7 @@ static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const C
         f.v = V; f.v_bytes = (uint32_t)(rows * c.C0 * 4); f.xi_stride = (uint32_t)((uint64_t)w.P_pad * c.C0 * 4);
         f.w = dptr(h, s.wino_off); f.w_bytes = (uint32_t)((size_t)16 * c.C0 * c.N * 4);
         f.y = c.dst; f.scale = dptr(h, drop ? l.wscalek_off : l.wscale_off); f.shift = c.shift;
-        f.C = c.C0; f.N = c.N; f.KT = c.C0 / 32; f.n_tiles = c.N / 128;
+        f.C = c.C0; f.N = c.N; f.KT = c.C0 / 32; f.n_tiles = c.N / wp.bn; f.bn = wp.bn;
         f.H = l.H; f.W = l.W; f.th = wp.th; f.tw = wp.tw; f.s0 = s0; f.P = w.P; f.P_pad = w.P_pad;
         f.bm = wp.bm; f.units = (w.P_pad / wp.bm) * f.n_tiles;
         f.flags = c.flags; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base; f.mask_bits = c.mask_bits;

@@ -122,9 +122,9 @@ struct WinoSplitParams {
     const float* w; uint32_t w_bytes;     // U: 16 * C / 32 K-tiles in (point, chunk) order, split-f16 fragment order (mfma_pipe.h)
     float* y;                             // output [S,H,W,N], hi/lo groups
     const float* scale; const float* shift;
-    int C, N, KT, n_tiles;                // KT = C / 32 (even), n_tiles = N / 128
+    int C, N, KT, n_tiles;                // KT = C / 32 (a multiple of 4), n_tiles = N / bn
     int H, W, th, tw, s0, P, P_pad;       // as WinoParams
-    int bm;                               // output tiles per workgroup: 64 | 128 (P_pad is a multiple of it)
+    int bm, bn;                           // output tiles / channels per workgroup: 64 | 128 (P_pad is a multiple of it), 128 | 256
     int units;                            // P_pad / bm * n_tiles workgroups
     int flags; uint32_t k0, k1, thr; uint64_t idx_base; const uint32_t* mask_bits;
     unsigned* status; int layer_idx;

@@ -43,14 +43,24 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(const ConvParams p) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) x[(ky * 3 + kx) * 3 + c] = ok ? px[c] : 0.f;
         }
-    const float* __restrict__ w = p.wpk;          // HWIO [27][NOUT]: uniform addresses -> scalar loads
+    // HWIO weights [27][NOUT] through LDS, read as broadcast 16-byte vectors (every lane the same address: no conflict).  As
+    // wave-uniform scalar loads -- 27 * NOUT s_load results feeding v_fmac -- the kernel spent its time waiting for the scalar
+    // cache: 0.43 ms per 8 images against 0.03 ms of FMA work (profiles/r3_a_bench_kernel_stats.md).
+    f32x4* wl = reinterpret_cast<f32x4*>(lds);
+    for (int i = threadIdx.x; i < 27 * NOUT / 4; i += 256) wl[i] = reinterpret_cast<const f32x4*>(p.wpk)[i];
+    __syncthreads();
     float acc[NOUT];
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
 #pragma unroll
     for (int k = 0; k < 27; ++k)
 #pragma unroll
-        for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(x[k], w[k * NOUT + n], acc[n]);
+        for (int n = 0; n < NOUT; n += 4) {
+            const f32x4 w4 = wl[k * (NOUT / 4) + n / 4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[n + q] = fmaf(x[k], w4[q], acc[n + q]);
+        }
+    __syncthreads();                              // the weights are read out: the rows take their place
     const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
     float vmax = 0.f;
 #pragma unroll

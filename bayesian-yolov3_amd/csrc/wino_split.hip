@@ -103,10 +103,12 @@ hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------------
 // WINO_BM = output tiles per workgroup (rows of the transform-domain GEMM): 64 -> 230 registers, two workgroups per CU;
 // 128 -> 473 registers (the outputs in the accumulator file), one workgroup per CU
-template <int WINO_BM>
-__global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(const WinoSplitParams p) {
+// WINO_BN = output channels per workgroup: 128 (4 waves) or 256 (8 waves side by side: ONE workgroup per CU stages a V row for 256
+// columns -- the column tiles of a row tile re-read V through the fabric, measured 4.7 GB per launch against 0.8 .. 1.4 GB of V)
+template <int WINO_BM, int WINO_BN>
+__global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(const WinoSplitParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using BT = SplitTile<WINO_BM, 128, 1, 4>;
+    using BT = SplitTile<WINO_BM, WINO_BN, 1, WINO_BN / 32>;
     constexpr int TM = BT::TM, A_LD = BT::A_LD;            // 4 row blocks of 32 per wave; 4 staging rows per thread
     static_assert(BT::TN == 1, "one 32-column block per wave");
     const BT bt(smem);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(
     uint32_t a_voff[A_LD];
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        const uint32_t m = rt * (uint32_t)WINO_BM + (uint32_t)bt.a_r + 32u * j;
+        const uint32_t m = rt * (uint32_t)WINO_BM + (uint32_t)bt.a_r + (uint32_t)(BT::NT / 8) * j;
         a_voff[j] = (m * (uint32_t)p.C + (uint32_t)bt.a_q * 4u) * 4u;
     }
     const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.v, p.v_bytes);
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(
     const uint32_t KT = (uint32_t)p.KT;
     const uint32_t w_step = (uint32_t)p.N * BK * 4;                        // one K-tile of all column blocks (N / 32 blocks of 4 KB)
     uint32_t a_soff = 0, a_kt = 0, a_xi_base = 0;                          // the NEXT tile to load
-    uint32_t w_soff = ct * (128 / 32) * SPLIT_WBLOCK;
+    uint32_t w_soff = ct * (WINO_BN / 32) * SPLIT_WBLOCK;
     // V streams from HBM (a chunk is far larger than the caches) and a K-tile of this tile is short (12 MFMAs per wave): the
     // activations of tile t + 1 + NSET are fetched while tile t multiplies, into a ring of NSET staging sets (timing ablation
     // with one set: without the activation path the launch ran 35 % faster -- the loop was waiting for its loads)
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(
     const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT;
     const float slope = do_leaky ? 0.1f : 1.f;
     const uint32_t tt = (uint32_t)(p.th * p.tw);
-    const int nb = (int)(ct * 128) + bt.wn * 32 + 4 * bt.lh;
+    const int nb = (int)(ct * WINO_BN) + bt.wn * 32 + 4 * bt.lh;
     float vmax = 0.f;
     f32x4 sc4[4], sf4[4];
 #pragma unroll
@@ -262,17 +264,18 @@ __global__ __launch_bounds__(256, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(
 
 bool wino_split_ok(int C, int N) { return C >= 128 && (C % 128) == 0 && N >= 128 && (N % 128) == 0; }     // K-tiles in groups of 4
 
-template <int WINO_BM>
+template <int WINO_BM, int WINO_BN>
 static hipError_t launch_wino_split_bm(const WinoSplitParams& p, hipStream_t st) {
-    using BT = SplitTile<WINO_BM, 128, 1, 4>;
-    auto k = wino_split_kernel<WINO_BM>;
+    using BT = SplitTile<WINO_BM, WINO_BN, 1, WINO_BN / 32>;
+    auto k = wino_split_kernel<WINO_BM, WINO_BN>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), BT::LDS_BYTES, attr_done); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((unsigned)p.units), dim3(256), BT::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(k, dim3((unsigned)p.units), dim3(WINO_BN * 2), BT::LDS_BYTES, st, p);
     return hipGetLastError();
 }
 hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st) {
-    return p.bm == 64 ? launch_wino_split_bm<64>(p, st) : launch_wino_split_bm<128>(p, st);
+    if (p.bn == 256) return p.bm == 64 ? launch_wino_split_bm<64, 256>(p, st) : hipErrorInvalidValue;
+    return p.bm == 64 ? launch_wino_split_bm<64, 128>(p, st) : launch_wino_split_bm<128, 128>(p, st);
 }
 
 }  // namespace byk

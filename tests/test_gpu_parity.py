@@ -472,9 +472,9 @@ def test_winograd_on_every_eligible_layer(variant, fused, monkeypatch, precision
     assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
 
 
-@pytest.mark.parametrize("bm", ["64", "128"])
+@pytest.mark.parametrize("bm,bn", [("64", "256"), ("64", "128"), ("128", "128")])
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, monkeypatch, precision):
+def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, bn, monkeypatch, precision):
     """Default precision: the large 3x3 / stride-1 head convolutions as Winograd F(2x2,3x3) in split-f16 arithmetic
     (csrc/wino_split.hip: hi/lo input transform, then GEMM + output transform + epilogue in one launch).  BYOLO_WINO_SPLIT=2
     forces it on EVERY eligible layer, both workgroup shapes: odd grids (2x3 ... 8x12 pad to 2x2 tiles), dropout and BN-only
@@ -487,6 +487,7 @@ def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, monke
     _, direct, _, _ = _run(variant, B, keep_all=False)
     monkeypatch.setenv("BYOLO_WINO_SPLIT", "2")
     monkeypatch.setenv("BYOLO_WINO_SPLIT_BM", bm)
+    monkeypatch.setenv("BYOLO_WINO_SPLIT_BN", bn)
     m, wino, params, imgs = _run(variant, B)
     m.engine.set_profiling(2)
     torch = _torch()
