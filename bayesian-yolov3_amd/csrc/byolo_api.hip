@@ -772,7 +772,8 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
             static const bool kx3_on = [] { const char* e = getenv("BYOLO_KX3"); return !e || atoi(e) != 0; }();
             st.kx3 = kx3_on && l.ksize == 3 && l.stride == 1 && st.in.n == 1 && st.in.s[0].sh == 0 && st.in.s[0].layer >= 0 && st.Npad >= 64 &&
                      (st.mode == STEP_NORMAL || st.mode == STEP_REP);
-            static const bool p1_on = [] { const char* e = getenv("BYOLO_P1"); return !e || atoi(e) != 0; }();
+            const char* p1e = getenv("BYOLO_P1");
+            const bool p1_on = !p1e || atoi(p1e) != 0;
             st.p1 = p1_on && l.ksize == 1 && l.stride == 1 && st.in.n == 1 && st.in.s[0].layer >= 0 && st.Npad >= 64;
             const int cts = Cs / 32;
             // split-f16 weights (mfma_pipe.h): w' = w * 2^wshift with the layer's largest |w'| in [2^13, 2^14), each
@@ -1467,7 +1468,13 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
     }
     const bool per_step = h->profiling >= 2;
     bool backbone_marked = false;
-    if (h->ev_convs_valid && h->convs_stream != st) HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0));   // (see ev_convs)
+    // (see ev_convs)  Only where a forward fills the chip by itself: a small one -- 8 images at 416 x 416 are 0.5 TFLOP in launches of
+    // a few dozen tiles -- gains from running beside the next (config 2: 2480 img/s one after the other, 3110 side by side).
+    // BYOLO_SERIALIZE_CONVS: 0 never, 1 forwards of >= 1 TFLOP (default), 2 always.
+    static const int ser_knob = [] { const char* e = getenv("BYOLO_SERIALIZE_CONVS"); return e ? atoi(e) : 1; }();
+    bool serialize = ser_knob >= 2;
+    if (ser_knob == 1) { double f = 0; (void)byolo_flops(h, B, T, &f); serialize = f >= 1e12; }
+    if (serialize && h->ev_convs_valid && h->convs_stream != st) HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0));
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     if (h->precision == 1 && h->img_split)
         HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st, h->d_status));

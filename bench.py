@@ -383,12 +383,13 @@ def main():
             # fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same command
             # (tools/profile_round.sh + tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent / another kernel
             traffic = tr_read = tr_write = measured_at = None
-            tpath = os.path.join(REPO, "profiles", "traffic_cfg%d.json" % args.config)
+            # one file per kernel that has been the dominant one: profiles/traffic_cfg<N>_<tag>.json
+            tag = {3128: "kx3", 140: "wino", 130: "wino_fused"}.get(dom, "v%d" % dom)
+            tpath = os.path.join(REPO, "profiles", "traffic_cfg%d_%s.json" % (args.config, tag))
             if os.path.exists(tpath) and not args.batch and args.scaling == "weak":
                 tj = json.load(open(tpath))
-                want = {3128: "conv_igemm_kernel<128, 128, 1, 4, true, true, true>", 3064: "conv_igemm_kernel<128, 64, 2, 2, true, true, true>",
-                        130: "wino_fused_kernel", 129: "gemm_stream_kernel", 128: "conv_igemm_kernel<128, 128, 2, 2"}.get(dom)
-                if want and tj.get("kernel", "").startswith(want.split(",")[0]) and (want in tj.get("kernel", "") or tj.get("kernel", "") in want):
+                want = {3128: "conv_igemm_kernel<128, 128, 1, 4, true, true, 1", 140: "wino_split_kernel", 130: "wino_fused_kernel"}.get(dom)
+                if want and (want in tj.get("kernel", "") or tj.get("kernel", "") in want):
                     traffic = tj.get("traffic_bytes_per_launch")
                     tr_read, tr_write = tj.get("read_bytes_per_launch"), tj.get("write_bytes_per_launch")
                     measured_at = tj.get("measured_at")
@@ -432,6 +433,8 @@ def main():
                                             "(byolo_api.hip ev_convs), so a convolution launch shares the chip only with the previous step's tail "
                                             "kernels (decode, sort, NMS: a few hundred microseconds of small launches)" % npipe)
             line["stage_ms_per_step"] = {k: v / args.steps for k, v in stage.items()}
+            if npipe > 1:       # stage events sit on the step's own stream: the first stage includes the wait for the previous step's convolutions
+                line["stage_ms_per_step"]["note"] = "pipelined steps: `backbone` includes waiting for the previous step's convolution stack (byolo_api.hip ev_convs)"
         # the reference's own arithmetic (float32, lib_yolo/layers.py:550) timed in the SAME run: a second handle in BYOLO_PREC_F32
         # on the same batch, a few steps on one stream after the headline region (the headline engine stays alive: its weights)
         if world == 1 and args.fp32_steps > 0 and eng.precision != "f32" and not args.batch and args.scaling == "weak":

@@ -1,5 +1,5 @@
 #!/bin/bash
-# run_soaks.sh [SEED] -- every randomised sweep once, on the GPU box (about five minutes):
+# run_soaks.sh [SEED] -- the randomised sweeps of the hot path (parity, NMS, decode; the generic-graph fuzzers are frozen: out of scope) once, on the GPU box (about five minutes):
 #   gpurun --timeout 1800 -- 'bash tools/run_soaks.sh 7'
 # Logs under gpurun_out/soaks_SEED/; the last line of each log is its verdict, the exit code is the number of sweeps
 # that reported a failure.
@@ -15,10 +15,7 @@ run() {
 }
 run parity      tools/soak_parity.py --cases 60 --seed "$SEED"
 run parity_big  tools/soak_parity.py --cases 12 --seed "$SEED" --max-cells 20 --max-T 30 --max-B 8 --budget 12000
-run graph       tools/fuzz_graph.py --cases 150 --seed "$SEED"
-run graph_big   tools/fuzz_graph.py --cases 40 --seed "$SEED" --max-cells 12
 run nms         tools/soak_nms.py --cases 400 --seed "$SEED"
 run decode      tools/soak_decode.py --cases 400 --seed "$SEED"
-run builder     tools/fuzz_builder.py --runs 30 --seed "$SEED"
 echo "$bad sweep(s) failed"
 exit $bad
