@@ -1025,6 +1025,17 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
             const double per_sample = 16.0 * w.th * w.tw * l.Cin * 4.0;
             const int nchunks = std::max(1, (int)std::ceil(S * per_sample / budget));          // equal chunks
             w.chunk = (S + nchunks - 1) / nchunks;
+            // BYOLO_WINO_SPLIT_ROUNDS=k (experiment): chunks whose fused launch is k whole rounds of resident workgroups, so that a
+            // chunk's V (<= ~140 MB per round) is still in the Infinity Cache when the GEMM reads it
+            static const int rounds = [] { const char* e = getenv("BYOLO_WINO_SPLIT_ROUNDS"); return e ? atoi(e) : 0; }();
+            if (rounds > 0) {
+                const int slots = (w.bn == 256 ? 256 : 512), n_tiles = l.filters / w.bn;
+                const int64_t row_tiles = (int64_t)rounds * slots / n_tiles;                // of w.bm rows each
+                const int tt = w.th * w.tw;
+                int c = (int)((row_tiles * w.bm) / tt);                                     // whole samples that fit
+                while (c > 1 && (int64_t)align_up((size_t)c * tt, 128) / w.bm * n_tiles > (int64_t)rounds * slots) --c;
+                w.chunk = std::max(1, std::min(S, c));
+            }
             const size_t P_pad = align_up((size_t)w.chunk * w.th * w.tw, 128);
             w.v_bytes = align_up((size_t)16 * P_pad * l.Cin * 4, 256);
             if (w.v_bytes > CONV_MAX_SRC_BYTES) { w = WinoPlan{}; continue; }                 // 32-bit buffer offsets
