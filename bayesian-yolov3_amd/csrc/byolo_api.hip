@@ -1485,13 +1485,18 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
     static const int ser_knob = [] { const char* e = getenv("BYOLO_SERIALIZE_CONVS"); return e ? atoi(e) : 1; }();
     bool serialize = ser_knob >= 2;
     if (ser_knob == 1) { double f = 0; (void)byolo_flops(h, B, T, &f); serialize = f >= 1e12; }
-    if (serialize && h->ev_convs_valid && h->convs_stream != st) HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0));
+    // BYOLO_SERIALIZE_AT=1 (experiment): wait in front of the first HEAD launch instead, i.e. let this forward's backbone (small
+    // launches that leave CUs idle) run beside the previous forward's heads
+    static const int ser_at = [] { const char* e = getenv("BYOLO_SERIALIZE_AT"); return e ? atoi(e) : 0; }();
+    bool wait_pending = serialize && h->ev_convs_valid && h->convs_stream != st;
+    if (wait_pending && !(ser_at == 1 && h->backbone_end >= 0)) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0)); wait_pending = false; }
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     if (h->precision == 1 && h->img_split)
         HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st, h->d_status));
     for (size_t si = 0; si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
+        if (wait_pending && s.layer >= h->backbone_end) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0)); wait_pending = false; }
         if (h->profiling && !backbone_marked && h->backbone_end >= 0 && s.layer >= h->backbone_end) {
             HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); backbone_marked = true;
         }
