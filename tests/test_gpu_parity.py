@@ -472,8 +472,7 @@ def test_winograd_on_every_eligible_layer(variant, fused, monkeypatch, precision
     assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
 
 
-@pytest.mark.parametrize("bm,bn", [("64", "256"), ("64", "128"), ("128", "128")])
-@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("variant,bm,bn", [(v, "64", "256") for v in VARIANTS] + [(VARIANTS[2], "64", "128"), (VARIANTS[2], "128", "128")])
 def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, bn, monkeypatch, precision):
     """Default precision: the large 3x3 / stride-1 head convolutions as Winograd F(2x2,3x3) in split-f16 arithmetic
     (csrc/wino_split.hip: hi/lo input transform, then GEMM + output transform + epilogue in one launch).  BYOLO_WINO_SPLIT=2
