@@ -3,8 +3,9 @@ bench.py builds them (`bench.build`: same weights, same device BN calibration, d
 on the benchmark's own batch, and
 
   * the launch list of that step (byolo_step_profile / byolo_step_split) must contain the kernels the benchmark's
-    number is about -- at config 4 the shared-tap split-f16 kernel (variants 3128 / 3064) on the nine big head
-    convolutions (default precision), or the fused Winograd kernel (variant 130) in chunks under BYOLO_PRECISION=f32;
+    number is about -- at config 4, default precision: Winograd in split arithmetic (variant 140 + its transform -4) on the six
+    19x19 / 38x38 head convolutions and the shared-tap split-f16 kernel (3128) on the three 76x76 ones; under BYOLO_PRECISION=f32
+    the fused Winograd kernel (variant 130) in chunks;
   * whole images of the batch, INCLUDING THE LAST ONE (its dropout masks sit at sample offset (B-1)*T of the logical
     batch, its rows in the last Winograd chunk), are compared with the CPU restatement per column group at the
     literal bound 1e-4 * max(1, |ref|) (conftest.assert_rows_close);
