@@ -35,7 +35,8 @@ namespace byk {
 using namespace pipe;
 
 // Timing ablations (build.py --ablate-ws N -> libbyolo_ws<N>.so, loaded with BYOLO_LIB=...; results are WRONG by construction):
-// 1 no weight-fragment loads in the loop, 2 no fold, 4 no activation loads / LDS staging in the loop, 8 no accumulator clears.
+// 1 no weight-fragment loads in the loop, 2 no fold, 4 no activation loads / LDS staging in the loop, 8 no accumulator clears,
+// 16 no workgroup barrier in the K-tile body, 32 no LDS fragment reads.
 #ifndef BYOLO_WS_ABLATE
 #define BYOLO_WS_ABLATE 0
 #endif
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
     // unit -> (row tile, column tile): the column tiles of a row tile are neighbours on one XCD (V rows shared in its L2)
     const int nwg = (int)gridDim.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-    const uint32_t unit = (uint32_t)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bi);
     const uint32_t n_tiles = (uint32_t)p.n_tiles;
+    const uint32_t unit = (uint32_t)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bi);
     const uint32_t rt = fdiv(unit, p.d_ntiles), ct = unit - rt * n_tiles;
 
     // ---- staging rows (V row = output tile index inside the chunk; every row of the padded extent exists) -------------
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
     auto ktile = [&](auto buf_tag, auto set_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         using ST = decltype(set_tag);
-        pipe::tile_body_split<BUF, true, (WS_ABL & 1) ? 0 : BT::NBF, (WS_ABL & 4) ? 0 : A_LD, (WS_ABL & 4) ? 0 : A_LD, 0>(
+        pipe::tile_body_split<BUF, true, (WS_ABL & 1) ? 0 : BT::NBF, (WS_ABL & 4) ? 0 : A_LD, (WS_ABL & 4) ? 0 : A_LD, ((WS_ABL & 16) ? 4 : 0) | ((WS_ABL & 32) ? 8 : 0)>(
             bt, M, af0, af1, bfr[(WS_ABL & 1) ? 0 : BUF], [&] { load_b(std::integral_constant<int, BUF ^ 1>{}); },
             [&] { next_tile(); load_a(ST{}); }, [&] { if constexpr (!(WS_ABL & 4)) bt.template store_a<BUF ^ 1>(a_reg[ST::value]); });
     };
