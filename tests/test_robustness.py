@@ -271,7 +271,7 @@ def test_a_non_finite_detection_output_is_an_error_in_split_mode(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["split", "f32"])
+@pytest.mark.parametrize("precision", ["split", "split-winograd", "f32"])
 def test_injected_dropout_masks(precision, monkeypatch):
     """tf.layers.dropout draws unseeded noise (layers.py:521-524): ANY Bernoulli(0.9) array is a run of the reference.
     Masks drawn by numpy go to the oracle (cpu_ref.forward(masks=...), pinned to the reference's call order by
@@ -280,6 +280,9 @@ def test_injected_dropout_masks(precision, monkeypatch):
     bit for bit (injection and hash index the same elements)."""
     import torch
     from oracle import cpu_ref, rng
+    if precision == "split-winograd":      # the six big head convolutions through csrc/wino_split.hip (its epilogue reads the bits too)
+        precision = "split"
+        monkeypatch.setenv("BYOLO_WINO_SPLIT", "2")
     monkeypatch.setenv("BYOLO_PRECISION", precision)
     B, T = 2, 3
     params = golden_params(VARIANT)
@@ -297,7 +300,11 @@ def test_injected_dropout_masks(precision, monkeypatch):
     masks = [g.random(s) < 0.9 for s in shapes]
     x = torch.from_numpy(imgs).cuda()
     bits = torch.from_numpy(eng.pack_masks(masks, B, T).view(np.int32)).cuda()
+    eng.set_profiling(2)
     got = eng.forward(x, T=T, seed=12345, want_boxes=True, mask_bits=bits)["boxes"].cpu().numpy()
+    wino = [s for s in eng.step_profile() if s["variant"] == 140]
+    eng.set_profiling(0)
+    assert bool(wino) == (os.environ.get("BYOLO_WINO_SPLIT") == "2"), "Winograd-in-split launches: %d" % len(wino)
     with torch.no_grad():
         ref64, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params, torch.float64), imgs, VARIANT, T=T, seed=777, dtype=torch.float64, masks=masks)
         ref32, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params), imgs, VARIANT, T=T, seed=777, masks=masks)
