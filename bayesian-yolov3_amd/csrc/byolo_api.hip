@@ -1512,10 +1512,11 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
                     const int64_t off = mask_layout(h, B, T, l.drop_ordinal, &n_el);
                     if ((l.filters & 3) && !l.direct) return fail(h, BYOLO_ERR_ARG, "byolo_forward: injected masks need cout %% 4 == 0 on a matrix-pipe dropout layer; '%s' has %d", l.scope.c_str(), l.filters);
                     if (n_el >= ((int64_t)1 << 32)) return fail(h, BYOLO_ERR_ARG, "byolo_forward: injected masks index a dropout tensor with 32 bits; layer '%s' has %lld elements", l.scope.c_str(), (long long)n_el);
-                    p.mask_bits = d_mask_bits + off / 32; p.idx_base = 0;
+                    p.mask_bits = d_mask_bits + off / 32;
                 }
-                // element index of this call's first output element in the logical batch's [S,h,w,c] tensor
-                p.idx_base = (uint64_t)h->first_image * (uint64_t)(l.stacked ? T : 1) * l.H * l.W * l.filters;
+                // element index of this call's first output element in the logical batch's [S,h,w,c] tensor (the counter hash);
+                // injected bits are indexed inside THIS call's tensor, whatever byolo_set_first_image says
+                p.idx_base = inject ? 0 : (uint64_t)h->first_image * (uint64_t)(l.stacked ? T : 1) * l.H * l.W * l.filters;
                 p.scale = dptr(h, l.scalek_off);             // scale / (1 - p)
             }
             if (l.fused_residual >= 0) {

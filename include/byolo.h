@@ -149,7 +149,8 @@ BYOLO_API int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t
  * d_mask_bits (nullable): INJECTED dropout masks instead of the library's counter stream -- tf.layers.dropout draws
  *   its Bernoulli noise from an unseeded op (layers.py:521-524), so a caller that wants the reference's masks (or its
  *   own) passes them: one bit per element of each dropout layer's input [S,h,w,cout] of THIS call (S = B*T in the
- *   stacked part of the graph), 1 = keep, layer after layer at the bit offsets of byolo_mask_layout.
+ *   stacked part of the graph; byolo_set_first_image does not enter), 1 = keep, layer after layer at the bit offsets of
+ *   byolo_mask_layout.
  * Numeric status (split precision): unless byolo_set_async(h, 1), the call waits for the stream and returns
  *   BYOLO_ERR_RANGE -- never rows of inf / NaN -- when an activation left the split-f16 range; outputs are then undefined. */
 BYOLO_API int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,

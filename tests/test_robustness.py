@@ -315,6 +315,9 @@ def test_injected_dropout_masks(precision, monkeypatch):
     own = [rng.keep_mask(4242, k, s, 0.1) for k, s in enumerate(shapes)]
     a = eng.forward(x, T=T, seed=4242, want_boxes=True)["boxes"].cpu().numpy()
     b = eng.forward(x, T=T, seed=1, want_boxes=True, mask_bits=torch.from_numpy(eng.pack_masks(own, B, T).view(np.int32)).cuda())["boxes"].cpu().numpy()
+    # injected bits index THIS call's tensors: the position of the call in a larger logical batch (first_image) does not enter
+    b3 = eng.forward(x, T=T, seed=1, want_boxes=True, first_image=3, mask_bits=torch.from_numpy(eng.pack_masks(own, B, T).view(np.int32)).cuda())["boxes"].cpu().numpy()
+    assert np.array_equal(b.view(np.uint32), b3.view(np.uint32)), "injected masks depend on first_image"
     if precision == "split":
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "injected bits and the counter hash disagree on an element"
     else:        # fp32 mode: the injected call runs the convolutions on other kernels (no Winograd): same masks, float32 rounding apart
