@@ -193,13 +193,14 @@ BYOLO_API int32_t byolo_copy_layer_output(const byolo_t* h, int32_t idx, float* 
 
 /* ---- staged tail entry points (parity tests on oracle-provided inputs) ------------------------ */
 /* decode one detection layer: d_raw [S,lh,lw,F] -> rows written at their concat_bbox position in
- * d_boxes [B,N_total,D] starting at box offset `box_base`; kind as above; EPISTEMIC reduces every
+ * d_boxes [B,N_total,D] starting at box offset `box_base` (d_raw dense, F floats per cell); kind as above; EPISTEMIC reduces every
  * image's T samples (S = B*T). */
 BYOLO_API int32_t byolo_decode(byolo_t* h, int32_t kind, const float* d_raw, int32_t B, int32_t T, int32_t lh, int32_t lw,
                      const float* priors_hw /*[3][2] host*/, int32_t layer_id, float* d_boxes,
                      int64_t n_total, int64_t box_base, void* stream);
 /* The entries of decode_epistemic's dict (lib_yolo/layers.py:397-411) that are not columns of the box row, from the
- * raw output d_raw [B*T,lh,lw,3*2*(5+C)] of an epistemic detection layer (byolo_layer_output): ev_loc [B,lh,lw,3,4]
+ * raw output d_raw [B*T,lh,lw,3*2*(5+C)] of an epistemic detection layer, DENSE float32 (as byolo_copy_layer_output hands it
+ * out; the library's own storage pads the rows, see byolo_layer_output): ev_loc [B,lh,lw,3,4]
  * (mean raw location logits), epi_covar_loc [B,lh,lw,3,4,4] (full covariance; its diagonal is columns 4..7 of the box
  * row), obj_samples [B*T,lh,lw,3] = sigmoid(obj), cls_samples [B*T,lh,lw,3,C] = softmax(cls).  Any output may be NULL.
  * (vis_uncertainty.py:49-163 and other consumers of DetLayer.det.) */
