@@ -70,6 +70,7 @@ PROTOTYPES = {
     "byolo_sort_nms": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _sz, _vp, _vp, _vp, _vp]),
     "byolo_calibrate_bn": (_i32, [_vp, _vp, _i32, _vp, _sz, _vp]),
     "byolo_set_profiling": (_i32, [_vp, _i32]),
+    "byolo_resume_profiling": (_i32, [_vp, _i32]),
     "byolo_stage_ms": (_i32, [_vp, _P(_f32)]),
     "byolo_set_profile_depth": (_i32, [_vp, _i32]),
     "byolo_select_profile": (_i32, [_vp, _i32]),

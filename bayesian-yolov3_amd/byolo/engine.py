@@ -327,9 +327,10 @@ class Engine:
         check(self._h, lib.byolo_calibrate_bn(self._h, ctypes.c_void_p(img.data_ptr()), B,
                                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(stream)))
 
-    def set_profiling(self, level):
-        """0 off, 1 per-stage hipEvents, 2 additionally one hipEvent per conv launch."""
-        check(self._h, lib.byolo_set_profiling(self._h, int(level)))
+    def set_profiling(self, level, keep=False):
+        """0 off, 1 per-stage hipEvents, 2 additionally one hipEvent per conv launch.  keep: the records already taken stay
+        readable (byolo_resume_profiling) -- for a run that records every n-th forward."""
+        check(self._h, (lib.byolo_resume_profiling if keep else lib.byolo_set_profiling)(self._h, int(level)))
 
     def set_profile_depth(self, depth):
         """Keep the profile records of the last `depth` forwards (read them with select_profile(age))."""

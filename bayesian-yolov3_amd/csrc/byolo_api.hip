@@ -1753,6 +1753,12 @@ extern "C" int32_t byolo_set_profiling(byolo_t* h, int32_t on) {
     return BYOLO_OK;
 }
 
+extern "C" int32_t byolo_resume_profiling(byolo_t* h, int32_t on) {
+    if (!h) return BYOLO_ERR_ARG;
+    h->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return BYOLO_OK;
+}
+
 extern "C" int32_t byolo_set_profile_depth(byolo_t* h, int32_t depth) {
     if (!h) return BYOLO_ERR_ARG;
     if (depth < 1 || depth > 4096) return fail(h, BYOLO_ERR_ARG, "byolo_set_profile_depth: depth out of [1, 4096]");

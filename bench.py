@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--global-batch", type=int, default=64, help="strong scaling: images per step over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch hipEvents in the timed region")
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="per-launch hipEvents on every n-th step of the timed region (a recorded event costs the GPU ~3 us: ~95 per "
+                         "step are 1.3 %% of a config-4 step); 1 = every step")
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many concurrent HIP streams")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="alternate whole steps over this many HIP streams (own workspace and output buffers each): the latency-bound "
@@ -265,8 +268,10 @@ def main():
     for i in range(args.warmup):
         step(i)
     n_sub = -(-B // eng.max_images(T))           # byolo_forward calls per step (a batch beyond max_images runs as sub-batches)
+    every = max(1, args.profile_every)
+    n_prof = len(range(0, args.steps, every))       # profiled steps of the timed region: i = 0, every, 2 * every, ...
     if prof:
-        eng.set_profile_depth(args.steps * n_sub)   # every step's launch records stay readable until after the run
+        eng.set_profile_depth(n_prof * n_sub)       # every profiled step's launch records stay readable until after the run
     eng.set_profiling(2 if prof else 0)
     acc = {}                      # variant -> [algorithmic flops, ms, launches, executed flops, useful flops, algorithmic read bytes, algorithmic write bytes]
     per_launch = {}
@@ -276,11 +281,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if prof and every > 1:
+            eng.set_profiling(2 if i % every == 0 else 0, keep=True)
         step(args.warmup + i)
     torch.cuda.synchronize()
     if pg:
         dist.barrier()
     dt = time.perf_counter() - t0
+    eng.set_profiling(2 if prof else 0, keep=True)
     if pg:
         t = torch.tensor([dt], dtype=torch.float64, device=x.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,7 +297,7 @@ def main():
     if prof and rank == 0:
         # the timed region is over: read the K steps' records (age K-1 = the first timed step)
         WINO = (129, 130, 140)
-        for age in range(args.steps * n_sub - 1, -1, -1):
+        for age in range(n_prof * n_sub - 1, -1, -1):
             eng.select_profile(age)
             for j, s in enumerate(eng.step_profile()):
                 a = acc.setdefault(s["variant"], [0.0, 0.0, 0, 0.0, 0.0, 0.0, 0.0])
@@ -304,7 +312,7 @@ def main():
                                (s["M"] * s["K"] + (16 if wino else 1) * s["K"] * s["N"]))
                 a[6] += 4.0 * ((s["M"] // 4) * s["N"] if s["variant"] in (130, 140) else s["M"] * s["N"])
                 if args.dump_steps:
-                    per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / args.steps
+                    per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / n_prof
             for k, v in eng.stage_ms().items():
                 stage[k] += v
         eng.select_profile(0)
@@ -403,7 +411,8 @@ def main():
                                 "read_amplification": (tr_read / ab_r) if tr_read else None,
                                 "write_amplification": (tr_write / ab_w) if tr_write else None,
                                 "kernel": KERNELS[dom],
-                                "launches": n, "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
+                                "launches": n, "profiled_steps": "%d of %d (every %d-th step of the timed region records per-launch hipEvents)" % (n_prof, args.steps, every),
+                                "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
                                 "definition": "SURVEY.md 8(d): achieved = algorithmic fp32-equivalent FLOPs of the launches (2MNK of the convolution as written; a "
                                               "Winograd launch stands for the direct-convolution FLOPs of its samples; tile padding not counted), each counted ONCE, "
                                               "/ hipEvent time of the launches on their launch stream; peak = dense peak of the matrix instruction issued ("
@@ -432,7 +441,7 @@ def main():
                 line["roofline"]["note"] = ("steps alternate over %d HIP streams; the library runs a handle's convolution stacks one after the other "
                                             "(byolo_api.hip ev_convs), so a convolution launch shares the chip only with the previous step's tail "
                                             "kernels (decode, sort, NMS: a few hundred microseconds of small launches)" % npipe)
-            line["stage_ms_per_step"] = {k: v / args.steps for k, v in stage.items()}
+            line["stage_ms_per_step"] = {k: v / n_prof for k, v in stage.items()}
             if npipe > 1:       # stage events sit on the step's own stream: the first stage includes the wait for the previous step's convolutions
                 line["stage_ms_per_step"]["note"] = "pipelined steps: `backbone` includes waiting for the previous step's convolution stack (byolo_api.hip ev_convs)"
         # the reference's own arithmetic (float32, lib_yolo/layers.py:550) timed in the SAME run: a second handle in BYOLO_PREC_F32

@@ -225,6 +225,9 @@ BYOLO_API int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B, 
 /* ---- profiling hooks: per-stage device time of the LAST forward (hipEvents on `stream`);
  * enable with byolo_set_profiling(h, 1).  stage: 0 backbone, 1 heads, 2 decode, 3 sort+nms. */
 BYOLO_API int32_t byolo_set_profiling(byolo_t* h, int32_t on);   /* 0 off, 1 per stage, 2 + per conv launch */
+/* The same switch WITHOUT discarding the records already taken (byolo_set_profiling invalidates them): a caller that times a
+ * run of forwards records every n-th one (an event costs the GPU a few microseconds; ~95 per forward) and reads them all afterwards. */
+BYOLO_API int32_t byolo_resume_profiling(byolo_t* h, int32_t on);
 BYOLO_API int32_t byolo_stage_ms(byolo_t* h, float ms[4]);
 /* Keep the records of the last `depth` profiled forwards (default 1) and choose which one byolo_stage_ms /
  * byolo_num_steps / byolo_step_profile / byolo_step_split read: age 0 = the last forward, 1 = the one before, ...
