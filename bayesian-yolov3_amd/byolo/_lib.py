@@ -79,6 +79,12 @@ PROTOTYPES = {
     "byolo_step_split": (_i32, [_vp, _i32, _P(_i32), _P(_i32)]),
     "byolo_flops": (_i32, [_vp, _i32, _i32, _P(ctypes.c_double)]),
     "byolo_crc32c": (ctypes.c_uint32, [_vp, _sz]),
+    "byolo_abi_version": (_i32, []),
+    "byolo_normalize_u8": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "byolo_copy_status": (_i32, [_vp, _vp, _vp]),
+    "byolo_png_decode_batch": (_i32, [_P(_vp), _P(_sz), _i32, _i32, _i32, _i32, _vp, _i32, _P(_i32), _P(_i32)]),
+    "byolo_feed_records": (_i32, [_P(_i32), _P(_i64), _P(_i64), _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _P(_i32), _P(_i32)]),
+    "byolo_format_ecp_json": (_i64, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P(_cp), _i32, _vp, _sz]),
 }
 
 
@@ -96,9 +102,15 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    have = lib.byolo_abi_version()
+    if have != ABI_VERSION:
+        raise ImportError("%s speaks ABI %d, this binding was written for %d (include/byolo.h: BYOLO_ABI_VERSION) -- rebuild it with "
+                          "`python bayesian-yolov3_amd/csrc/build.py --force`" % (LIB_PATH, have, ABI_VERSION))
     return lib
 
 
+ABI_VERSION = 4
+PNG_OK, PNG_UNSUPPORTED, PNG_SHAPE, PNG_CORRUPT, FEED_IO, FEED_CRC, FEED_PROTO = 0, 1, 2, 3, 4, 5, 6
 lib = _load()
 
 

@@ -25,11 +25,39 @@ def init(backend=None, force=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm.  BYOLO_DIST_BACKEND=gloo: the N > 1 path with REAL engines on a box with fewer GPUs than
+            # ranks (RCCL refuses two ranks on one device) -- the collectives then go through host memory (host_staged())
+            backend = os.environ.get("BYOLO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def local_device(local_rank):
+    """The GPU of this process: LOCAL_RANK, as torchrun numbers them -- unless BYOLO_DIST_SHARE_DEVICE=1 puts every rank on
+    cuda:0 (tests and bench.py --gpus 2 on a one-GPU box, together with BYOLO_DIST_BACKEND=gloo)."""
+    return 0 if os.environ.get("BYOLO_DIST_SHARE_DEVICE", "0") == "1" else local_rank
+
+
+def host_staged(tensor):
+    """True if a collective on `tensor` has to go through host memory: a device tensor under the gloo backend."""
+    import torch.distributed as dist
+    return dist.is_initialized() and dist.get_backend() == "gloo" and tensor.is_cuda
+
+
+def all_gather_flat(recv, send):
+    """dist.all_gather_into_tensor(recv, send) for flat float32 buffers; under gloo with device tensors the exchange is staged
+    through host memory (this WAITS for the current stream -- a test / small-box mode, never the RCCL path)."""
+    import torch
+    import torch.distributed as dist
+    if not host_staged(send):
+        dist.all_gather_into_tensor(recv, send)
+        return
+    h_send = send.cpu()                                   # synchronises with the current stream
+    h_recv = torch.empty(recv.numel(), dtype=recv.dtype)
+    dist.all_gather_into_tensor(h_recv, h_send)
+    recv.copy_(h_recv)
 
 
 def agree_on_error(err, src=0):
@@ -71,7 +99,7 @@ def allgather_boxes(rows, kept, count, world=None):
     send[n_r:n_r + n_k] = kept.reshape(-1).view(torch.float32)          # bit-cast, no conversion
     send[n_r + n_k:] = count.reshape(-1).view(torch.float32)
     recv = torch.empty(world * send.numel(), dtype=torch.float32, device=rows.device)
-    dist.all_gather_into_tensor(recv, send)
+    all_gather_flat(recv, send)
     recv = recv.view(world, -1)
     g_rows = recv[:, :n_r].reshape(world * Bl, cap, D)
     g_kept = recv[:, n_r:n_r + n_k].contiguous().view(torch.int32).reshape(world * Bl, cap)

@@ -72,6 +72,13 @@ class Engine:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(self._h, lib.byolo_status(self._h, ctypes.c_void_p(stream), None, None))
 
+    def copy_status(self, out):
+        """The two status words into `out` (2 x int32 / uint32 on the device) on the current stream, without waiting: the
+        multi-GPU driver sends them along with the box list (byolo/inference.py)."""
+        torch = _torch()
+        assert out.is_cuda and out.numel() >= 2 and out.element_size() == 4 and out.is_contiguous()
+        check(self._h, lib.byolo_copy_status(self._h, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
     def clear_status(self):
         torch = _torch()
         check(self._h, lib.byolo_clear_status(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
@@ -232,6 +239,23 @@ class Engine:
         if img.device.index != self.device:
             raise ValueError("img is on cuda:%s, engine on cuda:%d" % (img.device.index, self.device))
 
+    @property
+    def torch_device(self):
+        return "cuda:%d" % self.device
+
+    def normalize_u8(self, u8, out=None):
+        """decode_img's `convert_image_dtype(uint8 -> float32)` on the device: out = float(u8) * (1/255), fp32, on the current
+        stream (byolo_normalize_u8).  u8: contiguous uint8 CUDA tensor; returns the float32 tensor forward() takes."""
+        torch = _torch()
+        if not (isinstance(u8, torch.Tensor) and u8.is_cuda and u8.dtype == torch.uint8 and u8.is_contiguous()):
+            raise TypeError("u8 must be a contiguous uint8 CUDA tensor")
+        if out is None:
+            out = torch.empty(u8.shape, dtype=torch.float32, device=u8.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == u8.numel()
+        check(self._h, lib.byolo_normalize_u8(self._h, ctypes.c_void_p(u8.data_ptr()), u8.numel(), ctypes.c_void_p(out.data_ptr()),
+                                              ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
+
     def max_images(self, T=1):
         """Largest batch one byolo_forward call accepts at this T (32-bit source offsets: every activation < 3 GiB)."""
         n = ctypes.c_int32()
@@ -242,7 +266,10 @@ class Engine:
                 mask_bits=None):
         """One sess.run of the reference (inference_epistemic.py:76).  Returns a dict of device
         tensors: rows [B,cap,D], kept [B,cap] int32, count [B,2] int32 and (want_boxes) boxes [B,N,D].
-        Everything is enqueued on torch's current stream; no host synchronisation.
+        Everything is enqueued on torch's current stream.  Host synchronisation: in the split-f16 precision the call WAITS for
+        the stream at its end to read the range status and raises ByoloError(ERR_RANGE) itself -- unless set_async(True), under
+        which nothing waits and the caller asks check_status() / status() / copy_status() where it synchronises anyway (the
+        inference driver and bench.py do).  The fp32 mode never waits.
 
         first_image: position of img[0] in the logical batch (a shard of a data-parallel batch, a sub-batch): the
         dropout masks are those the unsplit batch would draw.  Batches beyond max_images(T) are run as

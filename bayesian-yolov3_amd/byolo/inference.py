@@ -7,7 +7,6 @@ import glob
 import json
 import logging
 import os
-import threading
 
 import numpy as np
 
@@ -140,17 +139,61 @@ def step_of(checkpoint):
 # ---------------------------------------------------------------------------------------------------
 # the driver loop
 # ---------------------------------------------------------------------------------------------------
-class InferenceLoop:
-    """`Inference` of the three scripts: dataset -> model.run -> one-deep asynchronous ECP-JSON writer.
-    Build extensions (all optional config keys): `weights='synthetic'` (random-init + device BN
-    calibration instead of a checkpoint), `seed`, `nms_mode`.
+class _Slot:
+    """Everything one batch in flight owns: a HIP stream, the uint8 / float32 image buffers, the packed send buffer
+    [rows | kept | count | status words] the forward writes its outputs INTO (so the all-gather needs no packing pass), the
+    gathered buffer, its pinned host mirror and the event that says the mirror is complete.  Workspace arena `ws_slot`."""
 
-    Multi-GPU (`torchrun --nproc-per-node N inference_epistemic.py`, one process per GPU; the reference pins one
-    device, `inference_epistemic.py:57`): `batch_size` stays the GLOBAL batch.  Rank r builds its engine on
-    cuda:LOCAL_RANK, decodes and runs its contiguous block of every global batch with `first_image` = the block's
-    position (the N-GPU job draws the dropout masks one GPU would draw on the whole batch), ONE all-gather
-    (byolo.dist.allgather_boxes: RCCL over xGMI) assembles the final box list, and rank 0 alone creates the output
-    directory and writes the JSON files.  Ranks other than 0 never copy results to the host."""
+    def __init__(self, loop, k, bl, world):
+        import torch
+        dev, cuda = loop.dev, loop.cuda
+        h, w, c = loop.img_size
+        cap, D = loop.cap, loop.D
+        self.ws_slot = 1 + k
+        self.stream = torch.cuda.Stream(device=dev) if cuda else None
+        self.event = torch.cuda.Event() if cuda else None
+        self.u8 = torch.empty((bl, h, w, c), dtype=torch.uint8, device=dev)
+        self.img = torch.empty((bl, h, w, c), dtype=torch.float32, device=dev)
+        self.words = bl * cap * D + bl * cap + bl * 2 + 2
+        self.send = torch.zeros(self.words, dtype=torch.float32, device=dev)
+        self.recv = torch.empty(world * self.words, dtype=torch.float32, device=dev) if loop.pg else self.send
+        self.host = torch.empty(self.recv.numel(), dtype=torch.float32, pin_memory=cuda)
+
+    def views(self, t, bl, cap, D):
+        """(rows [bl,cap,D] f32, kept [bl,cap] i32, count [bl,2] i32, status [2] i32) of one rank's packed buffer `t`."""
+        import torch
+        n_r, n_k = bl * cap * D, bl * cap
+        return (t[:n_r].view(bl, cap, D), t[n_r:n_r + n_k].view(torch.int32).view(bl, cap),
+                t[n_r + n_k:n_r + n_k + 2 * bl].view(torch.int32).view(bl, 2), t[n_r + n_k + 2 * bl:n_r + n_k + 2 * bl + 2].view(torch.int32))
+
+
+class InferenceLoop:
+    """`Inference` of the three scripts (`inference_epistemic.py:40-92`): dataset -> model.run -> asynchronous ECP-JSON writer.
+    Build extensions (all optional config keys): `weights='synthetic'` (random-init + device BN calibration instead of a
+    checkpoint), `seed`, `engine_options`, `writer_threads` (default 4), `data.prefetch` (default 2).
+
+    The reference overlaps three things: tf.data decodes (`cpu_thread_cnt` threads) and prefetches one batch while the session
+    runs, and one writer thread dumps the previous batch's JSON.  Same stages here, sized for a device that finishes a
+    608 x 608, T=30 image in 3 ms:
+
+      feed     lib_yolo.dataset_utils.TestingDataset.iter_shards_u8: native decode pool + prefetch, uint8 frames in pinned memory;
+      device   TWO batches in flight, each on its own HIP stream / workspace arena (`_Slot`): H2D of the bytes, * (1/255) on the
+               device, the forward with no host wait inside (byolo_set_async), the all-gather, D2H of the box list into pinned
+               memory, an event.  The loop enqueues batch i, then waits for batch i-1's event: the device always has work queued;
+      writer   `writer_threads` threads, one image per task: the JSON text comes from the native formatter (byolo_format_ecp_json,
+               byte-identical to json.dump of `to_ecp`'s dicts, no GIL held) when `to_ecp` is the script's stock function, from
+               json.dumps otherwise.
+
+    Multi-GPU (`torchrun --nproc-per-node N inference_epistemic.py`, one process per GPU; the reference pins one device,
+    `inference_epistemic.py:57`): `batch_size` stays the GLOBAL batch.  Rank r builds its engine on cuda:LOCAL_RANK, decodes and
+    runs its contiguous block of every global batch with `first_image` = the block's position (the N-GPU job draws the dropout
+    masks one GPU would draw on the whole batch), ONE all-gather per batch (RCCL over xGMI) assembles the final box list -- and
+    every rank's range status -- on every rank, and every rank writes the files of ITS images (rank 0 creates the directory).
+
+    BYOLO_ERR_RANGE (an activation beyond what split-f16 holds): all ranks read the same gathered status words, so they switch
+    to the fp32 mode TOGETHER, re-run the batches in flight and carry on in fp32 (`self.stats['precision_switches']`)."""
+
+    stock_to_ecp = None          # the script's own bbox_to_ecp_format: set by its Inference class
 
     def __init__(self, yolo, config, variant, to_ecp, batched):
         from lib_yolo import dataset_utils
@@ -166,7 +209,7 @@ class InferenceLoop:
         # existing output directory) tells the others, and all of them stop together instead of waiting for a dead peer
         self.rank, self.local_rank, self.world = bdist.init()
         if self.world > 1:                                # one engine per process, on this process's GPU
-            yolo.set_engine_option('device', self.local_rank)
+            yolo.set_engine_option('device', bdist.local_device(self.local_rank))
 
         self.dataset = dataset_utils.TestingDataset(config)
         self.model = yolo.init_model(inputs=self.dataset.placeholder, training=False).get_model()
@@ -185,7 +228,7 @@ class InferenceLoop:
         err = bdist.agree_on_error(err)                   # every rank learns of rank 0's failure (one broadcast)
         if err is not None:
             raise err
-        self.worker_thread = None
+        self.stats = {}
 
     def _load_weights(self):
         import torch
@@ -196,49 +239,174 @@ class InferenceLoop:
             eng.finalize()
             h, w, c = self.img_size
             # the same calibration frames on every rank -> identical weights
-            eng.calibrate_bn(torch.from_numpy(synth.synthetic_images(2, h, w, c, seed=999)).to(getattr(eng, 'torch_device', 'cuda:%d' % self.device)))
+            eng.calibrate_bn(torch.from_numpy(synth.synthetic_images(2, h, w, c, seed=999)).to(eng.torch_device))
         else:
             restore(self.model, self.checkpoint)
 
-    def run(self):
+    # ---- one batch: enqueue everything, wait for nothing ----------------------------------------------------------
+    def _enqueue(self, shard, step, slot):
+        import contextlib
         import torch
         from byolo import dist as bdist
+        eng = self.model.engine
+        n_loc = int(shard.u8.shape[0])
+        bl = bdist.padded_block(shard.n_global, self.world)       # images per rank in the gathered buffer
+        words = bl * self.cap * self.D + bl * self.cap + bl * 2 + 2
+        send = slot.send[:words]
+        rows, kept, count, status = slot.views(send, bl, self.cap, self.D)
+        with (torch.cuda.stream(slot.stream) if self.cuda else contextlib.nullcontext()):
+            if n_loc:
+                slot.u8[:n_loc].copy_(torch.from_numpy(shard.u8), non_blocking=True)          # pinned -> device, 1 byte per value
+                x = eng.normalize_u8(slot.u8[:n_loc], out=slot.img[:n_loc])                   # decode_img's * (1/255), on the device
+                self.model.run(x, seed=self.seed + step, want_boxes=False, first_image=shard.lo, slot=slot.ws_slot,
+                               out={'rows': rows[:n_loc], 'kept': kept[:n_loc], 'count': count[:n_loc]})
+            if n_loc < bl:
+                count[n_loc:].zero_()                             # padding images of a short block: nothing kept
+            eng.copy_status(status)                               # this rank's range status rides in the same buffer
+            recv = send
+            if self.pg:                                           # ONE collective per global batch
+                recv = slot.recv[:self.world * words]
+                bdist.all_gather_flat(recv, send)
+            host = slot.host[:recv.numel()]
+            host.copy_(recv, non_blocking=True)
+            if self.cuda:
+                slot.event.record(slot.stream)
+        return dict(shard=shard, step=step, slot=slot, bl=bl, words=words, n_loc=n_loc, host=host)
+
+    # ---- ... and its completion: the only place the host waits for the device ---------------------------------------
+    def _complete(self, job):
+        """Waits for the batch; returns False if some rank's forward left the split-f16 range (the rows are then not used)."""
+        import time
+        t0 = time.perf_counter()
+        if self.cuda:
+            job['slot'].event.synchronize()
+        self.stats['wait_device_s'] += time.perf_counter() - t0
+        slot, bl, words = job['slot'], job['bl'], job['words']
+        per_rank = job['host'].view(-1, words)
+        for r in range(per_rank.shape[0]):
+            flags = int(slot.views(per_rank[r], bl, self.cap, self.D)[3][0])
+            if flags:
+                self._range_rank = r
+                return False
+        rows, _, count, _ = slot.views(per_rank[self.rank if self.pg else 0], bl, self.cap, self.D)
+        counts = count[:job['n_loc'], 0].tolist()
+        # copies: the pinned mirror is overwritten two batches from now, the writer may be slower than that
+        boxes = [rows[j, :n].numpy().copy() for j, n in enumerate(counts)]
+        job['shard'].release()                                    # the frames have left the feed's buffer
+        self._write_async(boxes, job['shard'].names)
+        self.stats['images'] += job['n_loc']
+        return True
+
+    def _switch_to_fp32(self, jobs):
+        """Every rank runs this on the same batch (they all read the same gathered status words)."""
+        import torch
+        eng = self.model.engine
+        logging.warning('rank %d reported BYOLO_ERR_RANGE in batch %d: all ranks switch to the fp32 mode and re-run from that batch',
+                        self._range_rank, jobs[0]['step'])
+        if self.cuda:
+            for j in jobs:                                        # whatever is still in flight ran in the old arithmetic
+                j['slot'].event.synchronize()
+        eng.clear_status()
+        eng.set_precision('f32')
+        self.model.finalize()                                     # re-packs the handle's parameters (incl. calibrated statistics) for fp32
+        eng.set_async(True)
+        self.stats['precision_switches'] += 1
+        for j in jobs:
+            redo = self._enqueue(j['shard'], j['step'], j['slot'])
+            if not self._complete(redo):
+                raise RuntimeError('BYOLO_ERR_RANGE in the fp32 mode: a raw detection output is inf / NaN (batch %d)' % j['step'])
+
+    def run(self):
+        import collections
+        import time
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        from byolo import dist as bdist
         rank, _, world = bdist.init()
-        pg = torch.distributed.is_initialized()           # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
+        self.pg = torch.distributed.is_initialized()      # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
         self._load_weights()
         eng = self.model.engine
-        dev = getattr(eng, 'torch_device', 'cuda:%d' % self.device)      # (a CPU stand-in engine in the gloo tests names its own)
-        _, D = eng.num_boxes()
-        cap = eng.out_cap
+        eng.set_async(True)                               # no host wait inside forward(): the status words travel with the rows
+        self.dev = eng.torch_device                       # (a CPU stand-in engine in the gloo tests names its own)
+        self.cuda = str(self.dev).startswith('cuda')
+        _, self.D = eng.num_boxes()
+        self.cap = eng.out_cap
+        self.seed = int(self.config.get('seed', 0))
+        self.stats = dict(images=0, batches=0, wait_feed_s=0.0, wait_device_s=0.0, wait_writer_s=0.0, precision_switches=0,
+                          native_json=False, device=getattr(eng, 'device', None), rank=rank, world=world)
+        bl_max = bdist.padded_block(self.batch_size, world)
+        slots = [_Slot(self, k, bl_max, world if self.pg else 1) for k in range(2)]
+        self._writer_setup()
+
+        def pinned(shape):
+            return torch.empty(shape, dtype=torch.uint8, pin_memory=self.cuda).numpy()
+
+        inflight = collections.deque()
+        t_start = time.perf_counter()
+        feed = self.dataset.iter_shards_u8(rank, world, alloc=pinned, extra_buffers=len(slots) + 1)
         step = 0
-        seed = int(self.config.get('seed', 0))
-        for imgs, files, lo in self.dataset.iter_shards(rank, world):     # ends like tf.errors.OutOfRangeError
-            step += 1
-            n_glob, n_loc = len(files), int(imgs.shape[0])
-            bl = bdist.padded_block(n_glob, world)        # images per rank in the gathered buffer
-            out = {'rows': torch.zeros((bl, cap, D), dtype=torch.float32, device=dev),
-                   'kept': torch.full((bl, cap), -1, dtype=torch.int32, device=dev),
-                   'count': torch.zeros((bl, 2), dtype=torch.int32, device=dev)}
-            if n_loc:
-                x = torch.from_numpy(imgs).to(dev)
-                self.model.run(x, seed=seed + step, want_boxes=False, first_image=lo,
-                               out={k: v[:n_loc] for k, v in out.items()})
-            g = (out['rows'], out['kept'], out['count'])
-            if pg:                                        # ONE collective per global batch
-                g = bdist.allgather_boxes(*g, world)
-            if rank == 0:                                 # only the writer copies anything to the host
-                boxes = [r.cpu().numpy() for r in bdist.unpack_global(*g, n_glob, world)[0]]
-                if self.worker_thread:
-                    self.worker_thread.join()
-                self.worker_thread = threading.Thread(target=self.write_to_disc, args=(boxes, files))
-                self.worker_thread.start()
-            if step % 15 == 0:
-                logging.info('Processed {} images.'.format(step * self.batch_size))
+        with ThreadPoolExecutor(max_workers=self.writer_threads, thread_name_prefix='byolo-writer') as self._pool:
+            try:
+                while True:
+                    t0 = time.perf_counter()
+                    shard = next(feed, None)              # ends like tf.errors.OutOfRangeError
+                    self.stats['wait_feed_s'] += time.perf_counter() - t0
+                    if shard is None:
+                        break
+                    step += 1
+                    inflight.append(self._enqueue(shard, step, slots[step % len(slots)]))
+                    if len(inflight) == len(slots):
+                        self._retire(inflight)
+                    if step % 15 == 0:
+                        logging.info('Processed {} images.'.format(step * self.batch_size))
+                while inflight:
+                    self._retire(inflight)
+            finally:
+                feed.close()
+            self._writer_drain(0)
+        self.stats['batches'] = step
+        self.stats['loop_s'] = time.perf_counter() - t_start
+        self.stats['precision'] = getattr(eng, 'precision', None)
         logging.info('Processed {} batches.'.format(step))
-        if self.worker_thread:
-            self.worker_thread.join()
-        if pg:
+        if self.pg:
             torch.distributed.barrier()                   # the files exist when any rank returns
+        return self.stats
+
+    def _retire(self, inflight):
+        if self._complete(inflight[0]):
+            inflight.popleft()
+            return
+        jobs = list(inflight)
+        inflight.clear()
+        self._switch_to_fp32(jobs)
+
+    # ---- writer ---------------------------------------------------------------------------------------------------------
+    def _writer_setup(self):
+        import collections
+        self.writer_threads = max(1, int(self.config.get('writer_threads', 4)))
+        self._pending = collections.deque()
+        self._formatter = None
+        if self.stock_to_ecp is not None and self.to_ecp is self.stock_to_ecp:
+            try:
+                from byolo import hostio
+                self._formatter = hostio.EcpJsonFormatter(self.variant, self.img_size, self.model.cls_cnt, self.model.obj_idx,
+                                                          self.model.cls_start_idx, self.config['implicit_background_class'],
+                                                          LABEL_TO_CLS_NAME)
+            except ValueError as e:                       # a label table the native formatter does not write
+                logging.info('ECP JSON through json.dumps: %s', e)
+        self.stats['native_json'] = self._formatter is not None
+
+    def _write_async(self, boxes, files):
+        for bxs, filename in zip(boxes, files):
+            self._pending.append(self._pool.submit(self.write_ecp_json, bxs, filename))
+        self._writer_drain(16 * self.writer_threads)      # back-pressure: at most this many images wait for the writer
+
+    def _writer_drain(self, keep):
+        import time
+        t0 = time.perf_counter()
+        while len(self._pending) > keep:
+            self._pending.popleft().result()              # re-raises a writer's exception
+        self.stats['wait_writer_s'] += time.perf_counter() - t0
 
     def write_to_disc(self, boxes, files):
         for bxs, filename in zip(boxes, files):
@@ -247,7 +415,12 @@ class InferenceLoop:
     def write_ecp_json(self, boxes, img_name):
         out_name = '{}.json'.format(os.path.splitext(os.path.basename(img_name))[0])
         out_file = os.path.join(self.out_path, out_name)
-        with open(out_file, 'w') as f:
-            json.dump({
+        formatter = getattr(self, '_formatter', None)
+        if formatter is not None:
+            text = formatter.format(boxes)
+        else:                                             # json.dump(..., f) writes exactly these characters
+            text = json.dumps({
                 'children': [self.to_ecp(bbox, self.img_size, self.model, self.config) for bbox in boxes],
-            }, f, default=lambda x: x.tolist())
+            }, default=lambda x: x.tolist()).encode('ascii')
+        with open(out_file, 'wb') as f:
+            f.write(text)

@@ -206,7 +206,8 @@ static int32_t fail(byolo_t* h, int32_t code, const char* fmt, ...) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" const char* byolo_version(void) { return "byolo 0.2 (gfx950; fp32 MFMA and split-f16 MFMA)"; }
+extern "C" const char* byolo_version(void) { return "byolo 0.4 (gfx950; fp32 MFMA and split-f16 MFMA; abi 4)"; }
+extern "C" int32_t byolo_abi_version(void) { return BYOLO_ABI_VERSION; }
 
 extern "C" const char* byolo_last_error(const byolo_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -1453,6 +1454,26 @@ extern "C" int32_t byolo_clear_status(byolo_t* h, void* stream) {
     return BYOLO_OK;
 }
 
+extern "C" int32_t byolo_copy_status(byolo_t* h, uint32_t* d_out, void* stream) {
+    if (!h || !d_out) return fail(h, BYOLO_ERR_ARG, "byolo_copy_status: null argument");
+    if (!h->finalized) return fail(h, BYOLO_ERR_STATE, "byolo_copy_status: call byolo_finalize first");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!h->d_status) { HIPCHK(h, hipMemsetAsync(d_out, 0, 2 * sizeof(uint32_t), st)); return BYOLO_OK; }       // fp32 mode: never raised
+    HIPCHK(h, hipMemcpyAsync(d_out, h->d_status, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_normalize_u8(byolo_t* h, const uint8_t* d_u8, int64_t n, float* d_f32, void* stream) {
+    if (!h || n < 0 || (n > 0 && (!d_u8 || !d_f32))) return fail(h, BYOLO_ERR_ARG, "byolo_normalize_u8: bad argument");
+    if ((reinterpret_cast<uintptr_t>(d_u8) & 3) || (reinterpret_cast<uintptr_t>(d_f32) & 15))
+        return fail(h, BYOLO_ERR_ARG, "byolo_normalize_u8: d_u8 must be 4-byte and d_f32 16-byte aligned");
+    if (n == 0) return BYOLO_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_u8_to_f32(d_u8, d_f32, n, reinterpret_cast<hipStream_t>(stream)));
+    return BYOLO_OK;
+}
+
 extern "C" const char* byolo_precision_note(const byolo_t* h) { return h ? h->prec_note.c_str() : ""; }
 
 extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
@@ -1717,6 +1738,10 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         if (split) {                                                       // statistics of the accumulators -> of the convolution
             for (int c = 0; c < N; ++c) { const float f = 1.f / acc_scale_of(l, c); h->params[l.p_mean].data[c] *= f; h->params[l.p_var].data[c] *= f * f; }
         }
+        for (int c = 0; c < N; ++c)            // what byolo_finalize refuses in a checkpoint must not enter through calibration either
+            if (!std::isfinite(h->params[l.p_mean].data[c]) || !std::isfinite(h->params[l.p_var].data[c]))
+                return fail(h, BYOLO_ERR_ARG, "byolo_calibrate_bn: the batch statistics of layer '%s', channel %d are not finite (inf / NaN "
+                            "activations on the calibration frames)", l.scope.c_str(), c);
         fold_layer(h, l, sc, sf);
         if (split) fold_split(l, sc, sf);
         HIPCHK(h, hipMemcpyAsync(dptr(h, l.scale_off), sc.data(), sizeof(float) * N, hipMemcpyHostToDevice, st));

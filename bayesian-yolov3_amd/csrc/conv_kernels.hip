@@ -234,6 +234,21 @@ __global__ __launch_bounds__(256) void split_to_f32_kernel(const f32x4* s, f32x4
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
         d[i] = epi::split_decode4(s[i]) * mul;
 }
+// tf.image.convert_image_dtype(uint8 -> float32) of decode_img (lib_yolo/dataset_utils.py:6-11): float(u8) * (1 / 255) in fp32,
+// bit for bit what the host's `astype(float32) * float32(1 / 255)` gives; 4 pixels-channels per thread (one dword in, 16 bytes out)
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint32_t* s, f32x4* d, int64_t n4) {
+    const float k = 1.0f / 255.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = __builtin_nontemporal_load(s + i);
+        f32x4 v;
+        v[0] = (float)(w & 0xFFu) * k; v[1] = (float)((w >> 8) & 0xFFu) * k; v[2] = (float)((w >> 16) & 0xFFu) * k; v[3] = (float)(w >> 24) * k;
+        d[i] = v;
+    }
+}
+__global__ void u8_to_f32_tail_kernel(const uint8_t* s, float* d, int64_t lo, int64_t n) {
+    const int64_t i = lo + threadIdx.x;
+    if (i < n) d[i] = (float)s[i] * (1.0f / 255.0f);
+}
 static unsigned grid_for(int64_t n) { int64_t b = (n + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > 256 * 32 ? 256 * 32 : b)); }
 hipError_t launch_view_gather(const ConvParams& p, hipStream_t st) {
     hipLaunchKernelGGL(view_gather_kernel, dim3(grid_for((int64_t)p.M * (p.C0 + p.C1))), dim3(256), 0, st, p);
@@ -251,6 +266,13 @@ hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mu
     if (n & 3) return hipErrorInvalidValue;
     hipLaunchKernelGGL(f32_to_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src),
                        reinterpret_cast<f32x4*>(dst), n / 4, mul, status);
+    return hipGetLastError();
+}
+hipError_t launch_u8_to_f32(const uint8_t* src, float* dst, int64_t n, hipStream_t st) {
+    const int64_t n4 = n / 4;
+    if (n4) hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for(n4)), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(src),
+                               reinterpret_cast<f32x4*>(dst), n4);
+    if (n & 3) hipLaunchKernelGGL(u8_to_f32_tail_kernel, dim3(1), dim3(4), 0, st, src, dst, n4 * 4, n);
     return hipGetLastError();
 }
 hipError_t launch_split_to_f32(const float* src, float* dst, int64_t n, float mul, hipStream_t st) {

@@ -42,6 +42,8 @@ def concat_bbox(net_out):
 
 
 class Inference(_inf.InferenceLoop):
+    stock_to_ecp = staticmethod(bbox_to_ecp_format)     # written by the native formatter unless replaced (byolo/inference.py)
+
     def __init__(self, yolo, config):
         assert config['inference_mode']
         super().__init__(yolo, config, VARIANT, bbox_to_ecp_format, batched=False)
@@ -55,10 +57,11 @@ def inference(config):
     start = time.time()
 
     yolo = yolov3.bayesian_yolov3_aleatoric(config)
-    Inference(yolo, config).run()
+    stats = Inference(yolo, config).run()
 
     elapsed = int(time.time() - start)
     logging.info('----- FINISHED in {:02d}:{:02d}:{:02d} -----'.format(elapsed // 3600, (elapsed // 60) % 60, elapsed % 60))
+    return stats            # (the reference returns nothing) feed / device / writer waits of the loop: byolo/inference.py
 
 
 def main():
@@ -71,7 +74,7 @@ def main():
         'batch_size': 1,
         'T': 50,  # 288 GB of HBM: no need to lower it
         'inference_mode': True,
-        'cpu_thread_cnt': 24,  # unused here (kept for config compatibility)
+        'cpu_thread_cnt': 24,  # decode threads of the input feed (per process)
         'crop': False,
         'training': False,
         'aleatoric_loss': False,

@@ -41,6 +41,8 @@ def concat_bbox(net_out):
 
 
 class Inference(_inf.InferenceLoop):
+    stock_to_ecp = staticmethod(bbox_to_ecp_format)     # written by the native formatter unless replaced (byolo/inference.py)
+
     def __init__(self, yolo, config):
         super().__init__(yolo, config, VARIANT, bbox_to_ecp_format, batched=True)
 
@@ -53,10 +55,11 @@ def inference(config):
     start = time.time()
 
     yolo = yolov3.yolov3(config)
-    Inference(yolo, config).run()
+    stats = Inference(yolo, config).run()
 
     elapsed = int(time.time() - start)
     logging.info('----- FINISHED in {:02d}:{:02d}:{:02d} -----'.format(elapsed // 3600, (elapsed // 60) % 60, elapsed % 60))
+    return stats            # (the reference returns nothing) feed / device / writer waits of the loop: byolo/inference.py
 
 
 def main():
@@ -67,7 +70,7 @@ def main():
         'full_img_size': [1024, 1920, 3],  # edit if not ECP dataset
         'cls_cnt': 2,  # edit if not ECP dataset
         'batch_size': 11,  # edit
-        'cpu_thread_cnt': 24,  # unused here (kept for config compatibility)
+        'cpu_thread_cnt': 24,  # decode threads of the input feed (per process)
         'crop': False,
         'training': False,
         'priors': yolov3.ECP_9_PRIORS,  # edit

@@ -7,14 +7,27 @@
                      `image/filename`, `image/height`, `image/width`
   image              PNG -> uint8 HWC -> float32 * (1/255)   (tf.image.convert_image_dtype)
 
-The reference lists the shard files, interleaves them two at a time (cycle_length=2, block_length=1),
-batches and prefetches one batch; this iterator does the same in sorted file order (the reference's
-`list_files` order is shuffled and therefore not reproducible)."""
+The reference's pipeline (:190-199) is  list_files -> interleave(TFRecordDataset, cycle_length=2, block_length=1) ->
+map(parse_example, num_parallel_calls=config['cpu_thread_cnt']) -> batch -> prefetch(1).  Here:
+
+  * records are taken in sorted file order, interleaved two files at a time (the reference's `list_files` order is shuffled
+    and therefore not reproducible);
+  * the map stage runs on `cpu_thread_cnt` native threads (csrc/host_io.cpp through the C-ABI: byolo_feed_records, one call
+    per batch that holds no GIL): each reads its record's payload, checks the CRC, finds the PNG in the Example and inflates /
+    unfilters it (zlib) straight into its frame of a batch buffer the caller may have pinned;
+  * `prefetch` batches (config['data']['prefetch'], default 2) are decoded ahead of the consumer by a feeder thread;
+  * frames leave the host as uint8 -- the * (1/255) runs on the device (byolo_normalize_u8), bit-identical -- except through
+    the plain iterator (`for imgs, names in dataset`), which yields the reference's float32 batches;
+  * multi-GPU: a rank only reads, checks and decodes the records of ITS block of every global batch; the others are skipped by
+    their framing (12 header bytes each)."""
+import collections
 import ctypes
 import glob
 import io
 import os
+import queue
 import struct
+import threading
 
 import numpy as np
 
@@ -25,8 +38,7 @@ _MASK_DELTA = 0xA282EAD8
 
 def _masked_crc(data):
     from byolo._lib import lib
-    buf = (ctypes.c_char * len(data)).from_buffer_copy(data)
-    crc = lib.byolo_crc32c(buf, len(data))
+    crc = lib.byolo_crc32c(data if isinstance(data, bytes) else bytes(data), len(data))     # (ctypes drops the GIL for the call)
     return ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + _MASK_DELTA) & 0xFFFFFFFF
 
 
@@ -104,7 +116,7 @@ def _fields(buf):
 def parse_example(data):
     """tf.train.Example -> {feature name: list of bytes / int / float values}.  Malformed input raises ValueError."""
     try:
-        return _parse_example(data)
+        return _parse_example(memoryview(data))         # nested messages are slices of one buffer, not copies
     except (IndexError, TypeError, OverflowError, UnicodeDecodeError) as e:
         raise ValueError('corrupt tf.train.Example: {}'.format(e))
 
@@ -178,8 +190,11 @@ def make_example(features):
     return _pb_bytes(1, entries)
 
 
-def decode_img(encoded, shape):
-    """`lib_yolo/dataset_utils.py:6-11`: decode PNG and scale to [0, 1] as float32."""
+
+
+def decode_png_u8(encoded, shape):
+    """`tf.image.decode_png(encoded, dtype=tf.uint8)` + `set_shape` of decode_img (`lib_yolo/dataset_utils.py:6-9`) for one
+    record through the general decoder (Pillow): what the native pool falls back to for PNG flavours it does not read."""
     from PIL import Image
     img = np.asarray(Image.open(io.BytesIO(encoded)))
     if img.ndim == 2:
@@ -188,15 +203,62 @@ def decode_img(encoded, shape):
         raise ValueError('only 8-bit PNGs are on this path (decode_png dtype=tf.uint8)')
     if tuple(img.shape) != tuple(shape):
         raise ValueError('image shape {} != config full_img_size {}'.format(img.shape, tuple(shape)))
-    return img.astype(np.float32) * np.float32(1.0 / 255.0)        # convert_image_dtype(uint8 -> float32)
+    return img
+
+
+def decode_img(encoded, shape):
+    """`lib_yolo/dataset_utils.py:6-11`: decode PNG and scale to [0, 1] as float32."""
+    return decode_png_u8(encoded, shape).astype(np.float32) * np.float32(1.0 / 255.0)      # convert_image_dtype(uint8 -> float32)
+
+
+class _RecordFile:
+    """Records of one TFRecord file by their framing only: (offset, length) of every payload; payloads are read on demand
+    (os.pread: thread-safe), so a rank never touches the bytes of another rank's records."""
+
+    def __init__(self, path, verify_crc):
+        self.path, self.verify_crc = path, verify_crc
+        self.fd = os.open(path, os.O_RDONLY)
+        self.size = os.fstat(self.fd).st_size
+
+    def __del__(self):
+        try:
+            os.close(self.fd)
+        except Exception:
+            pass
+
+    def __iter__(self):
+        pos = 0
+        while pos < self.size:
+            head = os.pread(self.fd, 12, pos)
+            if len(head) < 12:
+                raise IOError('truncated TFRecord header in {}'.format(self.path))
+            length, = struct.unpack('<Q', head[:8])
+            if self.verify_crc and _masked_crc(head[:8]) != struct.unpack('<I', head[8:])[0]:
+                raise IOError('corrupt TFRecord length CRC in {}'.format(self.path))
+            if length > self.size - pos - 16:         # a corrupt length must not turn into a giant read
+                raise IOError('truncated TFRecord in {}'.format(self.path))
+            yield (self, pos + 12, length)
+            pos += 16 + length
+
+    def payload(self, off, length):
+        data = os.pread(self.fd, length + 4, off)
+        if len(data) < length + 4:
+            raise IOError('truncated TFRecord in {}'.format(self.path))
+        if self.verify_crc and _masked_crc(data[:length]) != struct.unpack('<I', data[length:])[0]:
+            raise IOError('corrupt TFRecord data CRC in {}'.format(self.path))
+        return memoryview(data)[:length]
+
+
+Shard = collections.namedtuple('Shard', 'u8 names lo n_global release')
+Shard.__doc__ = """One rank's block of one global batch: u8 [n_local,H,W,C] uint8 (a view of a batch buffer: call release() when
+the frames have left it -- the buffer then goes back to the feeder), the block's file names, its offset `lo` in the global
+batch (-> first_image: the dropout stream position) and the global batch's size."""
 
 
 class TestingDataset:
     """Iterable of (images [B,H,W,C] float32, [filenames]) batches; `placeholder` is what the model is
     built on.  `batch_size` is the GLOBAL batch, as in the reference (`lib_yolo/dataset_utils.py:188-219`).
-    Multi-GPU (torchrun, one process per GPU): `iter_shards(rank, world)` -- every rank reads the same record stream,
-    parses the (cheap) Example protos of a global batch for the file names and decodes only the PNGs of ITS
-    contiguous block of the batch axis (byolo.dist.shard_range)."""
+    The entry points read it through `iter_shards_u8(rank, world)` (module docstring)."""
     __test__ = False
 
     def __init__(self, config, config_key='data'):
@@ -206,15 +268,17 @@ class TestingDataset:
         self.batch_size = config['batch_size']
         self.shape = tuple(config['full_img_size'])
         self.verify_crc = info.get('verify_crc', True)
+        self.threads = max(1, int(config.get('cpu_thread_cnt', 1)))          # num_parallel_calls of the map stage (:196)
+        self.prefetch = max(1, int(info.get('prefetch', 2)))                 # batches decoded ahead (:199 prefetches 1)
         self.placeholder = _model.Placeholder((self.batch_size,) + self.shape)
 
     def _records(self):
-        # files.interleave(TFRecordDataset, cycle_length=2, block_length=1)
+        # files.interleave(TFRecordDataset, cycle_length=2, block_length=1): record handles, no payload is read here
         pending = list(self.files)
         active = []
         while pending or active:
             while len(active) < 2 and pending:
-                active.append(read_tfrecords(pending.pop(0), self.verify_crc))
+                active.append(iter(_RecordFile(pending.pop(0), self.verify_crc)))
             for it in list(active):
                 try:
                     yield next(it)
@@ -240,17 +304,107 @@ class TestingDataset:
         feats = parse_example(example)
         return decode_img(feats['image/encoded'][0], self.shape), self._filename(feats)
 
-    def __iter__(self):
-        for imgs, names, _ in self.iter_shards(0, 1):
-            yield imgs, names
+    def _load_block(self, recs, buf):
+        """The map stage for the records of one block: payload (+ CRC) -> Example -> PNG decoded into buf[j] ([H,W,C] uint8), on
+        `cpu_thread_cnt` native threads in ONE call that holds no GIL (byolo_feed_records); returns the file names."""
+        from byolo import _lib
+        n = len(recs)
+        if n == 0:
+            return []
+        i32, i64 = ctypes.c_int32, ctypes.c_int64
+        fds = (i32 * n)(*[r[0].fd for r in recs])
+        offs = (i64 * n)(*[r[1] for r in recs])
+        lens = (i64 * n)(*[r[2] for r in recs])
+        status = (i32 * n)()
+        found = (i32 * (3 * n))()
+        cap = 1024
+        names = ctypes.create_string_buffer(n * cap)
+        h, w, c = self.shape
+        assert buf.dtype == np.uint8 and buf.flags['C_CONTIGUOUS'] and buf.shape[0] >= n and tuple(buf.shape[1:]) == self.shape
+        rc = _lib.lib.byolo_feed_records(fds, offs, lens, n, int(bool(self.verify_crc)), h, w, c, ctypes.c_void_p(buf.ctypes.data),
+                                         self.threads, names, cap, status, found)
+        if rc < 0:
+            raise ValueError('byolo_feed_records: bad argument (full_img_size {})'.format(self.shape))
+        out = []
+        for j, (rf, off, length) in enumerate(recs):
+            st = status[j]
+            if st == _lib.PNG_OK:
+                out.append(names[j * cap:(j + 1) * cap].split(b'\0', 1)[0].decode('utf-8'))
+                continue
+            if st == _lib.FEED_IO:
+                raise IOError('truncated TFRecord in {}'.format(rf.path))
+            if st == _lib.FEED_CRC:
+                raise IOError('corrupt TFRecord data CRC in {}'.format(rf.path))
+            if st == _lib.PNG_SHAPE:
+                raise ValueError('image shape {} != config full_img_size {}'.format(tuple(found[3 * j:3 * j + 3]), self.shape))
+            # a malformed Example, or a PNG flavour the native decoder does not read (interlaced / palette / 16-bit) or finds
+            # damaged: the general path decides (and raises what it always raised)
+            feats = parse_example(rf.payload(off, length))
+            enc = feats.get('image/encoded')
+            if not enc:
+                raise ValueError('record without image/encoded in {}'.format(rf.path))
+            buf[j] = decode_png_u8(enc[0], self.shape)
+            out.append(self._filename(feats))
+        return out
 
-    def iter_shards(self, rank, world):
-        """Yields (images of this rank's block [n_local,H,W,C], ALL filenames of the global batch, lo): the block is
-        images [lo, lo + n_local) of the global batch; n_local may be 0 for a last, short batch."""
+    def __iter__(self):
+        for sh in self.iter_shards_u8(0, 1):
+            x = sh.u8.astype(np.float32) * np.float32(1.0 / 255.0)          # convert_image_dtype(uint8 -> float32)
+            sh.release()
+            yield x, sh.names
+
+    def iter_shards_u8(self, rank, world, alloc=None, extra_buffers=2):
+        """Yields a `Shard` per global batch: the frames of this rank's contiguous block (byolo.dist.shard_range; may be empty
+        for a last, short batch).  alloc(shape) -> uint8 ndarray provides the batch buffers (the driver passes pinned memory);
+        `prefetch` + 1 + extra_buffers of them circulate: one being filled, `prefetch` waiting, extra_buffers with the consumer."""
         from byolo.dist import shard_range
-        for recs in self._global_batches():
-            lo, hi = shard_range(len(recs), rank, world)
-            feats = [parse_example(r) for r in recs]
-            imgs = [decode_img(f['image/encoded'][0], self.shape) for f in feats[lo:hi]]
-            x = np.stack(imgs) if imgs else np.empty((0,) + self.shape, dtype=np.float32)
-            yield x, [self._filename(f) for f in feats], lo
+        alloc = alloc or (lambda shape: np.empty(shape, dtype=np.uint8))
+        cap = shard_range(self.batch_size, 0, world)[1]                      # the largest block of a full batch
+        free = queue.Queue()
+        for _ in range(self.prefetch + 1 + max(1, extra_buffers)):
+            free.put(alloc((max(cap, 1),) + self.shape))
+        ready = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    ready.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def feeder():
+            try:
+                for recs in self._global_batches():
+                    lo, hi = shard_range(len(recs), rank, world)
+                    buf = None
+                    while buf is None:
+                        if stop.is_set():
+                            return
+                        try:
+                            buf = free.get(timeout=0.1)
+                        except queue.Empty:
+                            pass
+                    names = self._load_block(recs[lo:hi], buf)               # a failed record raises here
+                    if not put((buf, hi - lo, names, lo, len(recs))):
+                        return
+                put(None)
+            except BaseException as e:                                        # delivered to the consumer, in order
+                put(e)
+
+        th = threading.Thread(target=feeder, name='byolo-feeder', daemon=True)
+        th.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                buf, n, names, lo, n_glob = item
+                yield Shard(buf[:n], names, lo, n_glob, (lambda b=buf: free.put(b)))
+        finally:
+            stop.set()
+            th.join(timeout=10)

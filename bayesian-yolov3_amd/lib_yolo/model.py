@@ -237,6 +237,8 @@ class Model:
         self.engine = builder.engine if builder is not None else None
         self.T = builder.T if builder is not None else 1
         self.last = None
+        self.range_fallback = True          # run(): BYOLO_ERR_RANGE -> switch this model to the fp32 mode and re-run
+        self.precision_switches = 0
         base = 0
         for dl in det_layers:
             dl._model = self
@@ -249,7 +251,7 @@ class Model:
         self.engine.finalize()
         return self
 
-    def run(self, img, seed=0, dropout_on=True, want_boxes=True, want_nms=True, first_image=0, out=None, mask_bits=None):
+    def run(self, img, seed=0, dropout_on=True, want_boxes=True, want_nms=True, first_image=0, out=None, mask_bits=None, slot=0):
         """img: float32 CUDA tensor [B,H,W,C] in [0,1).  Returns the dict of Engine.forward and keeps
         it as `self.last`, which the DetLayer accessors read.  `first_image`: position of img[0] in the logical
         (multi-GPU / split) batch; `out`: preallocated rows / kept / count tensors; `mask_bits`: injected dropout
@@ -258,21 +260,28 @@ class Model:
         The reference computes in float32 (`lib_yolo/layers.py:550`), which holds any activation a trained checkpoint
         produces.  The default split-f16 arithmetic holds |activation| <= 16376: the library detects anything beyond
         (BYOLO_ERR_RANGE), and this wrapper then re-runs the batch -- and everything after it -- in the fp32 mode, with
-        a warning, instead of handing out rows the reference would not produce."""
+        a warning, instead of handing out rows the reference would not produce; `self.precision_switches` counts those
+        switches and the returned dict says which arithmetic produced it ('precision').  This is the ONE-process behaviour
+        (detect.py, vis_uncertainty.py, tests); `self.range_fallback = False` turns it into a plain ByoloError.  The
+        multi-GPU driver (byolo/inference.py) runs the engine asynchronously -- the wrapper then never switches by itself --
+        and lets all ranks agree on the switch through the status words its all-gather carries.
+        `slot`: workspace arena of the call (forwards in flight on different HIP streams must not share one)."""
         if not self.engine.finalized:
             self.engine.finalize()
         kw = dict(T=self.T, seed=seed, dropout_on=dropout_on, want_boxes=want_boxes, want_nms=want_nms,
-                  first_image=first_image, out=out, mask_bits=mask_bits)
+                  first_image=first_image, out=out, mask_bits=mask_bits, slot=slot)
         try:
             self.last = self.engine.forward(img, **kw)
         except ByoloError as e:
-            if e.code != ERR_RANGE or self.engine.precision != 'split' or getattr(self.engine, '_async', False):
+            if e.code != ERR_RANGE or self.engine.precision != 'split' or getattr(self.engine, '_async', False) or not self.range_fallback:
                 raise
             import logging
             logging.warning('%s -- switching this model to the fp32 mode', e)
             self.engine.set_precision('f32')
             self.engine.finalize()
+            self.precision_switches += 1
             self.last = self.engine.forward(img, **kw)
+        self.last['precision'] = self.engine.precision
         return self.last
 
     def matches_blueprint(self, blueprint):

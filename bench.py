@@ -194,9 +194,9 @@ def main():
         sys.exit("bench.py --gpus %d, but WORLD_SIZE=%d: launch N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                  "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...` (one rank per GPU), N = 1 as plain `python bench.py`"
                  % (args.gpus, world, args.gpus, args.gpus))
-    if world > 1 and local >= torch.cuda.device_count():
+    device = bdist.local_device(local) if world > 1 else 0        # (BYOLO_DIST_SHARE_DEVICE=1: every rank on cuda:0, a one-GPU box)
+    if world > 1 and device >= torch.cuda.device_count():
         sys.exit("rank %d: LOCAL_RANK=%d but only %d GPUs are visible" % (rank, local, torch.cuda.device_count()))
-    device = local if world > 1 else 0
     pg = dist.is_initialized()         # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
     torch.cuda.set_device(device)
 

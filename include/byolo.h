@@ -81,6 +81,11 @@ BYOLO_API int32_t byolo_get_precision(const byolo_t* h);
 BYOLO_API const char* byolo_precision_note(const byolo_t* h);
 BYOLO_API const char* byolo_last_error(const byolo_t* h);
 BYOLO_API const char* byolo_version(void);
+/* Incremented on every incompatible change of a signature or of a buffer layout this header describes, so that a binding can
+ * refuse a library it was not written for (byolo/_lib.py does).  4: byolo_forward takes d_mask_bits; detection rows handed out
+ * by byolo_layer_output are padded to a multiple of 4 floats; the host-side feed / writer entry points exist. */
+#define BYOLO_ABI_VERSION 4
+BYOLO_API int32_t byolo_abi_version(void);
 
 /* ---- graph construction: one call per ModelBuilder.make_* (lib_yolo/model.py:52-185).
  * Each returns the new layer's index (>= 0) in the reference's `ModelBuilder.__layers` numbering
@@ -261,6 +266,53 @@ BYOLO_API int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops);
 /* ---- input feed helper (host only): CRC-32C of the TFRecord framing read by the reference's
  * tf.data.TFRecordDataset (lib_yolo/dataset_utils.py:188-199); returns the raw (unmasked) CRC. */
 BYOLO_API uint32_t byolo_crc32c(const void* h_data, size_t n);
+
+
+/* ---- input feed, device side: `tf.image.convert_image_dtype(img, tf.float32)` of decode_img
+ * (lib_yolo/dataset_utils.py:6-11) on the device -- d_f32[i] = float(d_u8[i]) * (1 / 255) in fp32, bit for bit the value the
+ * host conversion produces -- so that the feed ships one byte per pixel-channel over PCIe instead of four.  n = elements
+ * (B * H * W * C); d_f32 is what byolo_forward takes as d_img. */
+BYOLO_API int32_t byolo_normalize_u8(byolo_t* h, const uint8_t* d_u8, int64_t n, float* d_f32, void* stream);
+
+/* The two status words (byolo_status: {flags, layer}) copied device-to-device into d_out[2] on `stream`, without waiting: a
+ * multi-GPU driver appends them to the buffer its ONE all-gather carries, so that every rank learns of any rank's
+ * BYOLO_ERR_RANGE from the gathered list and all ranks switch to the fp32 mode together (byolo/inference.py). */
+BYOLO_API int32_t byolo_copy_status(byolo_t* h, uint32_t* d_out, void* stream);
+
+/* ---- input feed, host side: `tf.image.decode_png(encoded, dtype=tf.uint8)` of decode_img for the n records of a batch on
+ * `threads` host threads -- the `map(parse_example, num_parallel_calls=config['cpu_thread_cnt'])` stage of TestingDataset
+ * (lib_yolo/dataset_utils.py:196).  h_out: n frames of img_h * img_w * img_c bytes (e.g. pinned memory); status[i] per record:
+ * OK, UNSUPPORTED (interlaced / palette / 16-bit: the caller decodes that record with a general decoder), SHAPE (the PNG is
+ * not img_h x img_w x img_c; found_shape[3*i..] = what it is, like the reference's set_shape failure) or CORRUPT (signature,
+ * chunk CRC, zlib stream, filter type).  Returns the number of records that are not OK, or BYOLO_ERR_ARG. */
+enum { BYOLO_PNG_OK = 0, BYOLO_PNG_UNSUPPORTED = 1, BYOLO_PNG_SHAPE = 2, BYOLO_PNG_CORRUPT = 3 };
+BYOLO_API int32_t byolo_png_decode_batch(const uint8_t* const* h_png, const size_t* png_bytes, int32_t n, int32_t img_h,
+                                         int32_t img_w, int32_t img_c, uint8_t* h_out, int32_t threads, int32_t* status,
+                                         int32_t* found_shape);
+
+/* The whole map stage for the n records of a batch, natively: record i = lengths[i] payload bytes at offsets[i] of the open file
+ * fds[i] (TFRecord framing: the payload is followed by its masked CRC-32C, checked if verify_crc) -> tf.train.Example -> the
+ * first bytes value of `image/encoded` decoded as above into frame i of h_out, the first value of `image/filename` into
+ * h_names[i * name_cap ...] (NUL-terminated UTF-8).  status[i] = BYOLO_PNG_* or BYOLO_FEED_IO (short read) / _CRC / _PROTO
+ * (malformed Example, no image, a name of name_cap bytes or more).  Returns the number of records that are not OK. */
+enum { BYOLO_FEED_IO = 4, BYOLO_FEED_CRC = 5, BYOLO_FEED_PROTO = 6 };
+BYOLO_API int32_t byolo_feed_records(const int32_t* fds, const int64_t* offsets, const int64_t* lengths, int32_t n, int32_t verify_crc,
+                                     int32_t img_h, int32_t img_w, int32_t img_c, uint8_t* h_out, int32_t threads, char* h_names,
+                                     int32_t name_cap, int32_t* status, int32_t* found_shape);
+
+/* ---- output writer, host side: the text `json.dump({'children': [bbox_to_ecp_format(b, ...) for b in boxes]}, f)` writes for
+ * the kept rows of ONE image (inference_epistemic.py:84-92 + :131-170; inference_aleatoric.py:139-178;
+ * inference_standard_yolov3.py:128-150), byte for byte: keys in the reference's order, coordinates scaled in float32 then
+ * widened, score = obj * cls[argmax] in double, every number as CPython's float repr (shortest round-trip digits, NaN /
+ * Infinity spelt as json.dump does), the index quirks of the reference kept (aleatoric: cls_entropy / layer_id / prior_id all
+ * read column cls_start + C; epistemic: ped_score / rider_score = columns 17 / 18).  kind = BYOLO_DET_*; h_rows [n_rows,
+ * row_len]; identity = labels[argmax + implicit_background] if that entry exists and is not NULL (ASCII without quotes /
+ * backslashes), else the integer.  Returns the length of the text; if it exceeds cap nothing useful is in h_out and the
+ * return value is -(length) - 16. */
+BYOLO_API int64_t byolo_format_ecp_json(int32_t kind, const float* h_rows, int32_t n_rows, int32_t row_len, int32_t img_h,
+                                        int32_t img_w, int32_t cls_cnt, int32_t obj_idx, int32_t cls_start,
+                                        int32_t implicit_background, const char* const* labels, int32_t n_labels,
+                                        char* h_out, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
 """Worker for tests/test_dist_cpu.py::test_inference_epistemic_world2_*: `inference_epistemic.Inference` -- the driver loop of the
-entry point, unmodified (dataset sharding, first_image, padded blocks, the ONE all-gather, rank-0 JSON writer, error agreement)
+entry point, unmodified (dataset sharding, first_image, padded blocks, two batches in flight, the ONE all-gather that also carries
+the range status, every rank writing the files of its own images, error agreement)
 -- as rank `rank` of a gloo job on CPU tensors, with a stand-in for the GPU engine that returns rows which are a pure function
 of (pixels, position of the image in the GLOBAL batch, seed): any mistake in the sharding shows up in the JSON files."""
 import os
@@ -10,6 +11,13 @@ class FakeEngine:
     torch_device = "cpu"
     device = 0
     out_cap = 6
+    precision = "split"
+
+    def __init__(self):
+        self.raise_in = None          # (rank, forward call number): that forward "leaves the split-f16 range"
+        self.flags = 0
+        self.forwards = 0
+        self.log = []
 
     def num_boxes(self):
         return 50, 23
@@ -21,10 +29,29 @@ class FakeEngine:
         pass
 
     def finalize(self):
-        pass
+        self.log.append("finalize:" + self.precision)
 
     def calibrate_bn(self, x):
         pass
+
+    def set_async(self, on=True):
+        self.log.append("async")
+
+    def normalize_u8(self, u8, out=None):           # byolo_normalize_u8
+        import torch
+        out.copy_(u8.to(torch.float32) * torch.tensor(1.0 / 255.0, dtype=torch.float32))
+        return out
+
+    def copy_status(self, out):                     # byolo_copy_status: sticky until cleared
+        out[0] = self.flags
+        out[1] = 7 if self.flags else -1
+
+    def clear_status(self):
+        self.flags = 0
+
+    def set_precision(self, p):
+        self.precision = p
+        self.log.append("precision:" + p)
 
 
 class FakeModel:
@@ -34,9 +61,19 @@ class FakeModel:
         self.engine = FakeEngine()
         self.calls = []
 
+    def finalize(self):
+        self.engine.finalize()
+
     def run(self, x, seed=0, want_boxes=True, first_image=0, out=None, **kw):
         import torch
+        eng = self.engine
+        eng.forwards += 1
         self.calls.append((int(x.shape[0]), int(first_image), int(seed)))
+        if eng.precision == "split" and eng.raise_in == eng.forwards:
+            eng.flags = 1                            # what the epilogues do on the device; the rows are then garbage
+            out["rows"].fill_(float("nan"))
+            out["count"].fill_(3)
+            return out
         for j in range(x.shape[0]):
             g = first_image + j                                    # position in the global batch
             k = 1 + (int(x[j].sum().item() * 7) + g) % self.engine.out_cap
@@ -64,7 +101,7 @@ class FakeYolo:
         return self.model
 
 
-def main(rank, world, port, data_dir, out_path):
+def main(rank, world, port, data_dir, out_path, raise_rank=-1, raise_call=0):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.join(os.path.dirname(here), "bayesian-yolov3_amd"))
@@ -73,6 +110,8 @@ def main(rank, world, port, data_dir, out_path):
     cfg = {"batch_size": 5, "full_img_size": [32, 32, 3], "crop": False, "cls_cnt": 2, "implicit_background_class": True,
            "weights": "synthetic", "seed": 3, "inference_mode": True, "T": 3, "out_path": out_path, "data": {"file_pattern": os.path.join(data_dir, "val-*")}}
     yolo = FakeYolo()
+    if rank == raise_rank:
+        yolo.model.engine.raise_in = raise_call
     try:
         loop = ie.Inference(yolo, cfg)
     except OSError as e:                                   # rank 0's own failure
@@ -81,10 +120,11 @@ def main(rank, world, port, data_dir, out_path):
         print("RANK%d AGREED %s" % (rank, e)); sys.exit(7)
     loop.run()
     import json
-    json.dump({"calls": yolo.model.calls, "options": yolo.options}, open(os.path.join(data_dir, "calls_w%d_r%d.json" % (world, rank)), "w"))
+    json.dump({"calls": yolo.model.calls, "options": yolo.options, "log": yolo.model.engine.log, "stats": loop.stats,
+               "precision": yolo.model.engine.precision}, open(os.path.join(data_dir, "calls_w%d_r%d.json" % (world, rank)), "w"))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], *[int(a) for a in sys.argv[6:8]])

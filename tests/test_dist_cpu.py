@@ -57,37 +57,87 @@ def _records(tmp_path, n, H=32, W=32):
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_dataset_shards_cover_every_global_batch(tmp_path, world):
-    """TestingDataset.iter_shards: batch_size is the GLOBAL batch (as in the reference); rank r gets the contiguous
-    block shard_range(len(batch), r, world) of every global batch, its offset `lo` (-> first_image: the dropout stream
-    position) and ALL file names; the blocks of the ranks tile the batch, also the last short one (blocks may be empty)."""
+    """TestingDataset.iter_shards_u8: batch_size is the GLOBAL batch (as in the reference); rank r gets the contiguous
+    block shard_range(len(batch), r, world) of every global batch as uint8 frames, its offset `lo` (-> first_image: the dropout
+    stream position), the size of the global batch and the file names of ITS block; the blocks of the ranks tile the batch, also
+    the last short one (blocks may be empty).  The plain iterator yields the reference's float32 batches."""
     import numpy as np
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "bayesian-yolov3_amd"))
     from lib_yolo import dataset_utils as du
     from byolo import dist as bdist
     imgs = _records(tmp_path, 11)
-    cfg = {"batch_size": 4, "full_img_size": [32, 32, 3], "data": {"file_pattern": str(tmp_path / "val-*")}}
-    per_rank = [list(du.TestingDataset(cfg).iter_shards(r, world)) for r in range(world)]
+    cfg = {"batch_size": 4, "full_img_size": [32, 32, 3], "cpu_thread_cnt": 3, "data": {"file_pattern": str(tmp_path / "val-*")}}
+    per_rank = []
+    for r in range(world):
+        got = []
+        for sh in du.TestingDataset(cfg).iter_shards_u8(r, world):
+            got.append((sh.u8.copy(), sh.names, sh.lo, sh.n_global))
+            sh.release()
+        per_rank.append(got)
     plain = list(du.TestingDataset(cfg))
     assert [len(n) for _, n in plain] == [4, 4, 3]
     for step in range(3):
-        names = per_rank[0][step][1]
-        assert names == plain[step][1] == ["f%02d.png" % (4 * step + i) for i in range(len(names))]
+        names = plain[step][1]
+        assert names == ["f%02d.png" % (4 * step + i) for i in range(len(names))]
         pos = 0
         for r in range(world):
-            x, n_r, lo = per_rank[r][step]
-            assert n_r == names and lo == pos == bdist.shard_range(len(names), r, world)[0]
-            assert x.dtype == np.float32 and x.shape[1:] == (32, 32, 3)
+            x, n_r, lo, n_glob = per_rank[r][step]
+            assert n_glob == len(names) and lo == pos == bdist.shard_range(len(names), r, world)[0]
+            assert n_r == names[lo:lo + x.shape[0]]
+            assert x.dtype == np.uint8 and x.shape[1:] == (32, 32, 3)
             for j in range(x.shape[0]):
-                assert np.array_equal(x[j], imgs[4 * step + lo + j])
+                assert np.array_equal(x[j].astype(np.float32) * np.float32(1 / 255.), imgs[4 * step + lo + j])
+                assert np.array_equal(plain[step][0][lo + j], imgs[4 * step + lo + j])
             pos += x.shape[0]
         assert pos == len(names)
 
 
-def _run_infer(world, data_dir, out_path, timeout=300):
+def test_feed_prefetches_and_stops_cleanly(tmp_path):
+    """The feeder thread decodes `prefetch` batches ahead and no further (its buffers are finite: back-pressure), hands a
+    record's failure to the consumer at that batch's position, and goes away when the consumer stops early."""
+    import threading
+    import time
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "bayesian-yolov3_amd"))
+    from lib_yolo import dataset_utils as du
+    _records(tmp_path, 12)
+    cfg = {"batch_size": 2, "full_img_size": [32, 32, 3], "cpu_thread_cnt": 2, "data": {"file_pattern": str(tmp_path / "val-*"), "prefetch": 2}}
+    ds = du.TestingDataset(cfg)
+    loaded = []
+    orig = ds._load_block
+    ds._load_block = lambda recs, buf: (loaded.append(len(recs)), orig(recs, buf))[1]
+    it = ds.iter_shards_u8(0, 1, extra_buffers=1)
+    first = next(it)
+    time.sleep(0.5)
+    # 1 with the consumer + 2 waiting in the queue + 1 being held by the feeder for the next put = 4 batches, not all 6
+    assert 3 <= len(loaded) <= 4, loaded
+    first.release()
+    it.close()
+    time.sleep(0.3)
+    assert not [t for t in threading.enumerate() if t.name == "byolo-feeder"]
+    # a corrupt record: batches before it arrive, then the error
+    p = str(tmp_path / "val-00000-of-00001")
+    raw = bytearray(open(p, "rb").read())
+    recs = list(du._RecordFile(p, True))
+    raw[recs[5][1] + 40] ^= 0xFF                       # inside the 6th record's payload (batch 2)
+    open(p, "wb").write(bytes(raw))
+    got = []
+    with pytest.raises(IOError, match="CRC"):
+        for sh in du.TestingDataset(cfg).iter_shards_u8(0, 1):
+            got.append(sh.names); sh.release()
+    assert got == [["f00.png", "f01.png"], ["f02.png", "f03.png"]]
+    # ... which another rank's block does not see: rank 1 of 2 owns the odd records of every batch, record 5 is odd
+    got = []
+    for sh in du.TestingDataset(cfg).iter_shards_u8(0, 2):
+        got.append(sh.names); sh.release()
+    assert got == [["f%02d.png" % i] for i in range(0, 12, 2)]
+
+
+def _run_infer(world, data_dir, out_path, timeout=300, extra=()):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_infer_worker.py"), str(r), str(world), str(port), str(data_dir), out_path],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_infer_worker.py"), str(r), str(world), str(port), str(data_dir), out_path] + [str(e) for e in extra],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=timeout)[0] for p in procs]
     return [p.returncode for p in procs], outs
@@ -96,9 +146,9 @@ def _run_infer(world, data_dir, out_path, timeout=300):
 def test_inference_epistemic_world2_writes_the_single_process_json(tmp_path):
     """`torchrun --nproc-per-node 2 inference_epistemic.py` end to end up to the engine boundary, on CPU (gloo): the driver loop
     of the entry point with a stand-in engine whose rows depend on the pixels and on the image's position in the GLOBAL batch.
-    11 images, global batch 5 (so the last batch is short and rank 1's block of it has ONE image): the two-process job must write
-    byte-identical ECP JSON files to the one-process run, rank 1 writes nothing, every rank's engine option `device` is its
-    LOCAL_RANK, and the blocks / first_image values tile every global batch (inference_epistemic.py:56-83 + byolo/dist.py)."""
+    11 images, global batch 5 (so the last batch is short and rank 1's block of it is EMPTY): the two-process job must write
+    byte-identical ECP JSON files to the one-process run, every rank's engine option `device` is its LOCAL_RANK, and the
+    blocks / first_image values tile every global batch (inference_epistemic.py:56-83 + byolo/dist.py)."""
     import json
     _records(tmp_path, 11)
     rc1, o1 = _run_infer(1, tmp_path, str(tmp_path / "one" / "run"))
@@ -114,8 +164,38 @@ def test_inference_epistemic_world2_writes_the_single_process_json(tmp_path):
     assert c[0]["options"] == {"device": 0} and c[1]["options"] == {"device": 1}
     # (images in the block, first_image, seed) per global batch: 5 = 3 + 2, 5 = 3 + 2, 1 = 1 + 0 (rank 1 skips the call)
     assert c[0]["calls"] == [[3, 0, 4], [3, 0, 5], [1, 0, 6]] and c[1]["calls"] == [[2, 3, 4], [2, 3, 5]]
-    one = json.load(open(tmp_path / "calls_w1_r0.json"))["calls"]
-    assert one == [[5, 0, 4], [5, 0, 5], [1, 0, 6]]
+    # every rank wrote the files of ITS images, through the native formatter
+    assert [c[r]["stats"]["images"] for r in range(2)] == [7, 4] and all(c[r]["stats"]["native_json"] for r in range(2))
+    one = json.load(open(tmp_path / "calls_w1_r0.json"))
+    assert one["calls"] == [[5, 0, 4], [5, 0, 5], [1, 0, 6]] and one["stats"]["images"] == 11 and one["stats"]["batches"] == 3
+
+
+@pytest.mark.parametrize("raise_rank,raise_call", [(1, 1), (0, 2), (0, 3)])
+def test_inference_world2_ranks_switch_to_fp32_together(tmp_path, raise_rank, raise_call):
+    """BYOLO_ERR_RANGE on ONE rank (the stand-in raises its status words in one forward and returns garbage rows, as the device
+    does): the words travel in the batch's all-gather, so BOTH ranks switch to the fp32 mode at the same batch, re-run what was in
+    flight and write exactly the files of an undisturbed run -- no rank is left in another arithmetic, nothing hangs."""
+    import json
+    _records(tmp_path, 11)
+    rc1, o1 = _run_infer(1, tmp_path, str(tmp_path / "one" / "run"))
+    assert rc1 == [0], o1
+    rc2, o2 = _run_infer(2, tmp_path, str(tmp_path / "two" / "run"), extra=(raise_rank, raise_call))
+    assert rc2 == [0, 0], o2
+    a, b = str(tmp_path / "one" / "run_0"), str(tmp_path / "two" / "run_0")
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b))
+    for f in os.listdir(a):
+        assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+    c = [json.load(open(tmp_path / ("calls_w2_r%d.json" % r))) for r in range(2)]
+    for r in range(2):
+        assert c[r]["precision"] == "f32" and c[r]["stats"]["precision_switches"] == 1
+        assert c[r]["log"].count("precision:f32") == 1 and "finalize:f32" in c[r]["log"]
+    # both ranks re-ran from the SAME batch: the seeds of the repeated calls agree
+    redo = [[s for (_, _, s) in c[r]["calls"] if [x[2] for x in c[r]["calls"]].count(s) > 1] for r in range(2)]
+    assert redo[0] and min(redo[0]) == 3 + raise_call
+    if raise_call < 3:                                  # (rank 1's block of the third, short batch is empty: nothing to re-run)
+        assert redo[1] and min(redo[1]) == 3 + raise_call
+    else:
+        assert redo[1] == []
 
 
 def test_inference_world2_ranks_stop_together_when_the_output_directory_exists(tmp_path):

@@ -197,6 +197,83 @@ def test_inference_epistemic_as_a_torchrun_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_ranks_with_real_engines_write_the_single_process_json(tmp_path):
+    """The N > 1 path with TWO REAL engines (the driver's round-end box has one GPU, and RCCL refuses two ranks on one device:
+    both ranks run on cuda:0 and the one collective per batch is staged through host memory under gloo, byolo/dist.py
+    all_gather_flat): `inference_epistemic.inference` on 5 images, global batch 3 -- blocks of 2 + 1, then 1 + 1; each rank feeds,
+    runs and writes ITS images with the dropout masks of its position in the global batch -- must leave byte-identical JSON
+    files to the one-process run."""
+    import socket
+    import subprocess
+    import sys
+    import inference_epistemic as mod
+    imgs, names = _make_records(tmp_path, 5)
+    ck = tmp_path / "checkpoints" / "run"
+    ck.mkdir(parents=True)
+    np.savez(str(ck / "model-77.npz"), **golden_params("bayesian_yolov3_aleatoric"))
+    pattern = str(tmp_path / "ecp-day-val-*-of-*")
+    cfg = make_config("bayesian_yolov3_aleatoric", 64, 96, T=3, batch_size=3, checkpoint_path=str(tmp_path / "checkpoints"),
+                      run_id="run", step="last", seed=10, data={"file_pattern": pattern}, out_path=str(tmp_path / "plain" / "run"))
+    stats = mod.inference(cfg)
+    assert stats["images"] == 5 and stats["batches"] == 2 and stats["native_json"] and stats["precision_switches"] == 0
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BYOLO_DIST_BACKEND="gloo", BYOLO_DIST_SHARE_DEVICE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(here, "_inference_worker.py"), pattern, str(tmp_path / "checkpoints"),
+           str(tmp_path / "dist" / "run"), "3", str(tmp_path / "stats")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    a, b = str(tmp_path / "plain" / "run_77"), str(tmp_path / "dist" / "run_77")
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == sorted(n.replace(".png", ".json") for n in names)
+    for f in os.listdir(a):
+        assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+    st = [json.load(open(str(tmp_path / ("stats_rank%d.json" % r)))) for r in range(2)]
+    assert [x["images"] for x in st] == [3, 2] and all(x["device"] == 0 and x["native_json"] for x in st)
+
+
+@pytest.mark.gpu
+def test_normalize_u8_on_the_device_is_the_host_conversion():
+    """byolo_normalize_u8 == decode_img's `astype(float32) * float32(1 / 255)` bit for bit, every byte value, lengths that are
+    not a multiple of 4 included (`lib_yolo/dataset_utils.py:6-11`, tf.image.convert_image_dtype)."""
+    import torch
+    from conftest import build_model
+    _, m = build_model("yolov3", 64, 96)
+    rng = np.random.default_rng(0)
+    for n in (256, 4 * 1000 + 3, 64 * 96 * 3 * 2, 1):
+        u8 = np.concatenate([np.arange(256, dtype=np.uint8), rng.integers(0, 256, n, dtype=np.uint8)])[:max(n, 1)] if n >= 256 else rng.integers(0, 256, n, dtype=np.uint8)
+        got = m.engine.normalize_u8(torch.from_numpy(u8).cuda()).cpu().numpy()
+        want = u8.astype(np.float32) * np.float32(1.0 / 255.0)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), n
+
+
+@pytest.mark.gpu
+def test_inference_loop_switches_to_fp32_on_a_range_error(tmp_path, monkeypatch):
+    """A checkpoint whose activations leave the split-f16 range (BN gamma 3e4 in darknet53/conv_10): the pipelined driver loop
+    finds BYOLO_ERR_RANGE in the status words that come back with the FIRST batch's rows, switches to the fp32 mode, re-runs the
+    two batches in flight and carries on -- the files are those of a run that was in the fp32 mode from the start."""
+    import inference_epistemic as mod
+    imgs, names = _make_records(tmp_path, 5)
+    ck = tmp_path / "checkpoints" / "run"
+    ck.mkdir(parents=True)
+    p = {k: v.copy() for k, v in golden_params("bayesian_yolov3_aleatoric").items()}
+    p["darknet53/conv_10/batch_normalization/gamma"][:] = 3e4
+    np.savez(str(ck / "model-5.npz"), **p)
+    cfg = make_config("bayesian_yolov3_aleatoric", 64, 96, T=3, batch_size=2, checkpoint_path=str(tmp_path / "checkpoints"),
+                      run_id="run", step="last", seed=10, data={"file_pattern": str(tmp_path / "ecp-day-val-*-of-*")})
+    monkeypatch.setenv("BYOLO_PRECISION", "split")
+    s1 = mod.inference(dict(cfg, out_path=str(tmp_path / "split" / "run")))
+    assert s1["precision_switches"] == 1 and s1["precision"] == "f32" and s1["images"] == 5
+    monkeypatch.setenv("BYOLO_PRECISION", "f32")
+    s2 = mod.inference(dict(cfg, out_path=str(tmp_path / "f32" / "run")))
+    assert s2["precision_switches"] == 0 and s2["precision"] == "f32"
+    a, b = str(tmp_path / "split" / "run_5"), str(tmp_path / "f32" / "run_5")
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == sorted(n.replace(".png", ".json") for n in names)
+    for f in os.listdir(a):
+        assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+
+
+@pytest.mark.gpu
 def test_detect_do_it(tmp_path):
     import detect
     from lib_yolo import yolov3
