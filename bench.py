@@ -127,6 +127,87 @@ def parity_note(cfg, eng, x, oracle_rows, oracle_kept):
             "kept_set_symmetric_difference_vs_oracle_rows": int(len(set(kept.tolist()) ^ set(np.asarray(ok).tolist())))}
 
 
+def entry_point_leg(cfg, device, n_frames=512, distinct=32):
+    """The drop-in path a user of the reference runs: `inference_epistemic.inference(config)` (inference_epistemic.py:186-208) over
+    a TFRecord shard set generated here -- `distinct` synthetic frames (i.i.d. uniform, quantised to bytes) as PNG
+    records, repeated to n_frames with their own file names, two shards -- with the benchmark's batch, T and weights recipe.
+    Everything a user pays is inside: record framing + CRC-32C, PNG decode, H2D, the forward, the all-gather (N > 1), D2H,
+    ECP-JSON text, file writes.  `img_s` = frames / the driver loop's wall time (first record requested -> last file closed);
+    `wall_s` additionally holds building the engine, generating and calibrating the random weights.  `feed_img_s` /
+    `writer_img_s`: the feed and the writer ALONE on this host, same thread counts -- what bounds the loop when the device does not."""
+    import io
+    import shutil
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from byolo import synth, hostio
+    from byolo import inference as binf
+    from lib_yolo import dataset_utils as du, yolov3
+    import inference_epistemic
+    H, W, B, T = cfg["H"], cfg["W"], cfg["B"], cfg["T"]
+    tmp = tempfile.mkdtemp(prefix="byolo_entry_")
+    try:
+        t0 = time.perf_counter()
+        frames = (synth.synthetic_images(distinct, H, W, seed=1234) * 256.0).astype(np.uint8)
+        enc = []
+        for f in frames:
+            b = io.BytesIO()
+            Image.fromarray(f).save(b, format="PNG", compress_level=1)
+            enc.append(b.getvalue())
+        shards = [[], []]
+        for i in range(n_frames):
+            shards[i % 2].append(du.make_example({"image/encoded": enc[i % distinct], "image/filename": "frame_%05d.png" % i,
+                                                  "image/height": H, "image/width": W}))
+        for k, recs in enumerate(shards):
+            du.write_tfrecords(os.path.join(tmp, "ecp-day-val-%05d-of-00002" % k), recs)
+        t_gen = time.perf_counter() - t0
+        threads = max(1, min(24, (os.cpu_count() or 1) - 2))             # the reference's default cpu_thread_cnt is 24
+        config = {"checkpoint_path": tmp, "run_id": "bench", "step": "last", "weights": "synthetic", "full_img_size": [H, W, 3],
+                  "cls_cnt": 2, "batch_size": B, "T": T, "inference_mode": True, "cpu_thread_cnt": threads, "crop": False,
+                  "training": False, "aleatoric_loss": False, "priors": yolov3.ECP_9_PRIORS, "implicit_background_class": True,
+                  "engine_options": {"nms_mode": cfg["nms"], "device": device}, "seed": 1000, "writer_threads": 4,
+                  "data": {"file_pattern": os.path.join(tmp, "ecp-day-val-*-of-*")}, "out_path": os.path.join(tmp, "out", "bench")}
+        t0 = time.perf_counter()
+        stats = inference_epistemic.inference(config)
+        wall = time.perf_counter() - t0
+        out_dir = os.path.join(tmp, "out", "bench_0")
+        files = sorted(os.listdir(out_dir))
+        assert len(files) == n_frames, "the entry point wrote %d files for %d frames" % (len(files), n_frames)
+        sample = json.load(open(os.path.join(out_dir, files[0])))["children"]
+        json_bytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in files)
+        # the feed alone (decode pool + prefetch, frames dropped), then the writer alone (the rows of one written file, n_frames times)
+        t0 = time.perf_counter()
+        n = 0
+        for sh in du.TestingDataset(config).iter_shards_u8(0, 1):
+            n += len(sh.names)
+            sh.release()
+        feed_s = time.perf_counter() - t0
+        from concurrent.futures import ThreadPoolExecutor
+        D = 23
+        rows = np.random.default_rng(0).random((max(1, len(sample)), D), dtype=np.float32)
+        fmt = hostio.EcpJsonFormatter("bayesian_yolov3_aleatoric", [H, W, 3], 2, 14, 17, True, binf.LABEL_TO_CLS_NAME)
+        wdir = os.path.join(tmp, "w")
+        os.makedirs(wdir)
+
+        def one(i):
+            with open(os.path.join(wdir, "%05d.json" % i), "wb") as f:
+                f.write(fmt.format(rows))
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            list(pool.map(one, range(n_frames)))
+        writer_s = time.perf_counter() - t0
+        return {"img_s": n_frames / stats["loop_s"], "unit": "img/s", "frames": n_frames, "batch_size": B, "T": T,
+                "entry": "inference_epistemic.inference(config) -- TFRecord shards -> PNG decode -> device -> ECP JSON files",
+                "loop_s": stats["loop_s"], "wall_s": wall, "setup_s": wall - stats["loop_s"], "records_generated_in_s": t_gen,
+                "feed_img_s": n / feed_s, "writer_img_s": n_frames / writer_s, "cores": os.cpu_count(), "decode_threads": threads,
+                "writer_threads": 4, "prefetch_batches": 2, "batches_in_flight": 2,
+                "host_waited_s": {"feed": stats["wait_feed_s"], "device": stats["wait_device_s"], "writer": stats["wait_writer_s"]},
+                "boxes_per_image": len(sample), "json_mb_written": json_bytes / 1e6, "png_mb_read": sum(len(e) for e in enc) / distinct * n_frames / 1e6,
+                "native_json": stats["native_json"], "precision": stats["precision"], "precision_switches": stats["precision_switches"]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def time_steps(eng, x, cfg, steps, warmup, first_image=0):
     """warmup + `steps` forwards of the batch on the current stream with per-launch hipEvents; returns (seconds, {variant: [useful
     flops, ms, launches]}).  Used for the fp32_mode leg."""
@@ -178,6 +259,8 @@ def main():
                     help="alternate whole steps over this many HIP streams (own workspace and output buffers each): the latency-bound "
                          "tail of step i (decode, sort, NMS) overlaps the convolutions of step i+1.  1 = one stream")
     ap.add_argument("--fp32-steps", type=int, default=5, help="timed steps of the fp32_mode leg (0 = skip it)")
+    ap.add_argument("--entry-frames", type=int, default=512,
+                    help="frames of the entry_point leg (inference_epistemic.inference over generated TFRecord shards); 0 = skip it")
     ap.add_argument("--no-dropout", action="store_true",
                     help="[experiment, not the metric] skip the dropout masks: isolates the epilogue's RNG cost")
     ap.add_argument("--dump-steps", default=None, help="write the per-launch table (layer, variant, M, N, K, ms, TF/s) here")
@@ -464,6 +547,12 @@ def main():
                 del m32
             except Exception as e:
                 line["fp32_mode"] = {"value": None, "error": repr(e)}
+        if world == 1 and args.entry_frames > 0 and not args.batch and args.scaling == "weak":
+            try:
+                line["entry_point"] = entry_point_leg(cfg, device, n_frames=args.entry_frames)
+                line["entry_point"]["vs_value"] = line["entry_point"]["img_s"] / line["value"]
+            except Exception as e:
+                line["entry_point"] = {"img_s": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"], o_rows, o_kept = cpu_baseline(cfg, eng.get_params())
