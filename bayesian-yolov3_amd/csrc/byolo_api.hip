@@ -983,6 +983,17 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
         // byte streamed for the HBM-latency-bound 76x76 head layers (measured at config 4: 0.83 -> 0.56, 0.77 -> 0.67 ms)
         if (h->precision == 1) tile = conv_split_tile(tile, s.kx3 || s.p1);
         else if (inject && tile == TILE_128x128) tile = TILE_128x64;      // the fp32 128-wide build has no mask-injection path (conv_igemm.hip)
+        // shared-tap 3x3 with cout % 256 == 0 and enough rows to fill the chip: ONE 8-wave workgroup owns all 256 output channels of
+        // its 128 pixels, so an activation row is fetched and staged once per 256 columns instead of once per 128.  Measured at
+        // config 4 (round 4, gpurun_out/r4b_*): the three 76x76 head convolutions 2.13 -> 2.22 ms each (-4 %): with ONE workgroup per
+        // CU the epilogues of all eight waves coincide and nothing multiplies meanwhile, where two independent 4-wave workgroups
+        // overlap one's epilogue with the other's K loop -- so it is NOT the default.
+        // BYOLO_KX3_WIDE: 0 never (default), 1 launches of >= 4 rounds of 256 workgroups, 2 every eligible launch (tests)
+        const char* kwe = getenv("BYOLO_KX3_WIDE");           // (read per plan, like BYOLO_WINO_SPLIT: tests and fuzzers flip it inside one process)
+        const int kx3_wide = kwe ? atoi(kwe) : 0;
+        if (h->precision == 1 && s.kx3 && tile == TILE_128x128 && (s.Npad % 256) == 0 && kx3_wide &&
+            (kx3_wide >= 2 || (int64_t)((M + 127) / 128) * (s.Npad / 256) >= 4 * 256))
+            tile = TILE_128x256;
         p.tile[si] = tile;
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
         const bool sp = h->precision == 1, kx3 = sp && s.kx3;
@@ -1154,8 +1165,12 @@ static int32_t check_run(byolo_t* h, int32_t B, int32_t T, const char* what, boo
 extern "C" int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t* out) {
     int32_t rc = check_run(h, B, T, "byolo_workspace_bytes", false); if (rc) return rc;
     if (!out) return fail(h, BYOLO_ERR_ARG, "byolo_workspace_bytes: null out");
-    make_plan(h, B, T);
-    *out = h->plan.total;
+    // the plan of a call with injected dropout masks (byolo_forward's d_mask_bits) differs in the fp32 mode (64-wide tiles, other
+    // split-K slabs, no Winograd): the size returned covers BOTH, so a workspace sized here never fails either kind of call
+    make_plan(h, B, T, true);
+    const size_t with_masks = h->plan.total;
+    make_plan(h, B, T, false);
+    *out = std::max(h->plan.total, with_masks);
     return BYOLO_OK;
 }
 
@@ -1403,6 +1418,7 @@ extern "C" int32_t byolo_num_dropout(const byolo_t* h) { return h ? h->n_dropout
 
 extern "C" int32_t byolo_mask_layout(byolo_t* h, int32_t B, int32_t T, int32_t ordinal, int64_t* bit_offset, int64_t* elements) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_mask_layout: null handle");
+    if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }          // (layer shapes / dropout ordinals exist after lowering)
     if (B < 1 || T < 1 || ordinal < 0 || ordinal > h->n_dropout) return fail(h, BYOLO_ERR_ARG, "byolo_mask_layout: bad argument");
     int64_t n = 0;
     const int64_t off = mask_layout(h, B, T, ordinal, &n);

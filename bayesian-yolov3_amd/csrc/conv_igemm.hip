@@ -724,7 +724,7 @@ __device__ __forceinline__ void conv_tile_p1(const ConvParams& p, float* smem, c
 // also fit the register file, i.e. VGPRs + AGPRs <= 256 per wave.
 // KX3: 0 the (tap, chunk) loop of conv_tile, 1 shared-tap 3x3 stages (conv_tile_kx3), 2 the 1x1 loop (conv_tile_p1)
 template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT, int KX3 = 0>
-__global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const ConvParams p) {      // two waves per SIMD: <= 256 registers
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // One loop, one inlined conv_tile: the work items of this workgroup are either
     //  (stream-K, p.sk_grid > 0) the tiles its share of the launch's tiles * KT units overlaps.  Workgroup order =
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2 * WM * WN / 4) void conv_igemm_kern
     }
 }
 
-int conv_tile_bn(int tile) { return tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32); }
+int conv_tile_bn(int tile) { return tile == TILE_128x256 ? 256 : (tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32)); }
 
 // split precision: the tile configuration a launch really runs on
 int conv_split_tile(int tile, bool wide) { return (tile == TILE_128x128 && !wide) ? TILE_128x64 : tile; }
@@ -803,7 +803,7 @@ static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
 
 // workgroups of a tile configuration resident on the chip: LDS-limited (160 KB per CU; 73.7 / 55.3 / 46.1 KB per
 // workgroup), the register bound of __launch_bounds__ allows at least as many
-static int tile_slots(int tile) { return 256 * (tile == TILE_128x32 ? 3 : 2); }
+static int tile_slots(int tile) { return 256 * (tile == TILE_128x256 ? 1 : (tile == TILE_128x32 ? 3 : 2)); }      // (the 8-wave tile: one workgroup per CU)
 
 // Tile quantisation: a launch of `tiles` equal tiles on `slots` resident workgroups takes ceil(tiles/slots)
 // rounds although the last one may be nearly empty (5416 tiles on 512 slots: 10.58 -> 11 rounds, 3.8 % of
@@ -895,9 +895,11 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
                 if (!fast || p.ksize != 3 || p.stride != 1) return hipErrorInvalidValue;
                 return launch_one<BM, BN, WM, WN, true, true, 1>(q, grid, st);
             }
-            if (p.kx3 == 2) {
-                if (p.C1 != 0 || p.ksize != 1 || p.stride != 1) return hipErrorInvalidValue;
-                return launch_one<BM, BN, WM, WN, true, true, 2>(q, grid, st);
+            if constexpr (BN <= 128) {
+                if (p.kx3 == 2) {
+                    if (p.C1 != 0 || p.ksize != 1 || p.stride != 1) return hipErrorInvalidValue;
+                    return launch_one<BM, BN, WM, WN, true, true, 2>(q, grid, st);
+                }
             }
         }
         // (the plain split kernel is not built for the 128-wide tile: it needs more than 256 registers there, and this
@@ -912,6 +914,9 @@ hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st) {
     if (p.split) {      // split-f16: the waves sit side by side along N (each fetches its own weight fragments, mfma_pipe.h)
         // (a 2 x 2 wave grid -- half the LDS fragment reads, every weight fragment fetched twice -- measured the same: 18.4 ms)
         switch (tile) {
+            case TILE_128x256:                                                     // 8 waves of 128x32: the shared-tap 3x3 kernel only
+                if (p.kx3 != 1) return hipErrorInvalidValue;
+                return launch_cfg<128, 256, 1, 8, true>(p, st);
             case TILE_128x128: return launch_cfg<128, 128, 1, 4, true>(p, st);    // 4 waves of 128x32
             case TILE_128x64:  return launch_cfg<128, 64, 2, 2, true>(p, st);     // 4 waves of 64x32
             default:           return launch_cfg<128, 32, 4, 1, true>(p, st);     // 4 waves of 32x32

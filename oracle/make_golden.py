@@ -96,8 +96,8 @@ def import_reference():
     return ryolo, rutils, repi, rale, rstd, rdetect
 
 
-def ref_config(ryolo, variant, T=T_EPI):
-    return {"full_img_size": [H, W, 3], "crop": False, "cls_cnt": 2, "priors": ryolo.ECP_9_PRIORS,
+def ref_config(ryolo, variant, T=T_EPI, hw=None):
+    return {"full_img_size": [hw[0] if hw else H, hw[1] if hw else W, 3], "crop": False, "cls_cnt": 2, "priors": ryolo.ECP_9_PRIORS,
             "aleatoric_loss": False, "inference_mode": True, "T": T, "implicit_background_class": True}
 
 
@@ -121,14 +121,14 @@ def params_for(variant, stats):
     return p
 
 
-def run_reference(variant, params, imgs, dtype, seed=SEED_DROP, sample_offset=0, T=T_EPI, masks=None):
+def run_reference(variant, params, imgs, dtype, seed=SEED_DROP, sample_offset=0, T=T_EPI, masks=None, taps=(0, 1, 4, 36, 61, 74)):
     """Execute the reference's model class + concat_bbox + nms under the shim.  `masks`: keep-masks handed to the
     reference's tf.layers.dropout calls in call order (instead of the build-defined stream)."""
     shim.install(dtype=dtype, param_provider=lambda name, shape: params[name], seed=seed,
                  sample_offset=sample_offset, masks=masks)
     ryolo, rutils, repi, rale, rstd, rdetect = import_reference()
     cls = getattr(ryolo, variant)
-    yolo = cls(ref_config(ryolo, variant, T))
+    yolo = cls(ref_config(ryolo, variant, T, hw=imgs.shape[1:3]))
     x = shim.input_tensor(imgs)
     model = yolo.init_model(inputs=x, training=False).get_model()
     mod = {"yolov3": rstd, "yolov3_aleatoric": rale, "bayesian_yolov3_aleatoric": repi}[variant]
@@ -145,7 +145,7 @@ def run_reference(variant, params, imgs, dtype, seed=SEED_DROP, sample_offset=0,
         "var_names": [v[:-2] for v in shim.STATE.variables],
         "layer_names": [l.name for l in model.layers],
         "obj_idx": model.obj_idx, "cls_start_idx": model.cls_start_idx,
-        "layers": {i: model.layers[i].numpy() for i in (0, 1, 4, 36, 61, 74)},
+        "layers": {i: model.layers[i].numpy() for i in taps},
         "raw": [dl.raw_output.numpy() for dl in model.det_layers],
         "bbox": bbox.numpy(), "nms_rows": kept,
         "dropout_calls": list(shim.STATE.dropout_calls),
@@ -308,11 +308,39 @@ def gen_vis():
     np.savez_compressed(os.path.join(OUT, "vis_maps.npz"), **out)
 
 
+def gen_default_frame():
+    """The reference at ITS OWN default workload (inference_epistemic.py:212-240: the full 1024 x 1920 ECP frame, T = 50, one
+    image, class-agnostic NMS :99-102): the reference's model class, concat_bbox and nms executed under the shim on one synthetic
+    frame with the golden weights.  Stored: every 16th pre-NMS row (7560 x 23), the kept rows, and the kept rows' positions in
+    the box list -- 0.8 MB instead of 11 MB.  Takes a few minutes and ~20 GB on the build container's 8 cores."""
+    import time
+    stats = {k: v for k, v in np.load(os.path.join(OUT, "bn_stats.npz")).items()}
+    variant = "bayesian_yolov3_aleatoric"
+    params = params_for(variant, stats)
+    HD, WD, TD = 1024, 1920, 50
+    img = synth.synthetic_images(1, HD, WD, seed=1234)
+    t0 = time.time()
+    with torch.no_grad():
+        r = run_reference(variant, params, img, torch.float32, T=TD, taps=())
+    bbox, kept_rows = r["bbox"].astype(np.float32), r["nms_rows"][0].astype(np.float32)
+    assert bbox.shape == (3 * (32 * 60 + 64 * 120 + 128 * 240), 23), bbox.shape
+    # positions of the kept rows in the box list (tf.gather of the indices: every kept row is a row of bbox, bit for bit)
+    key = {row.tobytes(): i for i, row in enumerate(bbox)}
+    kept_idx = np.array([key[row.tobytes()] for row in kept_rows], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "fwd_default_frame.npz"), rows_every_16th=bbox[::16], kept_rows=kept_rows, kept_idx=kept_idx,
+                        meta=np.array([HD, WD, TD, SEED_W, SEED_DROP, 1234, 16], dtype=np.int32))
+    print("default frame: bbox", bbox.shape, "kept", kept_rows.shape, "%.0f s" % (time.time() - t0),
+          os.path.getsize(os.path.join(OUT, "fwd_default_frame.npz")), "bytes")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     if len(sys.argv) > 1 and sys.argv[1] == "vis":      # regenerate only this fixture
         gen_vis()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "default_frame":
+        gen_default_frame()
         return
     shim.install(dtype=torch.float32)
     mods = import_reference()

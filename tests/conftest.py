@@ -128,11 +128,33 @@ def assert_rows_close_vs_oracle(got, params, imgs, variant, what, T=1, seed=0, c
     floor = rows_report(ref32.numpy(), ref64.numpy(), variant, cls_cnt)
     rep = assert_rows_close(got, ref64.numpy(), variant, what + " vs the float64 oracle", C=cls_cnt, floor=floor)
     loose = rows_report(got, ref32.numpy(), variant, cls_cnt)
+    record_parity(what + " vs the float32 oracle", loose)
+    record_parity(what + ": float32 oracle vs float64 oracle (the floor)", floor)
     bad = {k: v for k, v in loose.items() if v["worst_in_bounds"] > VS_FLOAT32_BOUNDS.get(k, 1.0)}
     assert not bad, "%s vs the float32 oracle, beyond %s: %s" % (what, {k: VS_FLOAT32_BOUNDS.get(k, 1.0) for k in bad}, format_report(bad))
     print("%s: device vs float64 %s | device vs float32 %s | float32 oracle vs float64 %s"
           % (what, format_report(rep), format_report(loose), format_report(floor)))
     return rep
+
+
+def record_parity(what, rep, kind="rows"):
+    """Every per-group distance a GPU test computes goes into ONE json file instead of `pytest -q`'s swallowed stdout:
+    gpurun_out/parity_table.json (BYOLO_PARITY_TABLE overrides; gpurun merges that directory back, the builder copies the table to
+    profiles/rN_parity_table.json).  {comparison: {column group: {worst_in_bounds, max_abs_err, max_ref}}}, in units of the bound
+    1e-4 * max(1, |ref|); the precision in effect (BYOLO_PRECISION) is part of the key."""
+    import json
+    path = os.environ.get("BYOLO_PARITY_TABLE") or os.path.join(REPO, "gpurun_out", "parity_table.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        table = json.load(open(path)) if os.path.exists(path) else {}
+        key = "%s [%s]" % (what, os.environ.get("BYOLO_PRECISION", "default"))
+        table[key] = {k: {"worst_in_bounds": round(v["worst_in_bounds"], 4), "max_abs_err": float("%.3g" % v["max_abs_err"]),
+                          "max_ref": float("%.4g" % v["max_ref"])} for k, v in rep.items()}
+        with open(path + ".tmp", "w") as f:
+            json.dump(table, f, indent=1, sort_keys=True)
+        os.replace(path + ".tmp", path)
+    except OSError:
+        pass                                    # a read-only tree must not fail a parity test
 
 
 def assert_rows_close(got, ref, variant, what, C=2, floor=None):
@@ -147,6 +169,7 @@ def assert_rows_close(got, ref, variant, what, C=2, floor=None):
     assert np.array_equal(np.isnan(got), np.isnan(ref)), "%s: NaN pattern differs" % what
     assert np.array_equal(np.isinf(got), np.isinf(ref)) and np.array_equal(got[np.isinf(ref)], ref[np.isinf(ref)]), "%s: inf pattern" % what
     rep = rows_report(got, ref, variant, C)
+    record_parity(what, rep)
     if "ids" in rep:
         assert rep["ids"]["max_abs_err"] == 0.0, "%s: layer / prior ids differ" % what
     allowed = {k: max(1.0, 1.1 * floor[k]["worst_in_bounds"]) if floor else 1.0 for k in rep}

@@ -18,7 +18,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_rows_close, format_report, rows_report
+from conftest import assert_rows_close, format_report, rows_report, record_parity
 from test_gpu_parity import _check_nms_against_oracle
 
 pytestmark = pytest.mark.gpu
@@ -140,10 +140,12 @@ def test_config2_as_benched():
     assert boxes.shape == (8, 10647, 16)
     floor = rows_report(ref32.numpy(), ref64.numpy(), cfg["variant"])
     print("config 2, float32 CPU restatement vs float64:", format_report(floor))
+    record_parity("config 2 (416x416 aleatoric B=8): float32 oracle vs float64 oracle (the floor)", floor)
     rep = assert_rows_close(boxes, ref64.numpy(), cfg["variant"], "config 2 (416x416 aleatoric B=8) vs float64 oracle", floor=floor)
     print("config 2, device vs float64:", format_report(rep))
     vs32 = rows_report(boxes, ref32.numpy(), cfg["variant"])
     print("config 2, device vs float32:", format_report(vs32))
+    record_parity("config 2 (416x416 aleatoric B=8) vs the float32 oracle", vs32)
     from conftest import VS_FLOAT32_BOUNDS                            # single-pass exp(logvar): two float32 evaluations differ by > 1 bound
     assert all(v["worst_in_bounds"] <= max(VS_FLOAT32_BOUNDS.get(k, 1.0), 1.1 * floor[k]["worst_in_bounds"]) for k, v in vs32.items()), format_report(vs32)
     assert all(v["worst_in_bounds"] <= 1.0 for k, v in rep.items() if "(exp)" not in k)      # literal everywhere else

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import (REPO, RTOL, ATOL, golden, golden_params, golden_images, build_model, assert_close,
+from conftest import (REPO, RTOL, ATOL, golden, golden_params, golden_images, build_model, assert_close, format_report,
                       assert_rows_close_vs_oracle)
 
 pytestmark = pytest.mark.gpu
@@ -504,6 +504,33 @@ def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, bn, m
     assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
 
 
+def test_the_eight_wave_shared_tap_tile_computes_the_same_bits(monkeypatch, precision):
+    """BYOLO_KX3_WIDE=2: every shared-tap 3x3 convolution with cout % 256 == 0 on the 128 x 256 tile (8 waves, one workgroup owns
+    all 256 output channels of its pixels; conv_igemm_kernel<128,256,1,8,kx3>) -- not the default (measured 4 % slower at config 4,
+    byolo_api.hip make_plan), kept as the starting point of a back-to-back fusion.  An output element is the same chain of MFMAs over
+    the same K order whichever wave owns it: the rows must equal the default plan's bit for bit (no split-K at this size)."""
+    if precision != "split":
+        pytest.skip("the shared-tap kernel belongs to the default precision")
+    monkeypatch.setenv("BYOLO_WINO_SPLIT", "0")            # the eligible layers would otherwise be Winograd
+    monkeypatch.setenv("BYOLO_KSPLIT", "0")
+    monkeypatch.setenv("BYOLO_STREAMK", "0")
+    v = "bayesian_yolov3_aleatoric"
+    monkeypatch.setenv("BYOLO_KX3_WIDE", "0")
+    _, base, _, _ = _run(v, 1, keep_all=False)
+    monkeypatch.setenv("BYOLO_KX3_WIDE", "2")
+    m, wide, _, imgs = _run(v, 1, keep_all=False)
+    m.engine.set_profiling(2)
+    torch = _torch()
+    m.run(torch.from_numpy(imgs).cuda(), seed=42)
+    torch.cuda.synchronize()
+    var = [s["variant"] for s in m.engine.step_profile()]
+    m.engine.set_profiling(0)
+    assert var.count(3256) >= 10, "the 8-wave tile did not run: %s" % var
+    a, b = wide["boxes"].cpu().numpy(), base["boxes"].cpu().numpy()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(wide["kept"].cpu().numpy(), base["kept"].cpu().numpy())
+
+
 def test_first_image_makes_shards_equal_the_whole_batch():
     """byolo_set_first_image: image j of a shard / sub-batch draws the dropout masks of image first_image + j of the
     logical batch, so pieces equal the unsplit run (fp32 re-association aside: tile and split-K choices depend on
@@ -522,16 +549,42 @@ def test_first_image_makes_shards_equal_the_whole_batch():
     assert m.engine.max_images(m.T) > 1000            # 64x96: far from the 3 GiB bound
 
 
-def test_sources_beyond_2GiB(monkeypatch):
-    """The convolution addresses its sources with 32-bit buffer offsets.  At 608x608, T=30 and 12 images the
-    76x76x256 activation spans 2.13 GB (offsets with the top bit set): every image of the batch must equal
-    its own batch-1 run (dropout off, so that rows do not depend on the batch position)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("check_big_batch", os.path.join(REPO, "tools", "check_big_batch.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    monkeypatch.setattr(sys, "argv", ["check_big_batch.py", "12"])
-    mod.main()
+def test_a_batch_beyond_max_images_runs_as_sub_batches():
+    """The convolutions address their sources with 32-bit buffer offsets, so one byolo_forward call takes at most
+    byolo_max_images(T) images (17 at 608x608, T=30: the stacked 76x76x256 activation must stay below 3 GiB) and Engine.forward
+    runs a larger batch as consecutive sub-batches with `first_image` = their position -- the path a strong-scaling run on ONE GPU
+    (global batch 64) takes.  20 images, dropout ON: the first sub-batch (17 images: offsets with the top bit set) and the second
+    (3) must produce what ONE logical batch produces: images 17 (first of the second call) and 19 (last) against the CPU oracle
+    with the dropout stream of their position (sample_offset = i * T), images 0 and 16 against their own one-image calls at that
+    position, and the tail of all 20 bit-exact against the oracle's NMS on the device's rows."""
+    torch = _torch()
+    from byolo import synth
+    from oracle import cpu_ref
+    from conftest import assert_rows_close
+    v, B, T = "bayesian_yolov3_aleatoric", 20, 30
+    m = build_model(v, 608, 608, T=T)[1]
+    eng = m.engine
+    eng.set_params(synth.base_params(eng.param_shapes(), v, 2, seed=7))
+    eng.finalize()
+    imgs = synth.synthetic_images(B, 608, 608, seed=1234)
+    x = torch.from_numpy(imgs).cuda()
+    eng.calibrate_bn(x[:2])
+    cap = eng.max_images(T)
+    assert 1 <= cap < B, "the batch must exceed one call's capacity (%d) for this test to mean anything" % cap
+    out = eng.forward(x, T=T, seed=42, want_boxes=True, want_nms=True)
+    torch.cuda.synchronize()
+    boxes = out["boxes"].cpu().numpy()
+    assert boxes.shape[0] == B
+    for i in (0, cap - 1):                       # device vs device: the same image alone, at its position in the logical batch
+        one = eng.forward(x[i:i + 1], T=T, seed=42, want_boxes=True, first_image=i)["boxes"].cpu().numpy()[0]
+        assert_rows_close(boxes[i], one, v, "608x608 T=30 B=20, image %d of the sub-batched call vs its one-image call" % i)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    tp = cpu_ref.to_torch_params(eng.get_params())
+    with torch.no_grad():
+        for i in (cap, B - 1):
+            ref, _ = cpu_ref.detect_boxes(tp, imgs[i:i + 1], v, T=T, seed=42, sample_offset=i * T)
+            assert_rows_close(boxes[i], ref.numpy()[0], v, "608x608 T=30 B=20 (sub-batches of %d), image %d vs the float32 oracle" % (cap, i))
+    _check_nms_against_oracle(boxes, out, v)
 
 
 def test_full_size_vs_cpu_restatement():
@@ -557,6 +610,40 @@ def test_full_size_vs_cpu_restatement():
     err = assert_close(boxes, ref.numpy(), "608x608 T=30 pre-NMS rows")
     print("608x608 T=30: max |err| = %.3e over %d values" % (err, boxes.size))
     _check_nms_against_oracle(boxes, out, v)
+
+
+def test_reference_default_workload_vs_the_reference_run():
+    """The reference's OWN default workload -- inference_epistemic.py:212-240: the full 1024 x 1920 ECP frame, T = 50, one image,
+    class-agnostic NMS -- against tests/golden/fwd_default_frame.npz: the reference's model class, concat_bbox and nms executed in
+    the build container (oracle/make_golden.py default_frame, under the shim) on the golden weights.  Every 16th of the 120 960
+    pre-NMS rows at the literal bound 1e-4 * max(1, |ref|); the tail bit-exact against the oracle's NMS on the device's rows; and
+    the kept LIST against the reference's: the same boxes, up to visiting-order flips between near-tied scores."""
+    torch = _torch()
+    from byolo import synth
+    from conftest import assert_rows_close
+    g = golden("fwd_default_frame.npz")
+    HD, WD, TD, seed_w, seed_drop, img_seed, every = [int(v) for v in g["meta"]]
+    v = "bayesian_yolov3_aleatoric"
+    m = build_model(v, HD, WD, T=TD, params=golden_params(v))[1]
+    m.finalize()
+    x = torch.from_numpy(synth.synthetic_images(1, HD, WD, seed=img_seed)).cuda()
+    out = m.engine.forward(x, T=TD, seed=seed_drop, want_boxes=True, want_nms=True)
+    torch.cuda.synchronize()
+    boxes = out["boxes"].cpu().numpy()
+    assert boxes.shape == (1, 3 * (32 * 60 + 64 * 120 + 128 * 240), 23)
+    rep = assert_rows_close(boxes[0, ::every], g["rows_every_16th"], v, "reference default workload (1024x1920 T=50), every 16th row vs the reference run")
+    print("default workload:", format_report(rep))
+    _check_nms_against_oracle(boxes, out, v)
+    n = int(out["count"][0, 0])
+    kept = out["kept"][0, :n].cpu().numpy()
+    ref_kept = g["kept_idx"]
+    diff = set(kept.tolist()) ^ set(ref_kept.tolist())
+    print("default workload: kept %d, reference kept %d, symmetric difference %d" % (n, len(ref_kept), len(diff)))
+    assert abs(n - len(ref_kept)) <= 0.02 * len(ref_kept) + 2 and len(diff) <= 0.05 * len(ref_kept) + 4
+    # rows the two lists share are the same rows within the bound
+    common = sorted(set(kept.tolist()) & set(ref_kept.tolist()))
+    pos = {int(k): i for i, k in enumerate(ref_kept)}
+    assert_rows_close(boxes[0, common], g["kept_rows"][[pos[k] for k in common]], v, "reference default workload, kept rows vs the reference's kept rows")
 
 
 def test_reference_default_frame_vs_cpu_restatement():

@@ -31,7 +31,9 @@ def one_case(rng, idx, max_cells=5):
     H, W = int(rng.integers(1, max_cells + 1)) * 32, int(rng.integers(1, max_cells + 1)) * 32
     B, T = int(rng.integers(1, 4)), int(rng.integers(1, 5))
     prob = float(rng.choice([0.1, 0.25, 0.5]))
-    for k in ("BYOLO_WINOGRAD", "BYOLO_WINO_FUSED", "BYOLO_KSPLIT", "BYOLO_STREAMK", "BYOLO_STREAM1X1"):
+    # (BYOLO_WINO_SPLIT / BYOLO_KX3_WIDE: the split-precision plans -- Winograd in split arithmetic and the 8-wave shared-tap
+    #  tile -- forced on every eligible layer or off; they are read when a handle plans a (B, T))
+    for k in ("BYOLO_WINOGRAD", "BYOLO_WINO_FUSED", "BYOLO_KSPLIT", "BYOLO_STREAMK", "BYOLO_STREAM1X1", "BYOLO_WINO_SPLIT", "BYOLO_KX3_WIDE"):
         v = str(rng.choice(["", "", "0", "2"] if k != "BYOLO_KSPLIT" else ["", "", "0", "2", "3"]))
         if v:
             os.environ[k] = v
