@@ -157,6 +157,8 @@ struct byolo {
     unsigned* d_status = nullptr; unsigned* h_status = nullptr;
     bool async_status = false;     // byolo_set_async: byolo_forward does not wait for the status words
     bool plan_inject = false;      // the current plan was made for injected dropout masks (fp32 mode: conv_igemm launches only)
+    int plan_epoch = 0;            // bumped whenever the plan is invalidated (precision, finalize)
+    int wsm_B = -1, wsm_T = -1, wsm_epoch = -1; size_t wsm_total = 0;     // byolo_workspace_bytes: size of the masked-call plan of (B, T)
     // Forwards of ONE handle alternating over several streams (a caller pipelining whole steps: bench.py --pipeline): the
     // convolution stacks run one after the other -- two of them sharing the chip gain nothing and blur every per-launch timing
     // -- while a step's latency-bound tail (decode, sort, NMS) overlaps the next step's convolutions.  ev_convs is recorded
@@ -237,7 +239,7 @@ extern "C" int32_t byolo_set_precision(byolo_t* h, int32_t precision) {
     if (precision != BYOLO_PREC_F32 && precision != BYOLO_PREC_SPLIT_F16) return fail(h, BYOLO_ERR_ARG, "byolo_set_precision: unknown precision %d", precision);
     h->prec_requested = precision;
     if (precision == BYOLO_PREC_F32) h->prec_note.clear();          // asked for, not fallen back to
-    if (precision != h->precision) { h->precision = precision; h->prec_note.clear(); h->finalized = false; h->plan.B = -1; h->plan.T = -1; }
+    if (precision != h->precision) { h->precision = precision; h->prec_note.clear(); h->finalized = false; h->plan.B = -1; h->plan.T = -1; ++h->plan_epoch; }
     return BYOLO_OK;
 }
 extern "C" int32_t byolo_get_precision(const byolo_t* h) { return h ? h->precision : BYOLO_ERR_ARG; }
@@ -697,7 +699,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
             if (l.op == OP_CONV && (l.filters % 4)) {
                 char buf[256];
                 snprintf(buf, sizeof buf, "fp32 mode: split-f16 storage needs output channels in groups of 4, layer '%s' has %d", l.scope.c_str(), l.filters);
-                h->prec_note = buf; h->precision = 0; h->plan.B = -1; h->plan.T = -1;
+                h->prec_note = buf; h->precision = 0; h->plan.B = -1; h->plan.T = -1; ++h->plan_epoch;
                 static const bool quiet = [] { const char* e = getenv("BYOLO_QUIET"); return e && atoi(e); }();
                 if (!quiet) fprintf(stderr, "byolo: %s\n", buf);
                 break;
@@ -885,7 +887,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         HIPCHK(h, hipMemset(h->d_zeros, 0, sizeof(float) * maxC));
     }
     h->finalized = true;
-    h->plan.B = -1; h->plan.T = -1;                             // kernel choices depend on what was packed: plan again
+    h->plan.B = -1; h->plan.T = -1; ++h->plan_epoch;            // kernel choices depend on what was packed: plan again
     return BYOLO_OK;
 }
 
@@ -991,8 +993,9 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
         // BYOLO_KX3_WIDE: 0 never (default), 1 launches of >= 4 rounds of 256 workgroups, 2 every eligible launch (tests)
         const char* kwe = getenv("BYOLO_KX3_WIDE");           // (read per plan, like BYOLO_WINO_SPLIT: tests and fuzzers flip it inside one process)
         const int kx3_wide = kwe ? atoi(kwe) : 0;
-        if (h->precision == 1 && s.kx3 && tile == TILE_128x128 && (s.Npad % 256) == 0 && kx3_wide &&
-            (kx3_wide >= 2 || (int64_t)((M + 127) / 128) * (s.Npad / 256) >= 4 * 256))
+        if (h->precision == 1 && s.kx3 && (s.Npad % 256) == 0 && kx3_wide && (l.filters % 128) == 0 &&
+            (kx3_wide >= 2 ? (tile == TILE_128x128 || tile == TILE_128x64)       // (forced: also where the grid-fill rule above went narrow)
+                           : (tile == TILE_128x128 && (int64_t)((M + 127) / 128) * (s.Npad / 256) >= 4 * 256)))
             tile = TILE_128x256;
         p.tile[si] = tile;
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
@@ -1167,10 +1170,16 @@ extern "C" int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_
     if (!out) return fail(h, BYOLO_ERR_ARG, "byolo_workspace_bytes: null out");
     // the plan of a call with injected dropout masks (byolo_forward's d_mask_bits) differs in the fp32 mode (64-wide tiles, other
     // split-K slabs, no Winograd): the size returned covers BOTH, so a workspace sized here never fails either kind of call
-    make_plan(h, B, T, true);
-    const size_t with_masks = h->plan.total;
+    // (the plan in effect stays the unmasked one, made ONCE per (B, T): a caller asks for the size before every forward)
     make_plan(h, B, T, false);
-    *out = std::max(h->plan.total, with_masks);
+    if (h->wsm_B != B || h->wsm_T != T || h->wsm_epoch != h->plan_epoch) {
+        const Plan keep = h->plan;
+        h->plan.B = -1;
+        make_plan(h, B, T, true);
+        h->wsm_total = h->plan.total; h->wsm_B = B; h->wsm_T = T; h->wsm_epoch = h->plan_epoch;
+        h->plan = keep; h->plan_inject = false;
+    }
+    *out = std::max(h->plan.total, h->wsm_total);
     return BYOLO_OK;
 }
 

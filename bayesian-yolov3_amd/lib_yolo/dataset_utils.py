@@ -15,7 +15,8 @@ map(parse_example, num_parallel_calls=config['cpu_thread_cnt']) -> batch -> pref
   * the map stage runs on `cpu_thread_cnt` native threads (csrc/host_io.cpp through the C-ABI: byolo_feed_records, one call
     per batch that holds no GIL): each reads its record's payload, checks the CRC, finds the PNG in the Example and inflates /
     unfilters it (zlib) straight into its frame of a batch buffer the caller may have pinned;
-  * `prefetch` batches (config['data']['prefetch'], default 2) are decoded ahead of the consumer by a feeder thread;
+  * `prefetch` batches (config['data']['prefetch'], default max(2, cpu_thread_cnt / images per batch)) are decoded ahead of the
+    consumer, several at a time, so that the pool is full at batch_size = 1 as well (the reference's default);
   * frames leave the host as uint8 -- the * (1/255) runs on the device (byolo_normalize_u8), bit-identical -- except through
     the plain iterator (`for imgs, names in dataset`), which yields the reference's float32 batches;
   * multi-GPU: a rank only reads, checks and decodes the records of ITS block of every global batch; the others are skipped by
@@ -269,7 +270,7 @@ class TestingDataset:
         self.shape = tuple(config['full_img_size'])
         self.verify_crc = info.get('verify_crc', True)
         self.threads = max(1, int(config.get('cpu_thread_cnt', 1)))          # num_parallel_calls of the map stage (:196)
-        self.prefetch = max(1, int(info.get('prefetch', 2)))                 # batches decoded ahead (:199 prefetches 1)
+        self.prefetch = int(info.get('prefetch', 0))                         # batches decoded ahead (:199 prefetches 1); 0 = derive it (iter_shards_u8)
         self.placeholder = _model.Placeholder((self.batch_size,) + self.shape)
 
     def _records(self):
@@ -356,14 +357,23 @@ class TestingDataset:
     def iter_shards_u8(self, rank, world, alloc=None, extra_buffers=2):
         """Yields a `Shard` per global batch: the frames of this rank's contiguous block (byolo.dist.shard_range; may be empty
         for a last, short batch).  alloc(shape) -> uint8 ndarray provides the batch buffers (the driver passes pinned memory);
-        `prefetch` + 1 + extra_buffers of them circulate: one being filled, `prefetch` waiting, extra_buffers with the consumer."""
+        `prefetch` + 1 + extra_buffers of them circulate: `prefetch` decoded or being decoded ahead of the consumer,
+        extra_buffers with the consumer.
+
+        The map stage runs `cpu_thread_cnt` decodes at a time whatever the batch size: up to `prefetch` batches are in the
+        decode pool TOGETHER (each on min(cpu_thread_cnt, images of its block) native threads) and are handed over in order --
+        at the reference's default batch_size = 1 (inference_epistemic.py:222) a 1024 x 1920 frame is 50 ms of inflate on one
+        core, so one batch at a time would feed 20 img/s to a device that takes 41.  `prefetch` defaults to
+        max(2, cpu_thread_cnt / images per block), at most 16."""
+        from concurrent.futures import ThreadPoolExecutor
         from byolo.dist import shard_range
         alloc = alloc or (lambda shape: np.empty(shape, dtype=np.uint8))
-        cap = shard_range(self.batch_size, 0, world)[1]                      # the largest block of a full batch
+        cap = max(1, shard_range(self.batch_size, 0, world)[1])              # the largest block of a full batch
+        prefetch = self.prefetch if self.prefetch > 0 else max(2, min(16, -(-self.threads // cap)))
         free = queue.Queue()
-        for _ in range(self.prefetch + 1 + max(1, extra_buffers)):
-            free.put(alloc((max(cap, 1),) + self.shape))
-        ready = queue.Queue(maxsize=self.prefetch)
+        for _ in range(prefetch + 1 + max(1, extra_buffers)):
+            free.put(alloc((cap,) + self.shape))
+        ready = queue.Queue(maxsize=prefetch)                                # futures, in batch order
         stop = threading.Event()
 
         def put(item):
@@ -375,7 +385,11 @@ class TestingDataset:
                     pass
             return False
 
+        def load(recs, buf, lo, n_glob):
+            return buf, len(recs), self._load_block(recs, buf), lo, n_glob   # a failed record raises at the consumer, in order
+
         def feeder():
+            pool = ThreadPoolExecutor(max_workers=prefetch, thread_name_prefix='byolo-feed')
             try:
                 for recs in self._global_batches():
                     lo, hi = shard_range(len(recs), rank, world)
@@ -387,12 +401,13 @@ class TestingDataset:
                             buf = free.get(timeout=0.1)
                         except queue.Empty:
                             pass
-                    names = self._load_block(recs[lo:hi], buf)               # a failed record raises here
-                    if not put((buf, hi - lo, names, lo, len(recs))):
+                    if not put(pool.submit(load, recs[lo:hi], buf, lo, len(recs))):
                         return
                 put(None)
-            except BaseException as e:                                        # delivered to the consumer, in order
+            except BaseException as e:                                        # (the record index itself: framing errors) delivered in order
                 put(e)
+            finally:
+                pool.shutdown(wait=True)
 
         th = threading.Thread(target=feeder, name='byolo-feeder', daemon=True)
         th.start()
@@ -403,7 +418,7 @@ class TestingDataset:
                     return
                 if isinstance(item, BaseException):
                     raise item
-                buf, n, names, lo, n_glob = item
+                buf, n, names, lo, n_glob = item.result()
                 yield Shard(buf[:n], names, lo, n_glob, (lambda b=buf: free.put(b)))
         finally:
             stop.set()

@@ -191,7 +191,7 @@ def other_config_leg(num, device, steps=5, warmup=2, oracle=True):
     return res
 
 
-def entry_point_leg(cfg, device, n_frames=512, distinct=32):
+def entry_point_leg(cfg, device, n_frames=512, distinct=32, extras=True):
     """The drop-in path a user of the reference runs: `inference_epistemic.inference(config)` (inference_epistemic.py:186-208) over
     a TFRecord shard set generated here -- `distinct` synthetic frames (i.i.d. uniform, quantised to bytes) as PNG
     records, repeated to n_frames with their own file names, two shards -- with the benchmark's batch, T and weights recipe.
@@ -239,6 +239,11 @@ def entry_point_leg(cfg, device, n_frames=512, distinct=32):
         assert len(files) == n_frames, "the entry point wrote %d files for %d frames" % (len(files), n_frames)
         sample = json.load(open(os.path.join(out_dir, files[0])))["children"]
         json_bytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in files)
+        if not extras:
+            return {"img_s": n_frames / stats["loop_s"], "unit": "img/s", "frames": n_frames, "batch_size": B, "T": T,
+                    "img_size": [H, W], "loop_s": stats["loop_s"], "wall_s": wall, "decode_threads": threads,
+                    "host_waited_s": {"feed": stats["wait_feed_s"], "device": stats["wait_device_s"], "writer": stats["wait_writer_s"]},
+                    "boxes_per_image": len(sample), "precision": stats["precision"]}
         # the feed alone (decode pool + prefetch, frames dropped), then the writer alone (the rows of one written file, n_frames times)
         t0 = time.perf_counter()
         n = 0
@@ -264,7 +269,7 @@ def entry_point_leg(cfg, device, n_frames=512, distinct=32):
                 "entry": "inference_epistemic.inference(config) -- TFRecord shards -> PNG decode -> device -> ECP JSON files",
                 "loop_s": stats["loop_s"], "wall_s": wall, "setup_s": wall - stats["loop_s"], "records_generated_in_s": t_gen,
                 "feed_img_s": n / feed_s, "writer_img_s": n_frames / writer_s, "cores": os.cpu_count(), "decode_threads": threads,
-                "writer_threads": 4, "prefetch_batches": 2, "batches_in_flight": 2,
+                "writer_threads": 4, "prefetch_batches": max(2, min(16, -(-threads // B))), "batches_in_flight": 2,
                 "host_waited_s": {"feed": stats["wait_feed_s"], "device": stats["wait_device_s"], "writer": stats["wait_writer_s"]},
                 "boxes_per_image": len(sample), "json_mb_written": json_bytes / 1e6, "png_mb_read": sum(len(e) for e in enc) / distinct * n_frames / 1e6,
                 "native_json": stats["native_json"], "precision": stats["precision"], "precision_switches": stats["precision_switches"]}
@@ -629,6 +634,17 @@ def main():
                 line["entry_point"]["vs_value"] = line["entry_point"]["img_s"] / line["value"]
             except Exception as e:
                 line["entry_point"] = {"img_s": None, "error": repr(e)}
+            # the reference's own default workload through the same entry point: full ECP frame, T = 50, batch_size = 1
+            # (inference_epistemic.py:212-240; class-agnostic NMS as the reference runs it) -- a short run
+            if args.config == 4 and not args.no_other_configs:
+                try:
+                    c6 = dict(CONFIGS[6], nms=0)
+                    ep6 = entry_point_leg(c6, device, n_frames=48, distinct=8, extras=False)
+                    dev6 = (line.get("other_configs") or {}).get("reference default frame (inference_epistemic.py:218-221)", {}).get("img_s")
+                    ep6["vs_device_only"] = (ep6["img_s"] / dev6) if dev6 else None
+                    line["entry_point_reference_default"] = ep6
+                except Exception as e:
+                    line["entry_point_reference_default"] = {"img_s": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"], o_rows, o_kept = cpu_baseline(cfg, eng.get_params())

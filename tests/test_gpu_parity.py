@@ -37,6 +37,13 @@ def _f32_only(precision, what):
         pytest.skip(what + " exists in the fp32 mode only")
 
 
+def _default_precision_only(precision, why):
+    """The minutes of this module are host time of the CPU oracle at full-size shapes; where the fp32 mode is covered at the same
+    shape elsewhere (tests/test_gpu_bench_shapes.py::test_config4_as_benched[f32]) the full-size leg runs in the default precision."""
+    if precision != "split":
+        pytest.skip(why)
+
+
 def _sub(i, a):      # same subsampling as oracle/make_golden.py:tap_subsample
     if i == 0:
         return a[:, ::8, ::8, :]
@@ -549,7 +556,7 @@ def test_first_image_makes_shards_equal_the_whole_batch():
     assert m.engine.max_images(m.T) > 1000            # 64x96: far from the 3 GiB bound
 
 
-def test_a_batch_beyond_max_images_runs_as_sub_batches():
+def test_a_batch_beyond_max_images_runs_as_sub_batches(precision):
     """The convolutions address their sources with 32-bit buffer offsets, so one byolo_forward call takes at most
     byolo_max_images(T) images (17 at 608x608, T=30: the stacked 76x76x256 activation must stay below 3 GiB) and Engine.forward
     runs a larger batch as consecutive sub-batches with `first_image` = their position -- the path a strong-scaling run on ONE GPU
@@ -557,6 +564,7 @@ def test_a_batch_beyond_max_images_runs_as_sub_batches():
     (3) must produce what ONE logical batch produces: images 17 (first of the second call) and 19 (last) against the CPU oracle
     with the dropout stream of their position (sample_offset = i * T), images 0 and 16 against their own one-image calls at that
     position, and the tail of all 20 bit-exact against the oracle's NMS on the device's rows."""
+    _default_precision_only(precision, "sub-batching is host logic above the C-ABI, the same in both precisions")
     torch = _torch()
     from byolo import synth
     from oracle import cpu_ref
@@ -587,9 +595,10 @@ def test_a_batch_beyond_max_images_runs_as_sub_batches():
     _check_nms_against_oracle(boxes, out, v)
 
 
-def test_full_size_vs_cpu_restatement():
+def test_full_size_vs_cpu_restatement(precision):
     """BASELINE config 4 geometry (608x608, T=30), one image, against the CPU restatement run on the
     same device-calibrated weights: every pre-NMS row within 1e-4, tail bit-exact on the GPU's rows."""
+    _default_precision_only(precision, "the fp32 mode at this shape: tests/test_gpu_bench_shapes.py::test_config4_as_benched[f32]")
     torch = _torch()
     from byolo import synth
     from oracle import cpu_ref
@@ -624,7 +633,12 @@ def test_reference_default_workload_vs_the_reference_run():
     g = golden("fwd_default_frame.npz")
     HD, WD, TD, seed_w, seed_drop, img_seed, every = [int(v) for v in g["meta"]]
     v = "bayesian_yolov3_aleatoric"
-    m = build_model(v, HD, WD, T=TD, params=golden_params(v))[1]
+    params = golden_params(v)
+    for k in g.files:                                     # the BN statistics the fixture was generated with (calibrated at this size)
+        if k.startswith("bn/"):
+            assert params[k[3:]].shape == g[k].shape
+            params[k[3:]] = g[k].astype(np.float32)
+    m = build_model(v, HD, WD, T=TD, params=params)[1]
     m.finalize()
     x = torch.from_numpy(synth.synthetic_images(1, HD, WD, seed=img_seed)).cuda()
     out = m.engine.forward(x, T=TD, seed=seed_drop, want_boxes=True, want_nms=True)
