@@ -117,6 +117,7 @@ struct Plan {
     std::vector<int> tile;         // per step: tile configuration of the launch
     std::vector<WinoPlan> wino;    // per step
     std::vector<int> stream1x1;    // per step: tile width of the row-streaming 1x1 launch (gemm_stream.hip), 0 = conv_igemm
+    std::vector<char> fuse;        // per step: the NEXT step (a 1x1 convolution / detection head reading only this output) runs inside this launch
     size_t wino_off = 0;           // scratch for V and M of one chunk (shared by all steps)
 };
 static constexpr int CNT_PER_STEP = 1024;      // >= resident workgroups of any tile configuration
@@ -949,10 +950,38 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
         if (it + 1 != free_list.end() && it->off + it->size == (it + 1)->off) { it->size += (it + 1)->size; free_list.erase(it + 1); }
         if (it != free_list.begin() && (it - 1)->off + (it - 1)->size == it->off) { (it - 1)->size += it->size; free_list.erase(it); }
     };
+    // Back-to-back fusion (conv_igemm.hip fused_tail): a shared-tap 3x3 convolution with exactly 256 output channels (the 8-wave
+    // 128 x 256 tile), followed by a 1x1 convolution / detection head of <= 128 output channels that is the ONLY reader of its
+    // output: the follower runs inside the 3x3 launch from LDS, the 3x3 layer's output tensor is never written.  Decided here,
+    // before the arena is laid out: the fused launch reads the 3x3 layer's INPUT while it writes the FOLLOWER's output, so those
+    // two must not share memory (unfused, the follower's output may take the place of the 3x3 layer's dead input).
+    // Measured at config 4 (round 4, three A/B runs on one box each, gpurun_out/r4f-r4h): the three pairs of the 76x76 head
+    // 2.11 + 0.56 -> 2.60, 2.11 + 0.56 -> 2.59, 2.09 + 0.38 -> 2.32 ms; 342.6 -> 348.3, 344.5 -> 349.9, 347.1 -> 350.4 img/s.
+    // BYOLO_B2B: 0 never, 1 launches of >= 4 rounds of 256 workgroups (default), 2 every eligible pair (tests)
+    p.fuse.assign(h->steps.size(), 0);
+    { const char* be = getenv("BYOLO_B2B");
+      const int b2b = be ? atoi(be) : 1;
+      for (size_t si = 0; b2b && h->precision == 1 && !inject && !h->cfg.keep_all_outputs && si + 1 < h->steps.size(); ++si) {
+          const Step& s = h->steps[si];
+          const Layer& l = h->layers[s.layer];
+          if (!(s.is_conv() && s.kx3 && s.mode == STEP_NORMAL && l.op == OP_CONV && !l.direct && l.filters == 256 && s.Npad == 256 && l.fused_residual < 0)) continue;
+          int M, KT; step_geometry(h, s, B, T, &M, &KT);
+          if (b2b < 2 && (int64_t)((M + 127) / 128) < 4 * 256) continue;
+          const Step& s2 = h->steps[si + 1];
+          const Layer& l2 = h->layers[s2.layer];
+          const int out_t = s.out_tensor;
+          if (s2.is_conv() && s2.mode == STEP_NORMAL && s2.p1 && !l2.direct && l2.ksize == 1 && l2.stride == 1 && s2.in.n == 1 &&
+              s2.in.s[0].layer == out_t && !s2.in.s[0].tile && s2.in.s[0].sh == 0 && s2.in.s[0].C == 256 && s2.c_lo == 0 && s2.c_hi == 256 &&
+              l2.fused_residual < 0 && s2.Npad <= 128 && (layer_pitch(l2) % 4) == 0 && l2.H == l.H && l2.W == l.W && l2.stacked == l.stacked &&
+              h->last_use[out_t] == (int)si + 1)
+              p.fuse[si] = 1;
+      }
+    }
     for (int si = 0; si < (int)h->steps.size(); ++si) {
         const Layer& l = h->layers[h->steps[si].layer];
         const int t = h->steps[si].out_tensor;
-        p.off[t] = alloc(tensor_bytes(h, t, B, T));
+        if (!(si > 0 && p.fuse[si - 1])) p.off[t] = alloc(tensor_bytes(h, t, B, T));      // (a fused follower's output exists since the step before)
+        if (p.fuse[si]) { const int t2 = h->steps[si + 1].out_tensor; p.off[t2] = alloc(tensor_bytes(h, t2, B, T)); }
         if (h->cfg.keep_all_outputs) continue;
         for (int k = 0; k < n; ++k)
             if (p.off[k] >= 0 && h->last_use[k] == si) release(p.off[k], tensor_bytes(h, k, B, T));
@@ -997,10 +1026,12 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
             (kx3_wide >= 2 ? (tile == TILE_128x128 || tile == TILE_128x64)       // (forced: also where the grid-fill rule above went narrow)
                            : (tile == TILE_128x128 && (int64_t)((M + 127) / 128) * (s.Npad / 256) >= 4 * 256)))
             tile = TILE_128x256;
+        if (p.fuse[si]) tile = TILE_128x256;                  // (decided before the arena was laid out, above)
         p.tile[si] = tile;
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
         const bool sp = h->precision == 1, kx3 = sp && s.kx3;
         p.split[si] = conv_plan_split(M, s.Npad, kx3 ? KT / 3 : KT, tile, sp ? (kx3 ? 1.2 : 0.4) : 1.0);
+        if (tile == TILE_128x256) p.split[si] = ConvSplit{((M + 127) / 128) * (s.Npad / 256), 0, 0, 1};      // whole tiles only: its workgroups walk the tile list (conv_igemm.hip WALK); a follower needs a finished tile
         slab = std::max(slab, conv_split_slab_bytes(p.split[si], tile));
     }
     // Winograd F(2x2,3x3) for the large 3x3 / stride-1 convolutions (winograd.hip): samples per chunk such that
@@ -1025,7 +1056,7 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
         for (size_t si = 0; on && si < h->steps.size(); ++si) {
             const Step& s = h->steps[si];
             const Layer& l = h->layers[s.layer];
-            if (!s.wino_ok || !s.kx3 || s.mode != STEP_NORMAL || l.wshift_u.empty() || l.fused_residual >= 0) continue;
+            if (!s.wino_ok || !s.kx3 || s.mode != STEP_NORMAL || l.wshift_u.empty() || l.fused_residual >= 0 || p.fuse[si]) continue;
             int M, KT; step_geometry(h, s, B, T, &M, &KT);
             if (2.0 * M * l.filters * 9.0 * l.Cin < min_flops) continue;
             // per transform point the K loop is only Cin / 32 tiles long, and the fold + the 5x input stream are paid per point:
@@ -1539,15 +1570,12 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     if (h->precision == 1 && h->img_split)
         HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st, h->d_status));
-    for (size_t si = 0; si < h->steps.size(); ++si) {
+    // everything a convolution step's launch needs, up to the launch itself: sources, epilogue flags, this call's dropout keys /
+    // injected bits, tile configuration and split-K plan, the algorithmic FLOPs the step stands for
+    auto prep = [&](size_t si, ConvParams& p, int& tile, double& algo) -> int32_t {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
-        if (wait_pending && s.layer >= h->backbone_end) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0)); wait_pending = false; }
-        if (h->profiling && !backbone_marked && h->backbone_end >= 0 && s.layer >= h->backbone_end) {
-            HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); backbone_marked = true;
-        }
-        ConvParams p; fill_conv(h, s, d_img, ws, B, T, p);
-        if (!s.is_conv()) { rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
+        fill_conv(h, s, d_img, ws, B, T, p);
         if (l.op == OP_CONV && s.mode != STEP_PARTIAL) {
             p.flags = EPI_LEAKY;
             if (l.drop_ordinal >= 0 && dropout_on) {
@@ -1575,7 +1603,7 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
             if (l.op == OP_DETECTION) p.flags |= EPI_F32OUT;    // the decode kernels read plain fp32
         }
         // tile configuration and split-K of the last partial round: decided per (B, T) in make_plan
-        const int tile = h->plan.tile[si];
+        tile = h->plan.tile[si];
         const ConvSplit& sp = h->plan.split[si];
         p.full_tiles = sp.full_tiles; p.split_tiles = sp.split_tiles; p.split_blocks = sp.split_blocks; p.ksplit = sp.ksplit;
         p.sk_grid = sp.sk_grid;
@@ -1585,7 +1613,33 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         // ALGORITHMIC FLOPs the step stands for (graph as written): the whole layer on all MC
         // samples for a de-duplicated launch, nothing for the auxiliary partial launch
         const int64_t S_all = l.stacked ? (int64_t)B * T : B;
-        const double algo = s.mode == STEP_PARTIAL ? 0.0 : 2.0 * (double)(S_all * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);
+        algo = s.mode == STEP_PARTIAL ? 0.0 : 2.0 * (double)(S_all * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);
+        return BYOLO_OK;
+    };
+    for (size_t si = 0; si < h->steps.size(); ++si) {
+        const Step& s = h->steps[si];
+        const Layer& l = h->layers[s.layer];
+        if (wait_pending && s.layer >= h->backbone_end) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0)); wait_pending = false; }
+        if (h->profiling && !backbone_marked && h->backbone_end >= 0 && s.layer >= h->backbone_end) {
+            HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); backbone_marked = true;
+        }
+        ConvParams p;
+        if (!s.is_conv()) { fill_conv(h, s, d_img, ws, B, T, p); rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
+        int tile = 0; double algo = 0.0;
+        rc = prep(si, p, tile, algo); if (rc) return rc;
+        const ConvSplit& sp = h->plan.split[si];
+        if (h->plan.fuse[si]) {
+            // back-to-back: the next step (the 1x1 convolution / detection head that alone reads this output) inside this launch
+            ConvParams f; int ftile = 0; double falgo = 0.0;
+            rc = prep(si + 1, f, ftile, falgo); if (rc) return rc;
+            p.f_wpk = f.wpk; p.f_w_bytes = f.w_bytes; p.f_scale = f.scale; p.f_shift = f.shift; p.f_dst = f.dst;
+            p.f_N = f.N; p.f_Npad = f.Npad; p.f_ldc = f.ldc; p.f_flags = f.flags; p.f_layer_idx = f.layer_idx;
+            p.f_k0 = f.k0; p.f_k1 = f.k1; p.f_thr = f.thr; p.f_idx_base = f.idx_base; p.f_mask_bits = f.mask_bits;
+            if (per_step) { rc = mark_launch(h, s.layer, 4256, p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo + falgo, st, 1, 0); if (rc) return rc; }
+            HIPCHK(h, launch_conv_igemm(p, tile, st));
+            ++si;                                               // the follower is done
+            continue;
+        }
         if (h->plan.wino[si].chunk > 0 && h->precision == 1) { rc = run_wino_split(h, s, l, p, h->plan.wino[si], algo, ws, st); if (rc) return rc; continue; }
         if (h->plan.wino[si].chunk > 0) { rc = run_winograd(h, s, l, p, h->plan.wino[si], tile, algo, ws, st); if (rc) return rc; continue; }
         if (h->plan.stream1x1[si]) {                            // row-streaming 1x1 convolution / detection head

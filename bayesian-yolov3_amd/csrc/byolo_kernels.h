@@ -99,6 +99,16 @@ struct ConvParams {
     FastDiv d_wino;
     // filled by the launcher for the tile it picked
     FastDiv d_ntiles, d_cin, d_ks, d_ksplit;   // Npad / BN, cin_tiles, ksize, ksplit
+    // Back-to-back fusion (conv_igemm.hip fused_tail; the 8-wave 128 x 256 shared-tap tile with cout == 256 only): the 1x1 convolution
+    // or detection head that is the ONLY reader of this convolution's output runs in the same launch -- this layer's epilogue
+    // writes its hi/lo rows into LDS instead of memory, a second MFMA pass multiplies them with the follower's weights, the
+    // follower's epilogue stores.  f_wpk == null: no follower.  The f_ fields are the follower's ConvParams fields of the same name.
+    const float* f_wpk; uint32_t f_w_bytes;
+    const float* f_scale; const float* f_shift;
+    float* f_dst;
+    int f_N, f_Npad, f_ldc, f_flags, f_layer_idx;
+    uint32_t f_k0, f_k1, f_thr; uint64_t f_idx_base;
+    const uint32_t* f_mask_bits;
 };
 
 // Winograd F(2x2, 3x3) transforms around the GEMM (winograd.hip)

@@ -516,57 +516,179 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
     finish_tile<BM, BN, WM, WN, SPLIT>(p, smem, acc, tile_m, tile_n, sh);
 }
 
+// Back-to-back fusion on the 8-wave 128 x 256 tile (ConvParams::f_wpk): the accumulators of a finished 3x3 tile -- 128 pixels x
+// ALL 256 output channels of the layer, wave w owns channels 32 w .. 32 w + 31 -- go through this layer's epilogue (dropout mask,
+// BN, leaky, hi/lo encoding, range check) into LDS as the activation image of a 1x1 convolution: 8 K-tiles of [128 rows][32 hi |
+// 32 lo], exactly what the staging stores of conv_tile_p1 would have put there from memory.  A second MFMA pass multiplies them
+// with the follower's weights (N2 <= 128 columns: 8 waves as WM2 x WN2 blocks of TM2 x 1), and the follower's epilogue (finish_tile
+// on a copy of the parameters) stores ITS output.  The 3x3 layer's own output tensor -- 1.42 GB at config 4's 76x76 layers -- is
+// never written or read, and the follower's launch disappears.
+template <int WM2, int WN2>
+__device__ __forceinline__ void fused_tail(const ConvParams& p, float* smem, f32x16 (&acc)[4][1], const uint32_t tile_m) {
+    constexpr int BM = 128, ROWB = LD * 4, A_BUF = BM * ROWB, BN2 = 32 * WN2;
+    using BT2 = SplitTile<BM, BN2, WM2, WN2>;
+    constexpr int TM2 = BT2::TM;
+    static_assert(BT2::TN == 1 && WM2 * WN2 == 8, "8 waves, one column block each");
+    char* lds = reinterpret_cast<char*>(smem);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // nothing below is computed before, or carried through, the K loop above
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    // ---- this layer's epilogue -> LDS -------------------------------------------------------------------------------------
+    {
+        const bool do_drop = p.flags & EPI_DROPOUT;
+        const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
+        const int nb = wave * 32 + 4 * lh;                    // first channel of the lane's group g = 0
+        float vmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t rr = (uint32_t)(i * 32 + li), m = tile_m * BM + rr;
+            const uint64_t idx_row = p.idx_base + (uint64_t)m * (uint64_t)p.N + (uint64_t)nb;
+            const epi::DropRow drow(idx_row, p.k1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dn = 8 * g, n0 = nb + dn;
+                const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);
+                const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = acc[i][0][4 * g + q];
+                bool keep[4] = {true, true, true, true};
+                if (do_drop) epi::keep4(drow, dn, p.k0, p.thr, keep);     // (injected masks: the planner does not fuse such a call)
+                f32x4 v = epi::bn_act4(a4, sc4, sf4, keep, slope);
+                if (m >= (uint32_t)p.M) v = f32x4{0.f, 0.f, 0.f, 0.f};        // rows past the end: never stored by the follower either
+                vmax = epi::absmax4(vmax, v);
+                const f32x4 e = epi::split_encode4(v);
+                // K-tile `wave` of the follower's input; 4-channel group (lh + 2 g) of its 32 channels: hi at +8 q, lo at +64 + 8 q
+                char* at = lds + wave * A_BUF + rr * ROWB + (lh + 2 * g) * 8;
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<f32x2*>(at) = f32x2{e[0], e[1]};
+                *reinterpret_cast<f32x2*>(at + 64) = f32x2{e[2], e[3]};
+            }
+        }
+        if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
+    }
+    __syncthreads();
+    // ---- the follower's GEMM: [128 x 256] x [256 x N2] ---------------------------------------------------------------------
+    const BT2 bt(smem, tid);
+    f32x16 acc2[TM2][1];
+#pragma unroll
+    for (int i = 0; i < TM2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][0][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.f_wpk, p.f_w_bytes);
+    const uint32_t w_step = (uint32_t)p.f_Npad * BK * 4;
+    f16x8 bfr[2][2][1][2];
+    bt.load_b(bfr[0], w_rsrc, 0u);
+    auto ktile2 = [&](auto kt_tag) {
+        constexpr int KT2 = decltype(kt_tag)::value;
+        if constexpr (KT2 < 7) bt.load_b(bfr[(KT2 + 1) & 1], w_rsrc, (uint32_t)(KT2 + 1) * w_step);
+        f16x8 af0[TM2][2], af1[TM2][2];
+        bt.template read_frags<KT2, 0>(af0);
+        bt.template read_frags<KT2, 1>(af1);
+        mfma_step_split<TM2, 1>(acc2, af0, bfr[KT2 & 1][0]);
+        mfma_step_split<TM2, 1>(acc2, af1, bfr[KT2 & 1][1]);
+    };
+    ktile2(std::integral_constant<int, 0>{}); ktile2(std::integral_constant<int, 1>{}); ktile2(std::integral_constant<int, 2>{});
+    ktile2(std::integral_constant<int, 3>{}); ktile2(std::integral_constant<int, 4>{}); ktile2(std::integral_constant<int, 5>{});
+    ktile2(std::integral_constant<int, 6>{}); ktile2(std::integral_constant<int, 7>{});
+    __syncthreads();                              // every fragment is in registers: the next tile of this workgroup may stage again
+    // ---- the follower's epilogue (the vector form of finish_tile: cout and row pitch are multiples of 4; no addend, no residual, one
+    // sample per row -- the planner fuses nothing else) ------------------------------------------------------------------------------
+    {
+        const bool do_drop = p.f_flags & EPI_DROPOUT, split_out = !(p.f_flags & EPI_F32OUT);
+        const float slope = (p.f_flags & EPI_LEAKY) ? 0.1f : 1.f;
+        const int nb = bt.wn * 32 + 4 * lh;
+        float vmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM2; ++i) {
+            const uint32_t m = tile_m * BM + (uint32_t)((bt.wm * TM2 + i) * 32 + li);
+            if (m >= (uint32_t)p.M) continue;
+            const uint64_t idx_row = p.f_idx_base + (uint64_t)m * (uint64_t)p.f_N + (uint64_t)nb;
+            const epi::DropRow drow(idx_row, p.f_k1);
+            float* d = p.f_dst + (size_t)m * p.f_ldc + nb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dn = 8 * g, n0 = nb + dn;
+                if (n0 >= p.f_N) continue;
+                const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.f_scale + n0);
+                const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.f_shift + n0);
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = acc2[i][0][4 * g + q];
+                bool keep[4] = {true, true, true, true};
+                if (do_drop) epi::keep4(drow, dn, p.f_k0, p.f_thr, keep);
+                const f32x4 v = epi::bn_act4(a4, sc4, sf4, keep, slope);
+                if (split_out) vmax = epi::absmax4(vmax, v);
+                *reinterpret_cast<f32x4*>(d + dn) = split_out ? epi::split_encode4(v) : v;
+            }
+        }
+        if (split_out && p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.f_layer_idx); }
+    }
+}
+
 // 3x3 / stride-1 / one plain source, split-f16 (SplitTileKx in mfma_pipe.h): stages [sg_begin, sg_end) of the tile, a
 // stage = (filter row ky, 32-channel chunk) = the three K-tiles kx = 0, 1, 2 on one staged activation tile.  The body
 // is uniform: every K-tile stages the weight tile after it and fetches the one after that, every stage fetches and
 // stages its successor -- past the end of the range those loads read zeros / run past the buffer (bounds-checked) and
 // what they stage is never used.
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, const int logical, const int sg_begin,
+// WALK (the 8-wave 128 x 256 tile, whole tiles only): ONE workgroup per CU, so nothing covers the turn-over between two tiles
+// there -- the workgroup walks the tile list itself (stride gridDim.x from tile `logical_or_first` = blockIdx.x), and fetches the first
+// stage and weight tile of its NEXT tile before the epilogue of the current one: the loads fly while the epilogue computes.
+template <int BM, int BN, int WM, int WN, bool WALK = false>
+__device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, const int logical_or_first, const int sg_begin,
                                               const int sg_end, const TileShare sh) {
     using BT = SplitTileKx<BM, BN, WM, WN>;
     constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD, A_LDX = BT::A_LDX, ROWB = BT::ROWB;
     const BT bt(smem);
     const uint32_t n_tiles = (uint32_t)p.Npad / BN;
-    const uint32_t tile_m = fdiv((uint32_t)logical, p.d_ntiles), tile_n = (uint32_t)logical - tile_m * n_tiles;
     const uint32_t hw = (uint32_t)(p.Hout * p.Wout), W = (uint32_t)p.Wout;
+    int v = logical_or_first;                                  // WALK: position in the tile list (before the XCD remap)
+    uint32_t tile_m, tile_n;
+    auto locate = [&](int logical) { tile_m = fdiv((uint32_t)logical, p.d_ntiles); tile_n = (uint32_t)logical - tile_m * n_tiles; };
+    locate(WALK ? xcd_remap(v, p.full_tiles) : logical_or_first);
 
-    // ---- staging rows of this thread: A_LD rows of the tile + one halo row (threads 0 .. 15) ---------------------------
     uint32_t a_off0[A_LDX], a_vm[A_LDX], a_voff[A_LDX];   // offset of input pixel (y - 1, x); bit ky: row y + ky - 1 exists
-#pragma unroll
-    for (int j = 0; j < A_LDX; ++j) {
-        const int rho = j < A_LD ? bt.a_r + (NT / 8) * j + 1 : (bt.a_r == 0 ? 0 : (bt.a_r == 1 ? BM + 1 : -1));
-        const int64_t mm = (int64_t)tile_m * BM - 1 + rho;
-        const bool ok = rho >= 0 && mm >= 0 && mm < (int64_t)p.M;
-        const uint32_t m = ok ? (uint32_t)mm : 0u;
-        const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
-        const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
-        unsigned vm = 0;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) vm |= ((unsigned)((int)oy + t - 1) < (unsigned)p.Hin) ? (1u << t) : 0u;
-        a_vm[j] = ok ? vm : 0u;
-        const uint32_t s0 = fdiv(sidx, p.d_sdiv0);
-        a_off0[j] = ((((s0 * (uint32_t)p.Hs0 + (oy - 1u)) * (uint32_t)p.Ws0 + ox) * (uint32_t)p.C0) + bt.a_q * 4) * 4u;
-        a_voff[j] = CONV_OOB_OFFSET;
-    }
-    // ---- fragment row addresses: block i of this wave, kx = 0 / 1 / 2 -------------------------------------------------
     uint32_t fa[3][TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const uint32_t rr = bt.wm * TM * 32 + i * 32 + bt.li, m = tile_m * BM + rr;
-        const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
-        const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
-        fa[0][i] = (ox > 0 ? rr : (uint32_t)BT::ZROW) * ROWB + bt.lh * 16;
-        fa[1][i] = (rr + 1) * ROWB + bt.lh * 16;
-        fa[2][i] = (ox + 1 < W ? rr + 2 : (uint32_t)BT::ZROW) * ROWB + bt.lh * 16;
-    }
-
-    // ---- sequencing (scalar): the NEXT stage to load, the next weight tile ------------------------------------------
-    int ld_ky = (int)fdiv((uint32_t)sg_begin, p.d_cin), ld_c = sg_begin - ld_ky * p.cin_tiles;
+    int ld_ky = 0, ld_c = 0;
     bool ld_first = true;
-    uint32_t a_soff = 0;
+    uint32_t a_soff = 0, w_soff = 0;
     const uint32_t w_step = (uint32_t)p.Npad * BK * 4;
-    uint32_t w_soff = (uint32_t)sg_begin * 3u * w_step + tile_n * (BN / 32) * SPLIT_WBLOCK;
+    // per-tile bookkeeping for tile (tile_m, tile_n), its stages from `sgb` on
+    auto setup = [&](const int sgb) {
+        // ---- staging rows of this thread: A_LD rows of the tile + one halo row (threads 0 .. 15) -----------------------
+#pragma unroll
+        for (int j = 0; j < A_LDX; ++j) {
+            const int rho = j < A_LD ? bt.a_r + (NT / 8) * j + 1 : (bt.a_r == 0 ? 0 : (bt.a_r == 1 ? BM + 1 : -1));
+            const int64_t mm = (int64_t)tile_m * BM - 1 + rho;
+            const bool ok = rho >= 0 && mm >= 0 && mm < (int64_t)p.M;
+            const uint32_t m = ok ? (uint32_t)mm : 0u;
+            const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
+            const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
+            unsigned vm = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) vm |= ((unsigned)((int)oy + t - 1) < (unsigned)p.Hin) ? (1u << t) : 0u;
+            a_vm[j] = ok ? vm : 0u;
+            const uint32_t s0 = fdiv(sidx, p.d_sdiv0);
+            a_off0[j] = ((((s0 * (uint32_t)p.Hs0 + (oy - 1u)) * (uint32_t)p.Ws0 + ox) * (uint32_t)p.C0) + bt.a_q * 4) * 4u;
+            a_voff[j] = CONV_OOB_OFFSET;
+        }
+        // ---- fragment row addresses: block i of this wave, kx = 0 / 1 / 2 ---------------------------------------------
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t rr = bt.wm * TM * 32 + i * 32 + bt.li, m = tile_m * BM + rr;
+            const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
+            const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
+            fa[0][i] = (ox > 0 ? rr : (uint32_t)BT::ZROW) * ROWB + bt.lh * 16;
+            fa[1][i] = (rr + 1) * ROWB + bt.lh * 16;
+            fa[2][i] = (ox + 1 < W ? rr + 2 : (uint32_t)BT::ZROW) * ROWB + bt.lh * 16;
+        }
+        // ---- sequencing (scalar): the NEXT stage to load, the next weight tile --------------------------------------
+        ld_ky = (int)fdiv((uint32_t)sgb, p.d_cin); ld_c = sgb - ld_ky * p.cin_tiles;
+        ld_first = true;
+        a_soff = 0;
+        w_soff = (uint32_t)sgb * 3u * w_step + tile_n * (BN / 32) * SPLIT_WBLOCK;
+    };
+    setup(sg_begin);
     const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.src0, p.src0_bytes);
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wpk, p.w_bytes);
     f32x4 a_reg[A_LDX];
@@ -591,22 +713,12 @@ __device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, 
         w_soff += w_step;
     };
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
     using c2 = std::integral_constant<int, 2>;
+    f32x16 acc[TM][TN];
     f16x8 af0[TM][2], af1[TM][2];
     next_stage(); load_a(); load_b(c0{});
-    bt.template store_stage<0>(a_reg);
-    __syncthreads();
-    bt.template read_frags_kx<0, 0>(fa[0], af0);
 
     // K-tile Q (= kx) of a stage in activation buffer AP; its weight fragments are in set (AP + Q) & 1 (a stage flips both)
     auto ktile = [&](auto ap_tag, auto q_tag) {
@@ -632,14 +744,45 @@ __device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, 
         __builtin_amdgcn_sched_barrier(0);
     };
     const int NS = sg_end - sg_begin;
-    int sg = 0;
-    for (; sg + 1 < NS; sg += 2) {
-        ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{});
-        ktile(c1{}, c0{}); ktile(c1{}, c1{}); ktile(c1{}, c2{});
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        bt.template store_stage<0>(a_reg);
+        __syncthreads();
+        bt.template read_frags_kx<0, 0>(fa[0], af0);
+        int sg = 0;
+        for (; sg + 1 < NS; sg += 2) {
+            ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{});
+            ktile(c1{}, c0{}); ktile(c1{}, c1{}); ktile(c1{}, c2{});
+        }
+        if (sg < NS) { ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{}); }
+        __syncthreads();                          // the trailing LDS traffic of the uniform body is done before LDS is reused
+        const uint32_t cur_m = tile_m, cur_n = tile_n;
+        bool more = false;
+        if constexpr (WALK) {
+            v += (int)gridDim.x;
+            more = v < p.full_tiles;
+            if (more) {                           // the next tile's first stage and weight tile fly during this tile's epilogue
+                locate(xcd_remap(v, p.full_tiles));
+                setup(0);
+                next_stage(); load_a(); load_b(c0{});
+            }
+        }
+        bool fused = false;
+        if constexpr (BN == 256 && WM == 1 && WN == 8) {
+            if (p.f_wpk) {                        // back-to-back: the follower 1x1 / detection head in this launch (whole tiles only)
+                if (p.f_Npad > 64) fused_tail<2, 4>(p, smem, acc, cur_m);
+                else fused_tail<4, 2>(p, smem, acc, cur_m);
+                fused = true;
+            }
+        }
+        if (!fused) finish_tile<BM, BN, WM, WN, true>(p, smem, acc, cur_m, cur_n, sh);
+        if (!more) return;
     }
-    if (sg < NS) { ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{}); }
-    __syncthreads();                              // the trailing LDS traffic of the uniform body is done before LDS is reused
-    finish_tile<BM, BN, WM, WN, true>(p, smem, acc, tile_m, tile_n, sh);
 }
 
 // 1x1 / stride-1 convolution over ONE plain source, split-f16: K-tiles [kt_begin, kt_end) of the tile on a UNIFORM, tail-free loop.
@@ -734,6 +877,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const ConvP
     //  (otherwise) blocks [0, full_tiles): whole tiles, each XCD a contiguous range of them; blocks beyond: K slices of
     //    the remaining tiles -- slices of one tile on one XCD (block id % 8), neighbours in dispatch order:
     //    id = full_tiles + ((tile_local / 8) * ksplit + slice) * 8 + tile_local % 8
+    if constexpr (KX3 == 1 && BN == 256) {        // the 8-wave tile: whole tiles only (byolo_api.hip make_plan), walked by the workgroup itself
+        if ((int)blockIdx.x < p.full_tiles)
+            conv_tile_kx3<BM, BN, WM, WN, true>(p, smem, (int)blockIdx.x, 0, p.KT, TileShare{-1, 0, 1, 0, 0, 0});
+        return;
+    }
     const bool sk = p.sk_grid > 0;
     const uint32_t q = (uint32_t)p.sk_q, r = (uint32_t)p.sk_r, KT = (uint32_t)p.KT;
     auto start = [&](uint32_t w) { return w * q + (w < r ? w : r); };
@@ -793,10 +941,14 @@ int conv_pick_tile(int N) {
 
 template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT, int KX3 = 0>
 static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
-    constexpr size_t lds = KX3 == 1 ? (size_t)SplitTileKx<BM, BN, WM, WN>::LDS_BYTES : (SPLIT ? (size_t)SplitTile<BM, BN, WM, WN>::LDS_BYTES : (size_t)BlockTile<BM, BN, WM, WN>::LDS_BYTES);
+    constexpr size_t lds_loop = KX3 == 1 ? (size_t)SplitTileKx<BM, BN, WM, WN>::LDS_BYTES : (SPLIT ? (size_t)SplitTile<BM, BN, WM, WN>::LDS_BYTES : (size_t)BlockTile<BM, BN, WM, WN>::LDS_BYTES);
+    // the 8-wave shared-tap tile may carry a fused follower (fused_tail): 8 K-tiles of [128][144 bytes] of LDS
+    constexpr size_t lds_fused = (KX3 == 1 && BN == 256) ? (size_t)8 * 128 * LD * 4 : 0;
+    constexpr size_t lds_max = lds_fused > lds_loop ? lds_fused : lds_loop;
+    const size_t lds = (lds_fused && p.f_wpk) ? lds_max : lds_loop;
     auto k = conv_igemm_kernel<BM, BN, WM, WN, FAST, SPLIT, KX3>;
     static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), lds, attr_done); e != hipSuccess) return e;
+    if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), lds_max, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, st, p);
     return hipGetLastError();
 }
@@ -887,6 +1039,13 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     // BYOLO_PERSIST = workgroups per CU of a persistent grid (0 = one workgroup per tile; tuning knob)
     static const int persist = [] { const char* e = getenv("BYOLO_PERSIST"); return e ? atoi(e) : 0; }();
     if (persist > 0 && q.sk_grid == 0 && grid > 256 * persist) grid = 256 * persist;
+    // the 8-wave tile runs ONE workgroup per CU: nothing covers the turn-over between two workgroups (dispatch, kernel-argument
+    // loads, address prologue) there, so its workgroups walk the tile list themselves.  BYOLO_WIDE_PERSIST=0: one workgroup per tile
+    if constexpr (BN == 256) {
+        if (q.split_blocks != 0 || q.sk_grid != 0) return hipErrorInvalidValue;      // whole tiles only on this tile
+        static const int wide_persist = [] { const char* e = getenv("BYOLO_WIDE_PERSIST"); return e ? atoi(e) : 1; }();
+        if (wide_persist > 0 && q.sk_grid == 0 && grid > 256 * wide_persist) grid = 256 * wide_persist;
+    }
     const bool fast = p.C1 == 0 && p.sh0 == 0 && p.ksize <= 3;
     if (p.split != (SPLITCFG ? 1 : 0)) return hipErrorInvalidValue;
     if constexpr (SPLITCFG) {

@@ -215,9 +215,12 @@ struct SplitTile {
     int st_off, fa_off;
     uint32_t b_voff;                  // this lane's byte offset inside a weight block, + the wave's first column block
 
-    __device__ __forceinline__ explicit SplitTile(float* smem) {
+    __device__ __forceinline__ explicit SplitTile(float* smem) : SplitTile(smem, (int)threadIdx.x) {}
+    // (tid_ given by the caller: a value the compiler cannot see through keeps this bookkeeping from being hoisted above, and kept
+    //  alive across, a loop in front of it -- conv_igemm.hip fused_tail)
+    __device__ __forceinline__ SplitTile(float* smem, int tid_) {
         lds = reinterpret_cast<char*>(smem);
-        tid = threadIdx.x;
+        tid = tid_;
         const int wave = tid >> 6, lane = tid & 63;
         wm = wave / WN; wn = wave % WN;
         li = lane & 31; lh = lane >> 5;

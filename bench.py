@@ -455,15 +455,20 @@ def main():
             for j, s in enumerate(eng.step_profile()):
                 a = acc.setdefault(s["variant"], [0.0, 0.0, 0, 0.0, 0.0, 0.0, 0.0])
                 wino = s["variant"] in WINO
+                if s["variant"] == 4256:      # 3x3 + fused follower: {M, N, K} describe the 3x3; the launch's FLOPs hold both (nothing padded)
+                    n2 = (s["flops"] - 2.0 * s["M"] * s["N"] * s["K"]) / (2.0 * s["M"] * s["N"])      # the follower's output channels
+                    s = dict(s, flops_executed=s["flops"])
                 a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1; a[3] += s["flops_executed"]
                 a[4] += s["flops"] / 2.25 if wino else s["flops"]
                 # algorithmic bytes of the launch: A operand once + result once + weights once
                 # (a shared-tap 3x3 launch reads its input once: M * K / 9 elements, not the im2col matrix)
                 # (input once + weights once | result once)
                 a[5] += 4.0 * ((s["M"] * s["K"] + 16 * s["K"] * s["N"]) if s["variant"] in (130, 140) else
-                               (s["M"] * s["K"] // 9 + s["K"] * s["N"]) if s["variant"] in (3256, 3128, 3064) else
+                               (s["M"] * s["K"] // 9 + s["K"] * s["N"]) if s["variant"] in (4256, 3256, 3128, 3064) else
                                (s["M"] * s["K"] + (16 if wino else 1) * s["K"] * s["N"]))
-                a[6] += 4.0 * ((s["M"] // 4) * s["N"] if s["variant"] in (130, 140) else s["M"] * s["N"])
+                a[6] += 4.0 * ((s["M"] // 4) * s["N"] if s["variant"] in (130, 140) else s["M"] * (n2 if s["variant"] == 4256 else s["N"]))
+                if s["variant"] == 4256:
+                    a[5] += 4.0 * s["N"] * n2                # + the follower's weights
                 if args.dump_steps:
                     per_launch.setdefault(j, dict(s, ms=0.0))["ms"] += s["ms"] / n_prof
             for k, v in eng.stage_ms().items():
@@ -511,8 +516,9 @@ def main():
                                           "arithmetic in this run") if eng.precision == "split" else
                                          "fp32 operands on v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) on the large 3x3 layers"},
         }
-        SPLIT = (3256, 3128, 3064, 2128, 2064, 1128, 1064, 1032, 140)
-        KERNELS = {3256: "conv_igemm_kernel<128,256,1,8,kx3> (split-f16 3x3/stride-1 on shared-tap stages, 8 waves; BYOLO_KX3_WIDE)",
+        SPLIT = (4256, 3256, 3128, 3064, 2128, 2064, 1128, 1064, 1032, 140)
+        KERNELS = {4256: "conv_igemm_kernel<128,256,1,8,kx3>+fused_tail (split-f16 3x3/stride-1 on shared-tap stages with the following 1x1 convolution / detection head fused in; BYOLO_B2B)",
+                   3256: "conv_igemm_kernel<128,256,1,8,kx3> (split-f16 3x3/stride-1 on shared-tap stages, 8 waves; BYOLO_KX3_WIDE)",
                    3128: "conv_igemm_kernel<128,128,1,4,kx3> (split-f16 3x3/stride-1 on shared-tap stages, v_mfma_f32_32x32x16_f16 x3)",
                    3064: "conv_igemm_kernel<128,64,2,2,kx3> (split-f16 3x3/stride-1 on shared-tap stages)",
                    2128: "conv_igemm_kernel<128,128,1,4,p1> (split-f16 1x1 convolutions on the uniform loop)",
@@ -546,11 +552,11 @@ def main():
             # (tools/profile_round.sh + tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent / another kernel
             traffic = tr_read = tr_write = measured_at = None
             # one file per kernel that has been the dominant one: profiles/traffic_cfg<N>_<tag>.json
-            tag = {3128: "kx3", 140: "wino", 130: "wino_fused"}.get(dom, "v%d" % dom)
+            tag = {4256: "b2b", 3128: "kx3", 140: "wino", 130: "wino_fused"}.get(dom, "v%d" % dom)
             tpath = os.path.join(REPO, "profiles", "traffic_cfg%d_%s.json" % (args.config, tag))
             if os.path.exists(tpath) and not args.batch and args.scaling == "weak":
                 tj = json.load(open(tpath))
-                want = {3128: "conv_igemm_kernel<128, 128, 1, 4, true, true, 1", 140: "wino_split_kernel", 130: "wino_fused_kernel"}.get(dom)
+                want = {4256: "conv_igemm_kernel<128, 256, 1, 8, true, true, 1", 3128: "conv_igemm_kernel<128, 128, 1, 4, true, true, 1", 140: "wino_split_kernel", 130: "wino_fused_kernel"}.get(dom)
                 if want and (want in tj.get("kernel", "") or tj.get("kernel", "") in want):
                     traffic = tj.get("traffic_bytes_per_launch")
                     tr_read, tr_write = tj.get("read_bytes_per_launch"), tj.get("write_bytes_per_launch")

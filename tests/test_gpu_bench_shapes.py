@@ -4,7 +4,7 @@ on the benchmark's own batch, and
 
   * the launch list of that step (byolo_step_profile / byolo_step_split) must contain the kernels the benchmark's
     number is about -- at config 4, default precision: Winograd in split arithmetic (variant 140 + its transform -4) on the six
-    19x19 / 38x38 head convolutions and the shared-tap split-f16 kernel (3128) on the three 76x76 ones; under BYOLO_PRECISION=f32
+    19x19 / 38x38 head convolutions and the shared-tap split-f16 kernel with its follower fused in (4256) on the three 76x76 ones; under BYOLO_PRECISION=f32
     the fused Winograd kernel (variant 130) in chunks;
   * whole images of the batch, INCLUDING THE LAST ONE (its dropout masks sit at sample offset (B-1)*T of the logical
     batch, its rows in the last Winograd chunk), are compared with the CPU restatement per column group at the
@@ -92,12 +92,13 @@ def test_config4_as_benched(precision, monkeypatch):
     v = _variants(launches)
     print("config 4 (%s) launch variants:" % precision, v)
     if precision == "split":
-        kx = [s for s in launches if s["variant"] in (3128, 3064)]
-        big = [s for s in kx if s["flops"] > 5e11 and s["variant"] == 3128]     # 817.6 GFLOP each
+        # the three 76x76 head convolutions (128 -> 256 channels): the 8-wave shared-tap tile with the following 1x1 convolution /
+        # detection head fused in (variant 4256: 817.6 GFLOP + 90.8 / 29.8 of the follower); BYOLO_B2B=0: variant 3128 + the followers' own launches
+        big = [s for s in launches if s["flops"] > 5e11 and s["variant"] in (4256, 3128)]
         wino = [s for s in launches if s["variant"] == 140]                     # Winograd in split arithmetic: carries its layer's direct FLOPs
         # the nine big head 3x3 convolutions: 19x19 / 38x38 (512 / 256 input channels) as Winograd F(2x2,3x3) in split arithmetic
         # (csrc/wino_split.hip), 76x76 (128 channels) on the shared-tap direct kernel
-        assert len(big) == 3 and {s["K"] for s in big} == {1152}, "the 76x76 head 3x3 convolutions run on the shared-tap kernel: %s" % v
+        assert len(big) == 3 and {s["K"] for s in big} == {1152} and {s["variant"] for s in big} == {4256}, "the 76x76 head 3x3 convolutions run on the shared-tap kernel with their followers fused in: %s" % v
         assert {s["K"] for s in wino} == {256, 512} and abs(sum(s["flops"] for s in wino) - 6 * 817.6e9) < 1e10, "six head convolutions as Winograd: %s" % v
         assert v.get(-4, 0) == len(wino), "one input transform per fused Winograd launch: %s" % v
         assert not any(s["variant"] in (128, 64, 32, 129, 130, 131, 132, -2, -3) for s in launches), "an fp32-mode kernel ran: %s" % v

@@ -538,6 +538,35 @@ def test_the_eight_wave_shared_tap_tile_computes_the_same_bits(monkeypatch, prec
     assert np.array_equal(wide["kept"].cpu().numpy(), base["kept"].cpu().numpy())
 
 
+def test_back_to_back_fusion_computes_the_same_bits(monkeypatch, precision):
+    """BYOLO_B2B=2: every shared-tap 3x3 convolution with 256 output channels whose output is read by ONE 1x1 convolution /
+    detection head runs that follower inside its own launch (conv_igemm.hip fused_tail: epilogue -> hi/lo rows in LDS -> second MFMA
+    pass -> the follower's epilogue); the 3x3 layer's output never reaches memory.  In the reference's Bayesian model these are the
+    three pairs of the stride-8 head (lib_yolo/yolov3.py:593-622): 3x3 -> 1x1, 3x3 -> 1x1, 3x3 -> detection.  Same MFMA chain per
+    output element over the same K order as the two separate launches: rows, raw detection outputs and kept indices bit for bit."""
+    if precision != "split":
+        pytest.skip("the shared-tap kernel belongs to the default precision")
+    monkeypatch.setenv("BYOLO_KSPLIT", "0")
+    monkeypatch.setenv("BYOLO_STREAMK", "0")
+    torch = _torch()
+    for v in ("bayesian_yolov3_aleatoric", "yolov3_aleatoric"):
+        B = 1 if v.startswith("bayes") else 2
+        monkeypatch.setenv("BYOLO_B2B", "0")
+        _, base, _, _ = _run(v, B, keep_all=False)
+        monkeypatch.setenv("BYOLO_B2B", "2")
+        m, fused, _, imgs = _run(v, B, keep_all=False)
+        m.engine.set_profiling(2)
+        m.run(torch.from_numpy(imgs).cuda(), seed=42)
+        torch.cuda.synchronize()
+        prof = m.engine.step_profile()
+        m.engine.set_profiling(0)
+        var = [s["variant"] for s in prof]
+        assert var.count(4256) == 3, "three fused pairs expected in the stride-8 head: %s" % var
+        a, b = fused["boxes"].cpu().numpy(), base["boxes"].cpu().numpy()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), v
+        assert np.array_equal(fused["kept"].cpu().numpy(), base["kept"].cpu().numpy())
+
+
 def test_first_image_makes_shards_equal_the_whole_batch():
     """byolo_set_first_image: image j of a shard / sub-batch draws the dropout masks of image first_image + j of the
     logical batch, so pieces equal the unsplit run (fp32 re-association aside: tile and split-K choices depend on

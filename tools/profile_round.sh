@@ -12,8 +12,8 @@ TAG=${1:-round}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --fp32-steps 0"
-ONE="python $PWD/bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline --fp32-steps 0 --pipeline 1"
+BENCH="python $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --fp32-steps 0 --entry-frames 0 --no-other-configs"
+ONE="python $PWD/bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline --fp32-steps 0 --pipeline 1 --entry-frames 0 --no-other-configs"
 
 cd /tmp
 timeout 600 $BENCH --dump-steps "$OUT/per_launch.md" > "$OUT/bench_line.json" 2> "$OUT/bench.err"
