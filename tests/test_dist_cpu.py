@@ -234,3 +234,26 @@ def test_bench_line_through_rccl_one_rank():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_two_ranks_with_real_engines_on_one_device():
+    """`bench.py --gpus 2` with TWO real engines: the box has one GPU and RCCL refuses two ranks on one device, so both ranks run
+    on cuda:0 (BYOLO_DIST_SHARE_DEVICE=1) and the collectives go through gloo (the packed all-gather staged through host memory,
+    byolo/dist.py all_gather_flat).  What the line must show: two ranks with DIFFERENT first images of the global batch, the
+    global batch = 2 x the per-rank one, one kept-index checksum per image of the gathered list.  (That the N-rank job computes what
+    one process computes is tests/test_entry_points.py::test_two_ranks_with_real_engines_write_the_single_process_json -- byte-identical
+    files; the benchmark's position-weighted checksums of 1000 kept boxes per image are not comparable across per-call batch sizes:
+    other tile / stream-K schedules reorder boxes whose scores differ in the last bit.)"""
+    import json
+    base = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--steps", "2", "--warmup", "1", "--config", "3",
+            "--no-cpu-baseline", "--fp32-steps", "0", "--entry-frames", "0", "--no-other-configs", "--no-profile"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BYOLO_DIST_BACKEND="gloo", BYOLO_DIST_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + base[1:] + ["--gpus", "2", "--batch", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    two = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and [r["first_image"] for r in two["ranks"]] == [0, 2] and [r["images"] for r in two["ranks"]] == [2, 2]
+    assert two["config"]["images_per_gpu"] == 2 and len(two["kept_checksum_per_image_of_one_more_step"]) == 4
+    assert two["value"] > 0 and two["scaling"] == "weak" and two["range_status"].startswith("ok")
