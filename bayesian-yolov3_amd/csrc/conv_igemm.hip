@@ -577,20 +577,28 @@ __device__ __forceinline__ void fused_tail(const ConvParams& p, float* smem, f32
         for (int r = 0; r < 16; ++r) acc2[i][0][r] = 0.f;
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.f_wpk, p.f_w_bytes);
     const uint32_t w_step = (uint32_t)p.f_Npad * BK * 4;
-    f16x8 bfr[2][2][1][2];
+    // Software pipeline, pinned with scheduling barriers: while step s (16 channels) multiplies, the activation fragments of step s + 1
+    // and (every other step) the weight fragments of the next K-tile are in flight into the other register sets.  (Left to itself the compiler sank every weight load to just in
+    // front of its first use -- one fragment set, `s_waitcnt vmcnt(0)` after each of the 32 loads: 11 us of exposed latency per tile.)
+    f16x8 bfr[2][2][1][2];                        // [set = K-tile & 1][step][column block][plane]
+    f16x8 afr[2][TM2][2];                         // [set = step & 1][block][plane]
     bt.load_b(bfr[0], w_rsrc, 0u);
-    auto ktile2 = [&](auto kt_tag) {
-        constexpr int KT2 = decltype(kt_tag)::value;
-        if constexpr (KT2 < 7) bt.load_b(bfr[(KT2 + 1) & 1], w_rsrc, (uint32_t)(KT2 + 1) * w_step);
-        f16x8 af0[TM2][2], af1[TM2][2];
-        bt.template read_frags<KT2, 0>(af0);
-        bt.template read_frags<KT2, 1>(af1);
-        mfma_step_split<TM2, 1>(acc2, af0, bfr[KT2 & 1][0]);
-        mfma_step_split<TM2, 1>(acc2, af1, bfr[KT2 & 1][1]);
+    bt.template read_frags<0, 0>(afr[0]);
+    auto step2 = [&](auto s_tag) {                // step S (16 channels) of the 16: K-tile S / 2, half S % 2
+        constexpr int S = decltype(s_tag)::value, KT2 = S >> 1, H = S & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (H == 0 && KT2 < 7) bt.load_b(bfr[(KT2 + 1) & 1], w_rsrc, (uint32_t)(KT2 + 1) * w_step);
+        if constexpr (S < 15) bt.template read_frags<((S + 1) >> 1) & 7, (S + 1) & 1>(afr[(S + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step_split<TM2, 1>(acc2, afr[S & 1], bfr[KT2 & 1][H]);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    ktile2(std::integral_constant<int, 0>{}); ktile2(std::integral_constant<int, 1>{}); ktile2(std::integral_constant<int, 2>{});
-    ktile2(std::integral_constant<int, 3>{}); ktile2(std::integral_constant<int, 4>{}); ktile2(std::integral_constant<int, 5>{});
-    ktile2(std::integral_constant<int, 6>{}); ktile2(std::integral_constant<int, 7>{});
+    step2(std::integral_constant<int, 0>{}); step2(std::integral_constant<int, 1>{}); step2(std::integral_constant<int, 2>{});
+    step2(std::integral_constant<int, 3>{}); step2(std::integral_constant<int, 4>{}); step2(std::integral_constant<int, 5>{});
+    step2(std::integral_constant<int, 6>{}); step2(std::integral_constant<int, 7>{}); step2(std::integral_constant<int, 8>{});
+    step2(std::integral_constant<int, 9>{}); step2(std::integral_constant<int, 10>{}); step2(std::integral_constant<int, 11>{});
+    step2(std::integral_constant<int, 12>{}); step2(std::integral_constant<int, 13>{}); step2(std::integral_constant<int, 14>{});
+    step2(std::integral_constant<int, 15>{});
     __syncthreads();                              // every fragment is in registers: the next tile of this workgroup may stage again
     // ---- the follower's epilogue (the vector form of finish_tile: cout and row pitch are multiples of 4; no addend, no residual, one
     // sample per row -- the planner fuses nothing else) ------------------------------------------------------------------------------
