@@ -689,10 +689,12 @@ def test_reference_default_workload_vs_the_reference_run():
     assert_rows_close(boxes[0, common], g["kept_rows"][[pos[k] for k in common]], v, "reference default workload, kept rows vs the reference's kept rows")
 
 
-def test_reference_default_frame_vs_cpu_restatement():
+def test_reference_default_frame_vs_cpu_restatement(precision):
     """The reference's own default input (inference_epistemic.py:218: the full 1024x1920 ECP frame; the largest,
     non-square geometry: 32x60 / 64x120 / 128x240 cells, 120 960 boxes), T kept at 2 so that the CPU side finishes in
-    seconds: pre-NMS rows within 1e-4, 2-class NMS bit-exact on the GPU's rows."""
+    seconds: pre-NMS rows within 1e-4, 2-class NMS bit-exact on the GPU's rows.  (The same frame at the reference's T = 50 against
+    the reference's own graph code: test_reference_default_workload_vs_the_reference_run, both precisions.)"""
+    _default_precision_only(precision, "the fp32 mode at this shape: test_reference_default_workload_vs_the_reference_run[f32]")
     torch = _torch()
     from byolo import synth
     from oracle import cpu_ref
