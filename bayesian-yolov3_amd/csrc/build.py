@@ -12,11 +12,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "..", "byolo", "libbyolo.so")
 SRCS = ["byolo_api.hip", "conv_igemm.hip", "conv_kernels.hip", "winograd.hip", "gemm_stream.hip", "wino_fused.hip", "wino_split.hip", "tail_kernels.hip",
-        "host_io.cpp"]
+        "train_kernels.hip", "host_io.cpp"]
 HDRS = ["byolo_kernels.h", "byolo_rng.h", "mfma_pipe.h", "epilogue.h", os.path.join("..", "..", "include", "byolo.h")]
 DEPS = SRCS + HDRS
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
 LIBS = ["-lz"]          # host_io.cpp: the PNG decoder inflates with zlib
+# train_kernels.hip restates float32 arithmetic operation by operation (bit-identical masks against the float32 oracle): no
+# fused multiply-add, correctly rounded division
+FILE_FLAGS = {"train_kernels.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]}
 
 
 def build(force=False, verbose=False, ablate=0, ablate_wf=0, ablate_ws=0, jobs=None):
@@ -48,7 +51,7 @@ def build(force=False, verbose=False, ablate=0, ablate_wf=0, ablate_ws=0, jobs=N
         obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_time, os.path.getmtime(os.path.join(HERE, s))):
-            todo.append([hipcc] + FLAGS + defs + ["-c", os.path.join(HERE, s), "-o", obj])
+            todo.append([hipcc] + FLAGS + FILE_FLAGS.get(s, []) + defs + ["-c", os.path.join(HERE, s), "-o", obj])
     jobs = jobs or int(os.environ.get("BYOLO_BUILD_JOBS", "0")) or min(len(todo) or 1, os.cpu_count() or 1)
     running, failed = [], None
     for cmd in todo + [None] * jobs:

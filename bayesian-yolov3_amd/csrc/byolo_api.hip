@@ -209,7 +209,7 @@ static int32_t fail(byolo_t* h, int32_t code, const char* fmt, ...) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" const char* byolo_version(void) { return "byolo 0.4 (gfx950; fp32 MFMA and split-f16 MFMA; abi 4)"; }
+extern "C" const char* byolo_version(void) { return "byolo 0.5 (gfx950; fp32 MFMA and split-f16 MFMA; abi 5)"; }
 extern "C" int32_t byolo_abi_version(void) { return BYOLO_ABI_VERSION; }
 
 extern "C" const char* byolo_last_error(const byolo_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
@@ -1776,6 +1776,69 @@ extern "C" int32_t byolo_sort_nms(byolo_t* h, const float* d_boxes, int32_t B, i
     n.two_class = nms_mode == BYOLO_NMS_TWO_CLASS; n.max_out = max_out; n.iou_thr = iou_thresh;
     n.ws = d_sort_ws; n.ws_bytes = ws_bytes; n.rows = d_rows; n.kept = d_kept; n.count = d_count;
     HIPCHK(h, launch_sort_nms(n, reinterpret_cast<hipStream_t>(stream)));
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ground-truth encoding and training loss (train_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t byolo_encode_gt(byolo_t* h, int32_t n_layers, const int32_t* layer_hw, const double* priors_hw,
+                                   const float* d_boxes, const int32_t* d_labels, const int32_t* d_counts, int32_t B,
+                                   int32_t max_boxes, float ign_thresh, float* d_loc, float* d_obj, int32_t* d_cls,
+                                   float* d_ign, void* stream) {
+    if (!layer_hw || !priors_hw || !d_loc || !d_obj || !d_cls || !d_ign) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: null argument");
+    if (n_layers < 1 || n_layers > 4) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: 1 .. 4 detection layers");
+    if (B < 1 || max_boxes < 0 || (max_boxes > 0 && (!d_boxes || !d_labels))) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: bad batch / boxes");
+    if (h) HIPCHK(h, hipSetDevice(h->device));
+    EncodeGtParams p; memset(&p, 0, sizeof p);
+    int64_t n = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        p.lh[l] = layer_hw[2 * l]; p.lw[l] = layer_hw[2 * l + 1];
+        if (p.lh[l] < 1 || p.lw[l] < 1) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: empty detection layer %d", l);
+        p.base[l] = (int)n;
+        n += (int64_t)p.lh[l] * p.lw[l] * 3;
+        for (int k = 0; k < 3; ++k) {
+            p.ph[l][k] = priors_hw[(l * 3 + k) * 2]; p.pw[l][k] = priors_hw[(l * 3 + k) * 2 + 1];
+            // lib_yolo/data.py:143-144
+            if (!(p.ph[l][k] >= 0 && p.ph[l][k] <= 1 && p.pw[l][k] >= 0 && p.pw[l][k] <= 1))
+                return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: prior height and width must be numbers between 0 and 1");
+        }
+    }
+    if (n > (int64_t)1 << 28) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: too many prior boxes");
+    p.boxes = d_boxes; p.labels = d_labels; p.counts = d_counts; p.B = B; p.max_boxes = max_boxes; p.n_layers = n_layers; p.N = (int)n;
+    p.ign_thresh = ign_thresh; p.loc = d_loc; p.obj = d_obj; p.cls = d_cls; p.ign = d_ign;
+    hipError_t e = launch_encode_gt(p, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, BYOLO_ERR_HIP, "byolo_encode_gt: %s", hipGetErrorString(e));
+    return BYOLO_OK;
+}
+
+extern "C" size_t byolo_loss_workspace_bytes(void) { return loss_workspace_bytes() + 64; }
+
+extern "C" int32_t byolo_loss(byolo_t* h, int32_t kind, int32_t aleatoric_loss, int32_t cls_cnt, const float* d_raw, int32_t pitch,
+                              int32_t S, int32_t lh, int32_t lw, const float* d_gt_loc, const float* d_gt_obj,
+                              const int32_t* d_gt_cls, const float* d_gt_ign, int64_t gt_stride, double* d_loss,
+                              float* d_grad, int32_t grad_pitch, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!d_raw || !d_gt_loc || !d_gt_obj || !d_gt_cls || !d_gt_ign || !d_loss || !d_workspace) return fail(h, BYOLO_ERR_ARG, "byolo_loss: null argument");
+    if (kind != BYOLO_DET_STANDARD && kind != BYOLO_DET_ALEATORIC)
+        return fail(h, BYOLO_ERR_ARG, "byolo_loss: the loss exists for the standard and the aleatoric raw outputs (an epistemic layer "
+                                      "is an aleatoric one outside inference mode, lib_yolo/model.py:166-173)");
+    if (aleatoric_loss && kind != BYOLO_DET_ALEATORIC) return fail(h, BYOLO_ERR_ARG, "byolo_loss: aleatoric_loss needs log_loc_var (aleatoric output)");
+    if (S < 1 || lh < 1 || lw < 1 || cls_cnt < 1 || cls_cnt > BYOLO_MAX_CLASSES) return fail(h, BYOLO_ERR_ARG, "byolo_loss: bad shape");
+    const int F = 3 * (kind == BYOLO_DET_ALEATORIC ? 10 + 2 * cls_cnt : 5 + cls_cnt);
+    if (pitch == 0) pitch = F;
+    if (grad_pitch == 0) grad_pitch = F;
+    if (pitch < F || (d_grad && grad_pitch < F)) return fail(h, BYOLO_ERR_ARG, "byolo_loss: pitch below the %d values of a cell", F);
+    if (gt_stride < (int64_t)lh * lw * 3) return fail(h, BYOLO_ERR_ARG, "byolo_loss: gt_stride below the layer's prior boxes");
+    if ((reinterpret_cast<uintptr_t>(d_gt_loc) & 15) != 0) return fail(h, BYOLO_ERR_ARG, "byolo_loss: d_gt_loc must be 16-byte aligned");
+    if (workspace_bytes < byolo_loss_workspace_bytes()) return fail(h, BYOLO_ERR_NOMEM, "byolo_loss: workspace too small");
+    if (h) HIPCHK(h, hipSetDevice(h->device));
+    LossParams p; memset(&p, 0, sizeof p);
+    p.raw = d_raw; p.pitch = pitch; p.grad = d_grad; p.grad_pitch = grad_pitch; p.S = S; p.lh = lh; p.lw = lw; p.C = cls_cnt;
+    p.aleatoric = kind == BYOLO_DET_ALEATORIC; p.aleatoric_loss = aleatoric_loss != 0;
+    p.gt_loc = d_gt_loc; p.gt_obj = d_gt_obj; p.gt_cls = d_gt_cls; p.gt_ign = d_gt_ign; p.gt_stride = gt_stride;
+    p.partial = reinterpret_cast<double*>(align_up(reinterpret_cast<uintptr_t>(d_workspace), 64)); p.out = d_loss;
+    hipError_t e = launch_loss(p, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? BYOLO_ERR_ARG : BYOLO_ERR_HIP, "byolo_loss: %s", hipGetErrorString(e));
     return BYOLO_OK;
 }
 

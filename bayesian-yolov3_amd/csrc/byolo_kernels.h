@@ -241,4 +241,28 @@ struct NmsParams {
 };
 hipError_t launch_sort_nms(const NmsParams& p, hipStream_t st);
 
+// ---- ground-truth encoding and training loss (train_kernels.hip) ------------------------
+struct EncodeGtParams {
+    const float* boxes;      // [B, max_boxes, 4]  ymin, xmin, ymax, xmax (image fractions)
+    const int32_t* labels;   // [B, max_boxes]
+    const int32_t* counts;   // [B] boxes of each image (null: max_boxes everywhere)
+    int B, max_boxes, n_layers, N;      // N = prior boxes of all layers
+    int lh[4], lw[4], base[4];          // grid and first prior box of each layer ([row, col, box] inside a layer)
+    double ph[4][3], pw[4][3];          // priors as the Python doubles of lib_yolo/yolov3.py
+    float ign_thresh;
+    float* loc; float* obj; int32_t* cls; float* ign;      // [B, N, 4], [B, N], [B, N], [B, N]
+};
+hipError_t launch_encode_gt(const EncodeGtParams& p, hipStream_t st);
+constexpr int LOSS_MAX_BLOCKS = 1024;
+struct LossParams {
+    const float* raw; int pitch;        // raw detection output [S, lh, lw, pitch >= 3 * blk]
+    float* grad; int grad_pitch;        // d(loc + obj + cls) / d raw, or null
+    int S, lh, lw, C, aleatoric, aleatoric_loss;
+    const float* gt_loc; const float* gt_obj; const int32_t* gt_cls; const float* gt_ign;   // [S][gt_stride][4 | 1]: the layer's slice
+    int64_t gt_stride;                  // prior boxes between consecutive images in the ground-truth arrays
+    double* partial; double* out;       // LOSS_MAX_BLOCKS x 3 partial sums; out[3] = loc, obj, cls
+};
+size_t loss_workspace_bytes();
+hipError_t launch_loss(const LossParams& p, hipStream_t st);
+
 }  // namespace byk

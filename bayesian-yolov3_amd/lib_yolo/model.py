@@ -4,8 +4,11 @@
 The reference's ModelBuilder appends TF tensors to a layer list and routes by index; this one issues
 one C-ABI graph call per `make_*` (include/byolo.h) and keeps the same list (as `LayerRef`s that carry
 the TF tensor *names*, which the Darknet weight loader keys on).  Nothing is computed until
-`Model.run(img)` -- the counterpart of `sess.run`.  Training arguments are accepted for signature
-compatibility and rejected when they ask for training (out of scope: inference path only)."""
+`Model.run(img)` -- the counterpart of `sess.run`.  `training=True` (batch-statistics BN, back-propagation, the optimiser) is
+rejected: out of scope.  Ground truth IS accepted (`gt=` of the `make_detection_layer*` calls, as in the reference): the
+loss terms of `lib_yolo/layers.py:126-188` are then evaluated on the device from the raw outputs of the last run
+(`DetLayer.loc_loss` ..., `Model.total_loss` ...; csrc/train_kernels.hip) -- the validation-loss half of
+`lib_yolo/train.py:69-72`."""
 import contextlib
 
 from byolo import Engine, NORM_BN, NORM_DROPOUT, DET_STANDARD, DET_ALEATORIC, DET_EPISTEMIC, NMS_AGNOSTIC
@@ -60,6 +63,7 @@ def _shape_of(inputs):
 
 class ModelBuilder:
     def __init__(self, inputs, cls_cnt, l2_scale=0.0005, engine_options=None):
+        self.l2_scale = l2_scale                  # lib_yolo/model.py:27 (tf.contrib.layers.l2_regularizer)
         self.__layers = []
         self.inputs = inputs
         self.__cls_cnt = cls_cnt
@@ -193,9 +197,10 @@ class ModelBuilder:
             idx = self.engine.add_upsample()
             self.__update_layers(idx, scope + '/ResizeNearestNeighbor:0', 'upsample')
 
-    def __detection(self, all_priors, kind, gt):
-        if gt:
-            raise NotImplementedError('ground truth / loss: training is out of scope (inference path)')
+    def __detection(self, all_priors, kind, gt, aleatoric_loss=False):
+        if gt is not None and kind == DET_EPISTEMIC:
+            # lib_yolo/model.py:171-173 would feed the decode_epistemic dict (no 'loc' key) to loss_tf: a KeyError there
+            raise NotImplementedError('the loss exists outside inference mode only (lib_yolo/model.py:166-173)')
         priors = all_priors[self.__current_downsample]
         assert len(priors) == 3, 'exactly 3 priors per detection layer'
         with self.variable_scope('detection') as scope:
@@ -211,6 +216,8 @@ class ModelBuilder:
             raw_output=self.inputs,
             layer_id=len(self.__det_layers),
             kind=kind,
+            gt=gt,
+            aleatoric_loss=aleatoric_loss,
         ))
         return self.inputs
 
@@ -218,11 +225,11 @@ class ModelBuilder:
         return self.__detection(all_priors, DET_STANDARD, gt)
 
     def make_detection_layer_aleatoric(self, all_priors, aleatoric_loss, gt=None):
-        return self.__detection(all_priors, DET_ALEATORIC, gt)
+        return self.__detection(all_priors, DET_ALEATORIC, gt, aleatoric_loss)
 
     def make_detection_layer_aleatoric_epistemic(self, all_priors, aleatoric_loss, gt=None, inference_mode=False):
         # model.py:166-170: the T-reduction only exists in inference mode
-        return self.__detection(all_priors, DET_EPISTEMIC if inference_mode else DET_ALEATORIC, gt)
+        return self.__detection(all_priors, DET_EPISTEMIC if inference_mode else DET_ALEATORIC, gt, aleatoric_loss)
 
 
 class Model:
@@ -293,16 +300,70 @@ class Model:
             return False
         return True
 
+    # ---- losses of the last run (lib_yolo/model.py:197-216); None without ground truth, like the reference's attributes ----
+    def set_ground_truth(self, gt):
+        """gt: a byolo.loss.GroundTruth (lib_yolo.tfdata.encode_boxes_batch) or one dict per detection layer -- the counterpart
+        of the dataset iterator feeding gt1, gt2, gt3 into the graph (lib_yolo/train.py:35-36).  Must match the batch of the run."""
+        per_layer = gt.layers() if hasattr(gt, 'layers') else list(gt)
+        assert len(per_layer) == len(self.det_layers)
+        for dl, g in zip(self.det_layers, per_layer):
+            dl.gt = g
+            dl._loss_of = None
+
+    def _sum(self, key):
+        if self.det_layers[0].gt is None:
+            return None
+        total = None
+        for dl in self.det_layers:
+            v = dl.loss()[key]
+            total = v if total is None else total + v
+        return total
+
+    @property
+    def loc_loss(self):
+        return self._sum('loc')
+
+    @property
+    def obj_loss(self):
+        return self._sum('obj')
+
+    @property
+    def cls_loss(self):
+        return self._sum('cls')
+
+    @property
+    def detection_loss(self):
+        """`tf.losses.get_total_loss(add_regularization_losses=False)`: every term every detection layer added."""
+        if self.det_layers[0].gt is None:
+            return None
+        return self.loc_loss + self.obj_loss + self.cls_loss
+
+    @property
+    def regularization_loss(self):
+        if self.det_layers[0].gt is None:
+            return None
+        if getattr(self, '_reg', None) is None:
+            from byolo import loss as _loss
+            self._reg = _loss.l2_regularization(self.engine, self.builder.l2_scale)
+        return self._reg
+
+    @property
+    def total_loss(self):
+        if self.det_layers[0].gt is None:
+            return None
+        return self.detection_loss + self.regularization_loss
+
 
 class DetLayer:
-    def __init__(self, input_img_size, downsample_factor, priors, loss, det, bbox, raw_output, layer_id=0, kind=0):
+    def __init__(self, input_img_size, downsample_factor, priors, loss, det, bbox, raw_output, layer_id=0, kind=0, gt=None,
+                 aleatoric_loss=False):
         self.h = input_img_size[0] // downsample_factor
         self.w = input_img_size[1] // downsample_factor
         self.downsample = downsample_factor
         self.priors = priors
-        self.loc_loss = loss['loc'] if loss else None
-        self.obj_loss = loss['obj'] if loss else None
-        self.cls_loss = loss['cls'] if loss else None
+        self.gt = gt if gt else None            # dict 'loc' [B,h,w,3,4], 'obj', 'ign', 'cls' [B,h,w,3] (CUDA tensors), or None
+        self.aleatoric_loss = aleatoric_loss
+        self._loss_of = None
 
         self.det = det
         self.layer_id = layer_id
@@ -310,6 +371,37 @@ class DetLayer:
         self._raw_ref = raw_output
         self._model = None
         self._box_base = 0
+
+    def loss(self, want_grad=False):
+        """`layers.loss_tf(det, gt, aleatoric_loss)` of this layer (lib_yolo/model.py:118, :143, :173) on the raw output of the
+        last `Model.run`: {'loc', 'obj', 'cls'} as 0-d float64 CUDA tensors (want_grad: + 'grad', the derivative with respect to the raw
+        output).  Evaluated once per run."""
+        from lib_yolo import layers
+        if self.gt is None:
+            return None
+        last = self._model.last
+        if last is None:
+            raise RuntimeError('DetLayer.loss: call Model.run(img) first')
+        if self._loss_of is not None and self._loss_of[0] is last and (not want_grad or 'grad' in self._loss_of[1]):
+            return self._loss_of[1]
+        raw = self.raw_output
+        split = layers.split_detection if self.kind == DET_STANDARD else layers.split_detection_aleatoric
+        det = split(raw, boxes_per_cell=len(self.priors), cls_cnt=self._model.cls_cnt)
+        res = layers.loss_tf(det, self.gt, aleatoric_loss=self.aleatoric_loss, want_grad=want_grad, engine=self._model.engine)
+        self._loss_of = (last, res)
+        return res
+
+    @property
+    def loc_loss(self):
+        return self.loss()['loc'] if self.gt is not None else None
+
+    @property
+    def obj_loss(self):
+        return self.loss()['obj'] if self.gt is not None else None
+
+    @property
+    def cls_loss(self):
+        return self.loss()['cls'] if self.gt is not None else None
 
     @property
     def bbox(self):

@@ -96,8 +96,10 @@ class _Yolo:
     def init_model(self, inputs, training, gt1=None, gt2=None, gt3=None):
         if self._model is not None:
             raise Exception('model can only be initialized once!')
-        if training or gt1 or gt2 or gt3:
-            raise NotImplementedError('training graphs are out of scope: this build is the inference path')
+        if training:
+            raise NotImplementedError('training=True (batch-statistics BN, back-propagation, the optimiser) is out of scope; '
+                                      'ground truth with training=False evaluates the loss of the inference graph')
+        self._gt = [gt1, gt2, gt3]              # lib_yolo/train.py:35-36: the dataset's encoded ground truth, one dict per layer
 
         self._build_model(inputs, training)
         assert self._model.matches_blueprint(self.blueprint), 'Model does not match blueprint'
@@ -108,7 +110,7 @@ class _Yolo:
         bn = {'type': 'bn', 'training': training}
         return bn, bn                                    # (first five convs of a head, bn-only convs)
 
-    def _detection(self, mb):
+    def _detection(self, mb, gt=None):
         raise NotImplementedError
 
     def _stack(self, mb, layer):
@@ -143,7 +145,7 @@ class _Yolo:
                 for i in range(3):
                     mb.make_conv_layer(filters, 1, drop)
                     mb.make_conv_layer(2 * filters, 3, drop if i < 2 else bn)
-                self._detection(mb)
+                self._detection(mb, gt=self._gt[len(outs)])   # gt1 / gt2 / gt3 (yolov3.py:254, :278, :302)
                 outs.append(mb.inputs)
 
         self._model = mb.get_model(self.obj_idx, self.cls_start_idx)
@@ -156,8 +158,8 @@ class yolov3(_Yolo):
     obj_idx = 4
     cls_start_idx = 5
 
-    def _detection(self, mb):
-        mb.make_detection_layer(all_priors=self._priors)
+    def _detection(self, mb, gt=None):
+        mb.make_detection_layer(all_priors=self._priors, gt=gt)
 
 
 class yolov3_aleatoric(_Yolo):
@@ -169,8 +171,8 @@ class yolov3_aleatoric(_Yolo):
         self._aleatoric_loss = config['aleatoric_loss']          # required key (yolov3.py:315)
         super().__init__(config)
 
-    def _detection(self, mb):
-        mb.make_detection_layer_aleatoric(all_priors=self._priors, aleatoric_loss=self._aleatoric_loss)
+    def _detection(self, mb, gt=None):
+        mb.make_detection_layer_aleatoric(all_priors=self._priors, aleatoric_loss=self._aleatoric_loss, gt=gt)
 
 
 class bayesian_yolov3_aleatoric(_Yolo):
@@ -202,6 +204,6 @@ class bayesian_yolov3_aleatoric(_Yolo):
         mb.make_stack_feature_map_layer(layer, self._T)
         return True
 
-    def _detection(self, mb):
-        mb.make_detection_layer_aleatoric_epistemic(all_priors=self._priors, aleatoric_loss=self._aleatoric_loss,
+    def _detection(self, mb, gt=None):
+        mb.make_detection_layer_aleatoric_epistemic(all_priors=self._priors, aleatoric_loss=self._aleatoric_loss, gt=gt,
                                                     inference_mode=self._inference_mode)

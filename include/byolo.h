@@ -83,8 +83,9 @@ BYOLO_API const char* byolo_last_error(const byolo_t* h);
 BYOLO_API const char* byolo_version(void);
 /* Incremented on every incompatible change of a signature or of a buffer layout this header describes, so that a binding can
  * refuse a library it was not written for (byolo/_lib.py does).  4: byolo_forward takes d_mask_bits; detection rows handed out
- * by byolo_layer_output are padded to a multiple of 4 floats; the host-side feed / writer entry points exist. */
-#define BYOLO_ABI_VERSION 4
+ * by byolo_layer_output are padded to a multiple of 4 floats; the host-side feed / writer entry points exist.  5: byolo_encode_gt,
+ * byolo_loss (ground-truth encoding and training loss) exist. */
+#define BYOLO_ABI_VERSION 5
 BYOLO_API int32_t byolo_abi_version(void);
 
 /* ---- graph construction: one call per ModelBuilder.make_* (lib_yolo/model.py:52-185).
@@ -219,6 +220,39 @@ BYOLO_API int32_t byolo_sort_nms(byolo_t* h, const float* d_boxes, int32_t B, in
                        int32_t cls_start_idx, int32_t nms_mode, int32_t max_out, float iou_thresh,
                        void* d_sort_ws, size_t ws_bytes,
                        float* d_rows, int32_t* d_kept, int32_t* d_count, void* stream);
+
+/* ---- ground-truth encoding and training loss ------------------------
+ * The reference builds both into its TRAINING graph; here they are two stand-alone device functions (the optimiser, batch-
+ * statistics BN and back-propagation through the network stay out of scope).  `h` supplies the device and the error string
+ * and may be NULL (current device, byolo_last_error(NULL)).
+ *
+ * byolo_encode_gt = lib_yolo/tfdata.py:77-171 `encode_boxes` (the map function of the training dataset,
+ * lib_yolo/dataset_utils.py:58-63) for a batch of B images: boxes [B,max_boxes,4] as (ymin, xmin, ymax, xmax) image
+ * fractions, labels [B,max_boxes], counts [B] (NULL: every image has max_boxes boxes); detection layers as
+ * layer_hw [n_layers][2] and priors_hw [n_layers][3][2] = (h, w) DOUBLES (the Python floats of lib_yolo/yolov3.py:6-166: the
+ * prior boxes are computed in double and rounded to float32 like lib_yolo/data.py:125-166 does).  Outputs, per image the prior
+ * boxes of all layers back to back, inside a layer in the reference's [row, col, box] order (N = sum of lh * lw * 3): loc [B,N,4]
+ * (logit / log targets), obj [B,N], cls [B,N] (int32), ign [B,N]; layer k's slice reshapes to the reference's
+ * gt_k['loc'] [lh,lw,3,4] etc.  Later boxes overwrite earlier ones that claim the same prior box, as the reference's
+ * sequential tf.while_loop does.  The masks are bit-identical to a float32 evaluation of the reference's formulas. */
+BYOLO_API int32_t byolo_encode_gt(byolo_t* h, int32_t n_layers, const int32_t* layer_hw, const double* priors_hw,
+                                  const float* d_boxes, const int32_t* d_labels, const int32_t* d_counts, int32_t B,
+                                  int32_t max_boxes, float ign_thresh, float* d_loc, float* d_obj, int32_t* d_cls,
+                                  float* d_ign, void* stream);
+/* byolo_loss = lib_yolo/layers.py:126-188 `loss_tf` for ONE detection layer on its raw output d_raw [S,lh,lw,pitch]
+ * (pitch = floats per cell, 0 = dense; the library's own storage pads, see byolo_layer_output), split as
+ * lib_yolo/layers.py:11-84 does: kind BYOLO_DET_STANDARD (loc 4, obj, cls C per prior) or BYOLO_DET_ALEATORIC (loc 4,
+ * log_loc_var 4, obj, log_obj_stddev, cls C, log_cls_stddev C); aleatoric_loss as the reference's flag (lib_yolo/layers.py:150-153,
+ * log variance clipped to [-40, 40]).  Ground truth as byolo_encode_gt lays it out: pointers at the layer's first prior box,
+ * gt_stride = prior boxes between consecutive images (N of byolo_encode_gt, or lh * lw * 3 for per-layer arrays).
+ * d_loss[3] (double) = loc, obj, cls: sum / (2 S), sum / S, sum / S.  d_grad (or NULL) [S,lh,lw,grad_pitch] receives
+ * d(loc + obj + cls) / d(raw) -- what lib_yolo/train.py:88 `optimizer.minimize` would send into the network.  Terms are
+ * float32 like the graph's, sums double in a fixed order: results are deterministic.  d_workspace >= byolo_loss_workspace_bytes(). */
+BYOLO_API size_t  byolo_loss_workspace_bytes(void);
+BYOLO_API int32_t byolo_loss(byolo_t* h, int32_t kind, int32_t aleatoric_loss, int32_t cls_cnt, const float* d_raw, int32_t pitch,
+                             int32_t S, int32_t lh, int32_t lw, const float* d_gt_loc, const float* d_gt_obj,
+                             const int32_t* d_gt_cls, const float* d_gt_ign, int64_t gt_stride, double* d_loss,
+                             float* d_grad, int32_t grad_pitch, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- synthetic-weight support: data-dependent BN initialisation (no reference counterpart;
  * replaces "train the network" for benchmarking with random-init weights): runs the graph on

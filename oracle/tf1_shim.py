@@ -477,7 +477,65 @@ def _convert_image_dtype(image, dtype, saturate=False):
 
 
 def _constant(v, dtype=None):
-    return Tensor(torch.as_tensor(v))
+    t = torch.as_tensor(v)
+    if dtype is not None and (t.is_floating_point() or dtype is _FLOAT32):
+        t = t.to(_dt(dtype))          # tf.constant(x, dtype=tf.float32): "float32" of the graph = the working precision
+    return Tensor(t)
+
+
+# ---- symbols used only by the training side (lib_yolo/tfdata.py encode_boxes, lib_yolo/layers.py loss_tf; row f4) ----
+def _zeros(shape, dtype=None):
+    return Tensor(torch.zeros([int(s) for s in shape], dtype=_dt(dtype)))
+
+
+def _where(cond, x, y):
+    return Tensor(torch.where(_T(cond), _T(x), _T(y)))
+
+
+def _binary(fn):
+    def f(a, b, name=None):
+        a, b = _T(a), _T(b)
+        if a.is_floating_point() and not b.is_floating_point():
+            b = b.to(a.dtype)
+        elif b.is_floating_point() and not a.is_floating_point():
+            a = a.to(b.dtype)
+        elif a.is_floating_point() and b.is_floating_point() and a.dtype != b.dtype:
+            d = a.dtype if a.dim() >= b.dim() else b.dtype       # a Python scalar follows the tensor it meets
+            a, b = a.to(d), b.to(d)
+        return Tensor(fn(a, b))
+    return f
+
+
+def _sigmoid_cross_entropy_with_logits(labels=None, logits=None, name=None):
+    """tf.nn.sigmoid_cross_entropy_with_logits (documented formula): max(x, 0) - x * z + log(1 + exp(-|x|))."""
+    x, z = _T(logits), _T(labels)
+    return Tensor(torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-torch.abs(x))))
+
+
+def _sparse_softmax_cross_entropy_with_logits(labels=None, logits=None, name=None):
+    """tf.nn.sparse_softmax_cross_entropy_with_logits: -log_softmax(logits)[label] along the last axis."""
+    x, l = _T(logits), _T(labels).long()
+    ls = torch.log_softmax(x, dim=-1)
+    return Tensor(-torch.gather(ls, -1, l.unsqueeze(-1)).squeeze(-1))
+
+
+class _Losses:
+    """tf.losses: the LOSSES collection of the default graph."""
+
+    def __init__(self):
+        self.items = []
+
+    def add_loss(self, loss, loss_collection=None):
+        self.items.append(loss)
+
+    def get_total_loss(self, add_regularization_losses=True, name=None):
+        t = self.items[0]
+        for l in self.items[1:]:
+            t = t + l
+        return t
+
+    def get_regularization_loss(self, name=None):
+        return Tensor(torch.zeros((), dtype=STATE.dtype))
 
 
 def _while_loop(cond, body, loop_vars, shape_invariants=None, **kw):
@@ -542,11 +600,23 @@ def build_module():
     tf.ones, tf.ones_like, tf.zeros_like = _ones, _ones_like, _zeros_like
     tf.reshape, tf.gather, tf.constant, tf.cast = _reshape, _gather, _constant, _cast
     tf.while_loop = _while_loop
+    # lib_yolo/tfdata.py, lib_yolo/layers.py loss_tf
+    tf.zeros, tf.where = _zeros, _where
+    tf.greater_equal, tf.less_equal = _binary(lambda a, b: a >= b), _binary(lambda a, b: a <= b)
+    tf.greater, tf.less = _binary(lambda a, b: a > b), _binary(lambda a, b: a < b)
+    tf.logical_and = lambda a, b: Tensor(torch.logical_and(_T(a), _T(b)))
+    tf.maximum, tf.minimum = _binary(torch.maximum), _binary(torch.minimum)
+    tf.div, tf.add = _binary(lambda a, b: a / b), _binary(lambda a, b: a + b)
+    tf.reduce_max = lambda x, axis=None: Tensor(torch.max(_T(x))) if axis is None else Tensor(torch.amax(_T(x), dim=axis))
+    tf.nn.sigmoid_cross_entropy_with_logits = _sigmoid_cross_entropy_with_logits
+    tf.nn.sparse_softmax_cross_entropy_with_logits = _sparse_softmax_cross_entropy_with_logits
+    tf.losses = _Losses()
+    tf.summary = types.SimpleNamespace(scalar=lambda name, value: None)
     # vis_uncertainty.py
     tf.uint8 = _UINT8
     tf.contrib.distributions = types.SimpleNamespace(percentile=_percentile)
     tf.reduce_min = lambda x, axis=None: Tensor(torch.min(_T(x))) if axis is None else Tensor(torch.amin(_T(x), dim=axis))
-    tf.clip_by_value = lambda x, lo, hi: Tensor(torch.clamp(_T(x), lo, hi))
+    tf.clip_by_value = lambda x, clip_value_min, clip_value_max: Tensor(torch.clamp(_T(x), clip_value_min, clip_value_max))
     tf.to_int32 = lambda x: Tensor(_T(x).to(torch.int32))
     tf.round = lambda x: Tensor(torch.round(_T(x)))                  # half to even, like tf.round
     tf.image.convert_image_dtype = _convert_image_dtype
@@ -570,6 +640,7 @@ def install(dtype=torch.float32, param_provider=None, seed=0, drop_form="div", s
         sys.modules["tensorflow"] = tf
     if "cv2" not in sys.modules:
         sys.modules["cv2"] = types.ModuleType("cv2")
+    tf.losses.items = []                  # a fresh LOSSES collection per graph
     return tf
 
 

@@ -96,3 +96,30 @@ def test_injected_masks_mean_the_same_in_the_reference_graph_and_the_restatement
     with torch.no_grad():
         b2, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params), imgs, variant, T=T, seed=555, masks=other)
     assert np.abs(b2.numpy() - boxes.numpy()).max() > 1e-3
+
+
+def test_ground_truth_encoding_and_loss_restatement_equal_the_reference_functions():
+    """Row f4: oracle/train_ref.py against the reference's `tfdata.encode_boxes` / `layers.loss_tf`, live, on another image size,
+    another prior table, other boxes and raw tensors than the committed fixture (tests/golden/loss_gt.npz)."""
+    from oracle import make_golden_loss as mgl, train_ref
+    ryolo, rdata, rtfdata, rlayers = mgl.import_training_side()
+    rng = np.random.default_rng(99)
+    hw = (96, 160)
+    priors = ryolo.CITY_PERSONS_9_PRIORS
+    flat = [(p.h, p.w) for s in (32, 16, 8) for p in priors[s]]
+    bb, lab = mgl.boxes_for(rng, 9, hw[0] // 16, hw[1] // 16, flat)
+    ref = mgl.run_reference_encode(rdata, rtfdata, hw, priors, bb, lab, torch.float32)
+    layers = [(hw[0] // s, hw[1] // s, [(p.h, p.w) for p in priors[s]]) for s in (32, 16, 8)]
+    enc = train_ref.encode_boxes(bb, lab, layers, mgl.IGN)
+    for k in range(3):
+        for n in ("obj", "cls", "ign"):
+            assert np.array_equal(enc[k][n], ref[k][n]), (k, n)
+        assert_close(enc[k]["loc"], ref[k]["loc"], "loc %d" % k, rtol=1e-6, atol=1e-6)
+    assert sum(int(e["obj"].sum()) for e in enc) >= 9
+    for aleatoric, aleatoric_loss in ((False, False), (True, False), (True, True)):
+        for k, (lh, lw, _) in enumerate(layers):
+            raw = (rng.standard_normal((3, lh, lw, 3 * (14 if aleatoric else 7))) * 2.0).astype(np.float32)
+            gt = {n: np.stack([enc[k][n]] * 3) for n in ("loc", "obj", "cls", "ign")}
+            want = mgl.run_reference_loss(rlayers, raw, gt, 2, aleatoric, aleatoric_loss, torch.float64)
+            l = train_ref.loss(raw, gt, 2, aleatoric, aleatoric_loss)
+            assert_close(np.asarray([l["loc"], l["obj"], l["cls"]]), want, "loss layer %d" % k, rtol=1e-12, atol=1e-12)
