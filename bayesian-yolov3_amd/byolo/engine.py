@@ -272,8 +272,8 @@ class Engine:
         inference driver and bench.py do).  The fp32 mode never waits.
 
         first_image: position of img[0] in the logical batch (a shard of a data-parallel batch, a sub-batch): the
-        dropout masks are those the unsplit batch would draw.  Batches beyond max_images(T) are run as
-        consecutive sub-batches with exactly that mechanism, so the result does not depend on the split."""
+        dropout masks are those the unsplit batch would draw.  Batches beyond max_images(T) are run by byolo_forward itself as
+        consecutive pieces with exactly that mechanism, so the result does not depend on the cut."""
         torch = _torch()
         self._check_img(img)
         B = int(img.shape[0])
@@ -281,22 +281,8 @@ class Engine:
         if cap_b < 1:
             raise ValueError("T=%d at %dx%d: one image's stacked activation exceeds the 3 GiB a convolution source may "
                              "span (32-bit buffer offsets); lower T or the image size" % (T, self.cfg.img_h, self.cfg.img_w))
-        if B > cap_b:
-            N, D = self.num_boxes()
-            res = dict(out) if out is not None else {}
-            if want_boxes and res.get("boxes") is None:
-                res["boxes"] = torch.empty((B, N, D), dtype=torch.float32, device=img.device)
-            if want_nms and res.get("rows") is None:
-                res["rows"] = torch.empty((B, self.out_cap, D), dtype=torch.float32, device=img.device)
-                res["kept"] = torch.empty((B, self.out_cap), dtype=torch.int32, device=img.device)
-                res["count"] = torch.empty((B, 2), dtype=torch.int32, device=img.device)
-            for lo in range(0, B, cap_b):
-                hi = min(B, lo + cap_b)
-                sub = {k: v[lo:hi] for k, v in res.items() if v is not None}
-                assert mask_bits is None, "injected masks describe ONE byolo_forward call: keep B <= max_images(T)"
-                self.forward(img[lo:hi], T=T, seed=seed, dropout_on=dropout_on, want_boxes=want_boxes, want_nms=want_nms,
-                             out=sub, slot=slot, first_image=first_image + lo)
-            return dict(boxes=res.get("boxes"), rows=res.get("rows"), kept=res.get("kept"), count=res.get("count"))
+        if B > cap_b and mask_bits is not None:
+            raise ValueError("injected masks describe ONE piece of a forward: keep B <= max_images(T) = %d" % cap_b)
         check(self._h, lib.byolo_set_first_image(self._h, int(first_image)))
         ws = self._workspace(B, T, slot)
         self._last_ws = ws                                # byolo_layer_output points into the last forward's workspace

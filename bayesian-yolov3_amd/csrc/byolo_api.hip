@@ -1178,6 +1178,19 @@ extern "C" int32_t byolo_num_boxes(const byolo_t* h, int64_t* n, int32_t* d) {
     return BYOLO_OK;
 }
 
+// images one launch sequence may carry at this T (byolo_max_images): 32-bit source offsets and pixel counts
+static int64_t piece_cap(const byolo_t* h, int32_t T) {
+    uint64_t per_image = (uint64_t)h->cfg.img_h * h->cfg.img_w * h->cfg.img_c * 4;      // bytes per image of the largest tensor
+    int64_t rows = 0;                                                                  // pixels per image of the largest layer
+    for (const auto& l : h->layers) {
+        const uint64_t s = l.stacked ? (uint64_t)T : 1;
+        if (l.materialized) per_image = std::max(per_image, s * l.H * l.W * l.C * 4);
+        rows = std::max<int64_t>(rows, (int64_t)s * l.H * l.W);
+    }
+    const uint64_t by_bytes = CONV_MAX_SRC_BYTES / per_image, by_rows = (((uint64_t)1 << 31) - 1) / (uint64_t)rows;
+    return (int64_t)std::min<uint64_t>(std::min(by_bytes, by_rows), 1 << 20);
+}
+
 static int32_t check_run(byolo_t* h, int32_t B, int32_t T, const char* what, bool need_device = true) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "%s: null handle", what);
     if (need_device && !h->finalized) return fail(h, BYOLO_ERR_STATE, "%s: call byolo_finalize first", what);
@@ -1197,6 +1210,18 @@ static int32_t check_run(byolo_t* h, int32_t B, int32_t T, const char* what, boo
 }
 
 extern "C" int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t* out) {
+    if (h && B >= 1 && T >= 1) {                       // a batch beyond byolo_max_images runs in pieces (byolo_forward): the largest piece's arena
+        if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
+        const int64_t cap = piece_cap(h, T);
+        if (cap >= 1 && B > cap) {
+            if (!out) return fail(h, BYOLO_ERR_ARG, "byolo_workspace_bytes: null out");
+            size_t a = 0, b = 0;
+            int32_t rc = byolo_workspace_bytes(h, (int32_t)cap, T, &a); if (rc) return rc;
+            if (B % cap) { rc = byolo_workspace_bytes(h, (int32_t)(B % cap), T, &b); if (rc) return rc; }
+            *out = std::max(a, b);
+            return BYOLO_OK;
+        }
+    }
     int32_t rc = check_run(h, B, T, "byolo_workspace_bytes", false); if (rc) return rc;
     if (!out) return fail(h, BYOLO_ERR_ARG, "byolo_workspace_bytes: null out");
     // the plan of a call with injected dropout masks (byolo_forward's d_mask_bits) differs in the fp32 mode (64-wide tiles, other
@@ -1532,9 +1557,44 @@ extern "C" int32_t byolo_normalize_u8(byolo_t* h, const uint8_t* d_u8, int64_t n
 
 extern "C" const char* byolo_precision_note(const byolo_t* h) { return h ? h->prec_note.c_str() : ""; }
 
+static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
+                             const uint32_t* d_mask_bits, void* d_workspace, size_t workspace_bytes, float* d_boxes, float* d_rows,
+                             int32_t* d_kept, int32_t* d_count, void* stream);
+
+// A batch beyond byolo_max_images(h, T) -- the convolutions address their sources with 32-bit byte offsets -- runs as consecutive
+// pieces of at most that many images in the SAME workspace: images are independent end to end (the NMS is per image) and every
+// piece draws the dropout masks of its position in the logical batch (first_image), so the result does not depend on the cut.
 extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
                                  const uint32_t* d_mask_bits, void* d_workspace, size_t workspace_bytes, float* d_boxes, float* d_rows,
                                  int32_t* d_kept, int32_t* d_count, void* stream) {
+    if (h && h->finalized && B >= 1 && T >= 1) {
+        if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
+        const int64_t cap = piece_cap(h, T);
+        if (cap >= 1 && B > cap) {
+            if (d_mask_bits && dropout_on)
+                return fail(h, BYOLO_ERR_ARG, "byolo_forward: injected masks describe ONE piece: keep B <= byolo_max_images (%lld at T = %d)", (long long)cap, T);
+            const int64_t first = h->first_image;
+            const size_t img_el = (size_t)h->cfg.img_h * h->cfg.img_w * h->cfg.img_c;
+            const size_t out_cap = (size_t)h->cfg.max_out * (h->cfg.nms_mode == BYOLO_NMS_TWO_CLASS ? 2 : 1);
+            int32_t rc = BYOLO_OK;
+            for (int64_t lo = 0; lo < B && rc == BYOLO_OK; lo += cap) {
+                const int32_t n = (int32_t)std::min<int64_t>(cap, B - lo);
+                h->first_image = first + lo;
+                rc = forward_piece(h, d_img ? d_img + lo * img_el : nullptr, n, T, seed, dropout_on, nullptr, d_workspace, workspace_bytes,
+                                   d_boxes ? d_boxes + (size_t)lo * h->n_boxes * h->row_len : nullptr,
+                                   d_rows ? d_rows + (size_t)lo * out_cap * h->row_len : nullptr, d_kept ? d_kept + (size_t)lo * out_cap : nullptr,
+                                   d_count ? d_count + (size_t)lo * 2 : nullptr, stream);
+            }
+            h->first_image = first;
+            return rc;
+        }
+    }
+    return forward_piece(h, d_img, B, T, seed, dropout_on, d_mask_bits, d_workspace, workspace_bytes, d_boxes, d_rows, d_kept, d_count, stream);
+}
+
+static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
+                             const uint32_t* d_mask_bits, void* d_workspace, size_t workspace_bytes, float* d_boxes, float* d_rows,
+                             int32_t* d_kept, int32_t* d_count, void* stream) {
     int32_t rc = check_run(h, B, T, "byolo_forward"); if (rc) return rc;
     if (!d_img || !d_workspace) return fail(h, BYOLO_ERR_ARG, "byolo_forward: null image or workspace");
     if ((d_rows || d_kept || d_count) && !(d_rows && d_kept && d_count))
@@ -1968,15 +2028,7 @@ extern "C" int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images) 
     if (!h || !max_images) return BYOLO_ERR_ARG;
     if (T < 1) return fail(h, BYOLO_ERR_ARG, "byolo_max_images: T must be >= 1");
     if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
-    uint64_t per_image = (uint64_t)h->cfg.img_h * h->cfg.img_w * h->cfg.img_c * 4;      // bytes per image of the largest tensor
-    int64_t rows = 0;                                                                  // pixels per image of the largest layer
-    for (const auto& l : h->layers) {
-        const uint64_t s = l.stacked ? (uint64_t)T : 1;
-        if (l.materialized) per_image = std::max(per_image, s * l.H * l.W * l.C * 4);
-        rows = std::max<int64_t>(rows, (int64_t)s * l.H * l.W);
-    }
-    const uint64_t by_bytes = CONV_MAX_SRC_BYTES / per_image, by_rows = (((uint64_t)1 << 31) - 1) / (uint64_t)rows;
-    *max_images = (int32_t)std::min<uint64_t>(std::min(by_bytes, by_rows), 1 << 20);
+    *max_images = (int32_t)piece_cap(h, T);
     return BYOLO_OK;
 }
 

@@ -277,6 +277,59 @@ def entry_point_leg(cfg, device, n_frames=512, distinct=32, extras=True):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def training_side_leg(cfg, device, images=8, boxes_per_image=40, reps=50):
+    """SURVEY 8(f) item 4 on the benchmark's geometry: byolo_encode_gt (lib_yolo/tfdata.py:77-171) for `images` images with
+    `boxes_per_image` boxes each, and byolo_loss (lib_yolo/layers.py:126-188, aleatoric_loss, with the gradient) on the three raw
+    detection tensors of a training-mode batch (no T-stacking: S = images).  Device time per call from hipEvents over `reps`
+    back-to-back calls; `bytes` = ALGORITHMIC bytes (inputs read once + outputs written once) -> GB/s against the 8 TB/s HBM peak.
+    Both are launch-latency-sized at this batch (a few MB per call): the fraction says so."""
+    import numpy as np
+    import torch
+    from lib_yolo import yolov3, tfdata, data
+    from byolo import loss as bl, DET_ALEATORIC
+    H, W = cfg["H"], cfg["W"]
+    layers = [data.DetLayerInfo(h=H // s, w=W // s, priors=yolov3.ECP_9_PRIORS[s]) for s in (32, 16, 8)]
+    flat = [p for l in layers for p in l.priors]
+    rng = np.random.default_rng(5)
+    bb = np.zeros((images, boxes_per_image, 4), np.float32)
+    for i in range(images):
+        for j in range(boxes_per_image):
+            p = flat[rng.integers(len(flat))]
+            h, w, cy, cx = p.h * rng.uniform(0.7, 1.4), p.w * rng.uniform(0.7, 1.4), rng.uniform(0.05, 0.95), rng.uniform(0.05, 0.95)
+            bb[i, j] = [cy - h / 2, cx - w / 2, cy + h / 2, cx + w / 2]
+    lab = rng.integers(0, 2, (images, boxes_per_image)).astype(np.int32)
+    dev = "cuda:%d" % device
+    d_bb, d_lab = torch.from_numpy(bb).to(dev), torch.from_numpy(lab).to(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+
+    gt = tfdata.encode_boxes_batch(d_bb, d_lab, layers, 0.7)
+    N = gt.N
+    enc_ms = timed(lambda: tfdata.encode_boxes_batch(d_bb, d_lab, layers, 0.7))
+    enc_bytes = images * (N * 7 * 4 + boxes_per_image * 20)
+    F = 3 * 14
+    raws = [torch.randn((images, l.h, l.w, F), device=dev) for l in layers]
+    gts = gt.layers()
+    loss_ms = timed(lambda: [bl.detection_loss(r, DET_ALEATORIC, 2, g, aleatoric_loss=True, want_grad=True) for r, g in zip(raws, gts)])
+    loss_bytes = images * N // 3 * (2 * F * 4) + images * N * 7 * 4
+    return {"what": "byolo_encode_gt + byolo_loss (3 detection layers, aleatoric_loss, with gradient) at %dx%d, %d images, %d boxes each; "
+                    "host-side call overhead included" % (H, W, images, boxes_per_image),
+            "objects": int(gt.obj.sum().item()), "prior_boxes_per_image": N,
+            "encode_ms": enc_ms, "encode_algorithmic_MB": enc_bytes / 1e6, "encode_GBps": enc_bytes / (enc_ms * 1e-3) / 1e9,
+            "loss_ms_3_layers": loss_ms, "loss_algorithmic_MB": loss_bytes / 1e6, "loss_GBps": loss_bytes / (loss_ms * 1e-3) / 1e9,
+            "hbm_peak_GBps": 8000.0, "bound": "launch latency at this size (a few MB per call); HBM for large batches"}
+
+
 def time_steps(eng, x, cfg, steps, warmup, first_image=0):
     """warmup + `steps` forwards of the batch on the current stream with per-launch hipEvents; returns (seconds, {variant: [useful
     flops, ms, launches]}).  Used for the fp32_mode leg."""
@@ -651,6 +704,11 @@ def main():
                     line["entry_point_reference_default"] = ep6
                 except Exception as e:
                     line["entry_point_reference_default"] = {"img_s": None, "error": repr(e)}
+        if world == 1 and not args.no_other_configs and not args.batch and args.scaling == "weak":
+            try:
+                line["training_side"] = training_side_leg(cfg, device)
+            except Exception as e:
+                line["training_side"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"], o_rows, o_kept = cpu_baseline(cfg, eng.get_params())

@@ -158,7 +158,11 @@ BYOLO_API int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t
  *   stacked part of the graph; byolo_set_first_image does not enter), 1 = keep, layer after layer at the bit offsets of
  *   byolo_mask_layout.
  * Numeric status (split precision): unless byolo_set_async(h, 1), the call waits for the stream and returns
- *   BYOLO_ERR_RANGE -- never rows of inf / NaN -- when an activation left the split-f16 range; outputs are then undefined. */
+ *   BYOLO_ERR_RANGE -- never rows of inf / NaN -- when an activation left the split-f16 range; outputs are then undefined.
+ * Any B: a batch beyond byolo_max_images(h, T) runs inside this call as consecutive pieces of at most that many images in the
+ *   same workspace (byolo_workspace_bytes sizes it for the largest piece), each drawing the dropout masks of its position in
+ *   the batch -- the result does not depend on the cut (images are independent; the NMS is per image).  Injected masks
+ *   (d_mask_bits) describe one piece: with them B must not exceed byolo_max_images.  byolo_layer_output then shows the LAST piece. */
 BYOLO_API int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
                       const uint32_t* d_mask_bits, void* d_workspace, size_t workspace_bytes,
                       float* d_boxes, float* d_rows, int32_t* d_kept, int32_t* d_count, void* stream);
@@ -182,8 +186,9 @@ BYOLO_API int32_t byolo_clear_status(byolo_t* h, void* stream);
  * every call where its first image sits in the logical batch: image j of the call then draws the masks of image
  * first_image + j, and the pieces equal the unsplit run.  Sticky per handle; 0 after byolo_create. */
 BYOLO_API int32_t byolo_set_first_image(byolo_t* h, int64_t first_image);
-/* Largest B byolo_forward accepts at this T: the convolutions address their sources with 32-bit byte offsets,
- * so every activation tensor [B*T or B, h, w, c] must stay below 3 GiB (16 images at 608x608, T=30). */
+/* Images ONE launch sequence carries at this T: the convolutions address their sources with 32-bit byte offsets, so every
+ * activation tensor [B*T or B, h, w, c] of a piece stays below 3 GiB (18 images at 608x608, T=30).  byolo_forward cuts larger
+ * batches into such pieces itself; the number matters to a caller that injects masks or reads byolo_layer_output. */
 BYOLO_API int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images);
 /* After a forward with keep_all_outputs: device pointer + NHWC shape of layer `idx`'s output
  * (the reference's model.layers[idx], model.py:191); for detection layers the raw conv output

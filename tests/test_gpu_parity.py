@@ -586,14 +586,14 @@ def test_first_image_makes_shards_equal_the_whole_batch():
 
 
 def test_a_batch_beyond_max_images_runs_as_sub_batches(precision):
-    """The convolutions address their sources with 32-bit buffer offsets, so one byolo_forward call takes at most
-    byolo_max_images(T) images (17 at 608x608, T=30: the stacked 76x76x256 activation must stay below 3 GiB) and Engine.forward
-    runs a larger batch as consecutive sub-batches with `first_image` = their position -- the path a strong-scaling run on ONE GPU
+    """The convolutions address their sources with 32-bit buffer offsets, so one launch sequence takes at most
+    byolo_max_images(T) images (18 at 608x608, T=30: the stacked 76x76x256 activation must stay below 3 GiB) and byolo_forward
+    runs a larger batch as consecutive pieces with `first_image` = their position -- the path a strong-scaling run on ONE GPU
     (global batch 64) takes.  20 images, dropout ON: the first sub-batch (17 images: offsets with the top bit set) and the second
     (3) must produce what ONE logical batch produces: images 17 (first of the second call) and 19 (last) against the CPU oracle
     with the dropout stream of their position (sample_offset = i * T), images 0 and 16 against their own one-image calls at that
     position, and the tail of all 20 bit-exact against the oracle's NMS on the device's rows."""
-    _default_precision_only(precision, "sub-batching is host logic above the C-ABI, the same in both precisions")
+    _default_precision_only(precision, "the cut is made above the kernels (byolo_forward), the same in both precisions")
     torch = _torch()
     from byolo import synth
     from oracle import cpu_ref

@@ -4,7 +4,7 @@ with the top bit set) and compare every image with its own batch-1 run.
 
     python tools/check_big_batch.py [B]        (default 12: the 76x76x256 activation is 2.13 GB)
 
-Beyond Engine.max_images(T) (17 at this geometry) Engine.forward runs consecutive sub-batches; B = 20 checks that.
+Beyond Engine.max_images(T) (18 at this geometry) byolo_forward runs consecutive pieces; B = 20 checks that.
 """
 import os
 import sys
