@@ -81,6 +81,9 @@ struct ConvParams {
     // numeric status of the handle (byolo_status): status[0] |= 1 when a split-f16 output leaves the fp16 range,
     // status[1] = min(status[1], layer) -- the first layer it happened in; null = not tracked
     unsigned* status; int layer_idx;
+    // set by launch_conv_igemm: a split-f16 launch whose epilogue is the plain case -- no addend, residual, T-replay, raw / fp32 output
+    // or injected masks, cout % 32 == 0, 16-byte rows -- and may run the straight-line epilogue (conv_igemm.hip finish_plain)
+    int plain;
     FastDiv d_hw, d_wout, d_sdiv0, d_sdiv1, d_addT;   // Hout*Wout, Wout, sdiv0, sdiv1, addend_T
     // split-K of the last partial round of tiles (conv_plan_split): blocks [0, full_tiles) compute whole
     // tiles, the remaining split_tiles tiles are computed by ksplit K-slice blocks each
@@ -190,7 +193,7 @@ ConvSplit conv_plan_split(int M, int Npad, int KT, int tile, double tk_scale = 1
 size_t conv_split_slab_bytes(const ConvSplit& sp, int tile);
 
 // tile configuration ids
-enum : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_128x256 = 3 };      // 128x256: 8 waves, split-f16 shared-tap 3x3 only
+enum : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_128x256 = 3, TILE_256x256 = 4 };      // 128x256: 8 waves, 256x256: 4 waves of 128x128; split-f16 shared-tap 3x3 only
 int conv_tile_bn(int tile);           // BN of a tile config
 int conv_pick_tile(int N);            // tile config for cout = N
 int conv_split_tile(int tile, bool wide);  // split precision: 128-wide tiles exist for the shared-tap 3x3 and the 1x1 kernels only

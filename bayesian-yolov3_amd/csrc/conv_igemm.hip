@@ -296,6 +296,82 @@ __device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f3
     }
 }
 
+// The epilogue of the PLAIN case (ConvParams::plain, set by the launcher): a split-f16 launch without addend, residual, T-replay,
+// raw / fp32 output or injected masks, cout % 32 == 0, 16-byte rows, a whole tile -- which is every large launch of the reference's
+// models (the head convolutions, most of the backbone).  finish_tile decides all of that per channel group at run time: its
+// unrolled body carries a dozen block-uniform branches, scalar spills read back through v_readlane and hazard no-ops per group
+// -- 24 vector instructions per output value measured (PMC, round 4) where the arithmetic needs ~14, and a timing ablation without
+// the epilogue's arithmetic ran the 76x76 shared-tap launches 29 % faster: vector instructions are paid in matrix-pipe time
+// (mfma_pipe.h), the epilogue is the largest single cost after the MFMAs themselves.  Here: ONE decision per tile (DROP is a
+// template parameter), column block outermost so that one block's scale / shift vectors are live at a time, no branches inside.
+// Same arithmetic in the same order per value (epilogue.h): the same bits.
+template <int BM, int BN, int WM, int WN, bool DROP>
+__device__ __forceinline__ void finish_plain(const ConvParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const uint32_t tile_m, const uint32_t tile_n) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+    const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
+    const int nb = (int)(tile_n * BN) + wn * TN * 32 + 4 * lh;
+    float vmax = 0.f;
+    if constexpr ((ABL & 64) != 0) {              // timing ablation: no epilogue arithmetic, one 16-byte store per accumulator block
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t m = tile_m * BM + wm * TM * 32 + i * 32 + li;
+            if (m >= (uint32_t)p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][q] + acc[i][j][4 + q] + acc[i][j][8 + q] + acc[i][j][12 + q];
+                *reinterpret_cast<f32x4*>(p.dst + (size_t)m * p.ldc + nb + j * 32) = a4;
+            }
+        }
+        return;
+    }
+    uint32_t row_m[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) row_m[i] = tile_m * BM + wm * TM * 32 + i * 32 + li;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        if (nb - 4 * lh + j * 32 >= p.N) continue;                      // (wave-uniform) a column block of the padding
+        f32x4 sc4[4], sf4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            sc4[g] = *reinterpret_cast<const f32x4*>(p.scale + nb + j * 32 + 8 * g);
+            sf4[g] = *reinterpret_cast<const f32x4*>(p.shift + nb + j * 32 + 8 * g);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (row_m[i] >= (uint32_t)p.M) continue;
+            const uint64_t idx_row = p.idx_base + (uint64_t)row_m[i] * (uint64_t)p.N + (uint64_t)nb;
+            const epi::DropRow drow(idx_row, p.k1);
+            float* d = p.dst + (size_t)row_m[i] * p.ldc + nb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dn = j * 32 + 8 * g;
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
+                bool keep[4] = {true, true, true, true};
+                if constexpr (DROP) epi::keep4(drow, dn, p.k0, p.thr, keep);
+                const f32x4 v = epi::bn_act4_pk(a4, sc4[g], sf4[g], keep, slope);
+                vmax = epi::absmax4(vmax, v);
+                *reinterpret_cast<f32x4*>(d + dn) = epi::split_encode4(v);
+            }
+        }
+    }
+    if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
+}
+// the end of a tile of a split-f16 launch: the straight-line epilogue where the launch and the tile allow it
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void finish_split(const ConvParams& p, float* smem, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
+                                             const uint32_t tile_m, const uint32_t tile_n, const TileShare sh) {
+    if (p.plain && sh.counter < 0) {
+        if (p.flags & EPI_DROPOUT) finish_plain<BM, BN, WM, WN, true>(p, acc, tile_m, tile_n);
+        else finish_plain<BM, BN, WM, WN, false>(p, acc, tile_m, tile_n);
+    } else finish_tile<BM, BN, WM, WN, true>(p, smem, acc, tile_m, tile_n, sh);
+}
+
 // SPLIT: split-f16 operands and activations (mfma_pipe.h): sources, weights and residual are [4 hi | 4 lo] groups, three
 // fp16 MFMAs per product into the same fp32 accumulators; the output is encoded the same way unless EPI_F32OUT / EPI_RAW.
 template <int BM, int BN, int WM, int WN, bool FAST, bool SPLIT>
@@ -513,7 +589,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, float* smem, cons
         });
     }
 
-    finish_tile<BM, BN, WM, WN, SPLIT>(p, smem, acc, tile_m, tile_n, sh);
+    if constexpr (SPLIT) finish_split<BM, BN, WM, WN>(p, smem, acc, tile_m, tile_n, sh);
+    else finish_tile<BM, BN, WM, WN, SPLIT>(p, smem, acc, tile_m, tile_n, sh);
 }
 
 // Back-to-back fusion on the 8-wave 128 x 256 tile (ConvParams::f_wpk): the accumulators of a finished 3x3 tile -- 128 pixels x
@@ -788,9 +865,198 @@ __device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, 
                 fused = true;
             }
         }
-        if (!fused) finish_tile<BM, BN, WM, WN, true>(p, smem, acc, cur_m, cur_n, sh);
+        if (!fused) finish_split<BM, BN, WM, WN>(p, smem, acc, cur_m, cur_n, sh);
         if (!more) return;
     }
+}
+
+// The shared-tap 3x3 loop on a 256 x 256 block tile of FOUR waves, each a 128 x 128 wave tile in a 512-register wave (one wave
+// per SIMD): per MFMA a third of the LDS fragment reads and of the weight-fragment loads of the 128 x 32 wave tiles above (per
+// 16-channel step a wave reads 8 activation fragments and fetches 8 weight fragments for 48 MFMAs, against 8 + 4 for 12 there)
+// -- the matrix pipe of this precision runs against the socket's power cap, so operand traffic is clock.
+// Same stages, same K order, same MFMA order per accumulator: the same bits.
+//   * 256 accumulators per lane leave ~200 registers, so the weight fragments are double-buffered per STEP, not per K-tile: the
+//     fragments of step s of K-tile t+1 are fetched into the registers step s of K-tile t has just read (after its MFMAs in
+//     program order), one step = 48 MFMAs = ~1500 matrix-pipe cycles ahead of their use (the 1.2 MB of a 76x76 layer's weights
+//     sit in the XCD's L2); the per-row bookkeeping is packed;
+//   * whole tiles only, ONE workgroup per CU walking the tile list (as the 8-wave tile does);
+//   * the straight-line epilogue only (finish_plain: the general finish_tile keeps the scale / shift vectors of all 16 channel
+//     groups in registers -- 128 of them here -- and spilled; this library stays out of scratch memory): the
+//     planner sends only plain layers here.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_tile_kx3_big(const ConvParams& p, float* smem, const int first) {
+    using BT = SplitTileKx<BM, BN, WM, WN>;
+    constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD, A_LDX = BT::A_LDX, ROWB = BT::ROWB;
+    const BT bt(smem);
+    const uint32_t n_tiles = (uint32_t)p.Npad / BN;
+    const uint32_t hw = (uint32_t)(p.Hout * p.Wout), W = (uint32_t)p.Wout;
+    int v = first;
+    uint32_t tile_m, tile_n;
+    auto locate = [&](int logical) { tile_m = fdiv((uint32_t)logical, p.d_ntiles); tile_n = (uint32_t)logical - tile_m * n_tiles; };
+    locate(xcd_remap(v, p.full_tiles));
+
+    // 256 accumulators leave this wave ~200 other registers: the per-row bookkeeping is packed.
+    //   a_row[j]  byte offset of input pixel (y - 1, x) of staging row j (a multiple of 16) | bit ky: input row y + ky - 1 exists
+    //   fa1       LDS offset of fragment row (block 0, kx = 1); block i is i * 32 rows further, kx = 0 / 2 one row before / after --
+    //   edge      or the stage's zero row where the pixel sits in the first / last image column: bit i (kx = 0), bit 4 + i (kx = 2)
+    uint32_t a_row[A_LDX];
+    uint32_t fa1, edge;
+    int ld_ky = 0, ld_c = 0;
+    uint32_t a_soff = 0, w_soff = 0, a_delta = 0, a_bit = 0;
+    const uint32_t w_step = (uint32_t)p.Npad * BK * 4;
+    const uint32_t zrow = (uint32_t)BT::ZROW * ROWB + bt.lh * 16;
+    auto setup = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LDX; ++j) {
+            const int rho = j < A_LD ? bt.a_r + (NT / 8) * j + 1 : (bt.a_r == 0 ? 0 : (bt.a_r == 1 ? BM + 1 : -1));
+            const int64_t mm = (int64_t)tile_m * BM - 1 + rho;
+            const bool ok = rho >= 0 && mm >= 0 && mm < (int64_t)p.M;
+            const uint32_t m = ok ? (uint32_t)mm : 0u;
+            const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
+            const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
+            unsigned vm = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) vm |= ((unsigned)((int)oy + t - 1) < (unsigned)p.Hin) ? (1u << t) : 0u;
+            const uint32_t s0 = fdiv(sidx, p.d_sdiv0);
+            a_row[j] = (((((s0 * (uint32_t)p.Hs0 + (oy - 1u)) * (uint32_t)p.Ws0 + ox) * (uint32_t)p.C0) + bt.a_q * 4) * 4u) | (ok ? vm : 0u);
+        }
+        edge = 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t rr = bt.wm * TM * 32 + i * 32 + bt.li, m = tile_m * BM + rr;
+            const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
+            const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
+            (void)oy;
+            edge |= (ox > 0 ? 0u : 1u << i) | (ox + 1 < W ? 0u : 16u << i);
+        }
+        fa1 = (bt.wm * TM * 32 + bt.li + 1) * ROWB + bt.lh * 16;
+        ld_ky = 0; ld_c = 0; a_soff = 0; a_delta = 0; a_bit = 1u;
+        w_soff = tile_n * (BN / 32) * SPLIT_WBLOCK;
+    };
+    setup();
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.src0, p.src0_bytes);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wpk, p.w_bytes);
+    f32x4 a_reg[A_LDX];
+    f16x8 bf[2][TN][2];                           // weight fragments of the two steps of the K-tile in progress (set = step)
+    auto next_stage = [&]() {                     // (scalar) the stage to load: filter row ld_ky, chunk ld_c
+        a_delta = (uint32_t)(ld_ky * p.Ws0 * p.C0) * 4u; a_bit = 1u << ld_ky;              // ky >= 3 (past the end): no bit
+        a_soff = (uint32_t)ld_c * (BK * 4);
+        if (++ld_c == p.cin_tiles) { ld_c = 0; ++ld_ky; }
+    };
+    auto load_a = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LDX; ++j)
+            a_reg[j] = buffer_load_x4(a_rsrc, (a_row[j] & a_bit) ? (a_row[j] & ~15u) + a_delta : CONV_OOB_OFFSET, a_soff);
+    };
+    auto load_b_step = [&](auto s_tag) {          // step S of the K-tile at w_soff
+        constexpr int S = decltype(s_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                bf[S][j][h] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, bt.b_voff, w_soff + (uint32_t)(j * SPLIT_WBLOCK + (S * 2 + h) * 1024), 0));
+    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    f32x16 acc[TM][TN];
+    // activation fragments by HALF steps (row blocks 0-1 / 2-3 of the wave's four): while one half multiplies (24 MFMAs) the other
+    // half's fragments are read -- 32 registers instead of the 64 of two whole steps
+    constexpr int HM = TM / 2;
+    f16x8 afA[HM][2], afB[HM][2];
+    auto read_half = [&](auto ap_tag, auto s_tag, auto q_tag, auto h_tag, f16x8 (&af)[HM][2]) {
+        constexpr int AP = decltype(ap_tag)::value, S = decltype(s_tag)::value, Q = decltype(q_tag)::value, H = decltype(h_tag)::value;
+#pragma unroll
+        for (int i = 0; i < HM; ++i) {
+            const uint32_t plain = fa1 + (uint32_t)(((H * HM + i) * 32 + Q - 1) * ROWB);
+            uint32_t fa = plain;
+            if constexpr (Q != 1) fa = (edge & ((Q == 0 ? 1u : 16u) << (H * HM + i))) ? zrow : plain;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                af[i][h] = *reinterpret_cast<const f16x8*>(bt.lds + fa + (AP * BT::A_STAGE + S * 32 + h * 64));
+        }
+    };
+    // hi*hi, hi*lo, lo*hi of the half's 2 x TN blocks, product-major (per accumulator the order of mfma_step_split)
+    auto mfma_half = [&](auto h_tag, const f16x8 (&af)[HM][2], const f16x8 (&b)[TN][2]) {
+        constexpr int H = decltype(h_tag)::value;
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int i = 0; i < HM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[H * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j][pr == 2 ? 1 : 0], af[i][pr == 1 ? 1 : 0], acc[H * HM + i][j], 0, 0, 0);
+    };
+    next_stage(); load_a(); load_b_step(c0{}); load_b_step(c1{}); w_soff += w_step;
+
+    // K-tile Q (= kx) of a stage in activation buffer AP; on entry afA = rows 0-1 of its step 0, bf[0] / bf[1] = its two steps'
+    // weight fragments, w_soff at K-tile t+1
+    auto ktile = [&](auto ap_tag, auto q_tag) {
+        constexpr int AP = decltype(ap_tag)::value, Q = decltype(q_tag)::value;
+        constexpr int GH = 3 * HM * TN, NFH = 2 * HM;
+        using ap = std::integral_constant<int, AP>;
+        using apn = std::integral_constant<int, AP ^ 1>;
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(ap{}, c0{}, q_tag, c1{}, afB);
+        if constexpr (Q == 2) bt.template store_stage<AP ^ 1>(a_reg);              // the next stage (fetched in K-tile 0)
+        mfma_half(c0{}, afA, bf[0]);
+        sched_interleave<GH, 0, NFH, Q == 2 ? A_LDX : 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(ap{}, c1{}, q_tag, c0{}, afA);
+        mfma_half(c1{}, afB, bf[0]);
+        sched_interleave<GH, 0, NFH, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        load_b_step(c0{});                                                         // step 0 of K-tile t+1, into the registers just read
+        __builtin_amdgcn_sched_barrier(0);
+
+        if constexpr (Q == 0) { next_stage(); load_a(); }
+        read_half(ap{}, c1{}, q_tag, c1{}, afB);                                   // the last read of this stage's buffer (Q == 2)
+        mfma_half(c0{}, afA, bf[1]);
+        sched_interleave<GH, Q == 0 ? A_LDX : 0, NFH, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (Q == 2) __syncthreads();                                     // the next stage is visible; this one is read out
+        if constexpr (Q < 2) read_half(ap{}, c0{}, std::integral_constant<int, Q + 1>{}, c0{}, afA);
+        else read_half(apn{}, c0{}, c0{}, c0{}, afA);
+        mfma_half(c1{}, afB, bf[1]);
+        sched_interleave<GH, 0, NFH, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        load_b_step(c1{});
+        w_soff += w_step;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int NS = p.KT;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        bt.template store_stage<0>(a_reg);
+        __syncthreads();
+        read_half(c0{}, c0{}, c0{}, c0{}, afA);
+        int sg = 0;
+        for (; sg + 1 < NS; sg += 2) {
+            ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{});
+            ktile(c1{}, c0{}); ktile(c1{}, c1{}); ktile(c1{}, c2{});
+        }
+        if (sg < NS) { ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{}); }
+        __syncthreads();
+        // (no loads of the next tile in flight across the epilogue: with 256 accumulators live it has no registers to hold them)
+        if (p.flags & EPI_DROPOUT) finish_plain<BM, BN, WM, WN, true>(p, acc, tile_m, tile_n);
+        else finish_plain<BM, BN, WM, WN, false>(p, acc, tile_m, tile_n);
+        v += (int)gridDim.x;
+        if (v >= p.full_tiles) return;
+        locate(xcd_remap(v, p.full_tiles));
+        setup();
+        next_stage(); load_a(); load_b_step(c0{}); load_b_step(c1{}); w_soff += w_step;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 1) void conv_kx3_big_kernel(const ConvParams p) {      // one 512-register wave per SIMD
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < p.full_tiles) conv_tile_kx3_big<BM, BN, WM, WN>(p, smem, (int)blockIdx.x);
 }
 
 // 1x1 / stride-1 convolution over ONE plain source, split-f16: K-tiles [kt_begin, kt_end) of the tile on a UNIFORM, tail-free loop.
@@ -862,7 +1128,7 @@ __device__ __forceinline__ void conv_tile_p1(const ConvParams& p, float* smem, c
     for (; t + 1 < n; t += 2) { ktile(c0{}); ktile(c1{}); }
     if (t < n) ktile(c0{});
     __syncthreads();                              // the trailing LDS traffic of the uniform body is done before LDS is reused
-    finish_tile<BM, BN, WM, WN, true>(p, smem, acc, tile_m, tile_n, sh);
+    finish_split<BM, BN, WM, WN>(p, smem, acc, tile_m, tile_n, sh);
 }
 
 // Workgroups walk the tile list with stride gridDim.x: with gridDim.x == #tiles every workgroup owns one
@@ -936,7 +1202,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const ConvP
     }
 }
 
-int conv_tile_bn(int tile) { return tile == TILE_128x256 ? 256 : (tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32)); }
+int conv_tile_bn(int tile) { return (tile == TILE_128x256 || tile == TILE_256x256) ? 256 : (tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32)); }
 
 // split precision: the tile configuration a launch really runs on
 int conv_split_tile(int tile, bool wide) { return (tile == TILE_128x128 && !wide) ? TILE_128x64 : tile; }
@@ -963,7 +1229,7 @@ static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
 
 // workgroups of a tile configuration resident on the chip: LDS-limited (160 KB per CU; 73.7 / 55.3 / 46.1 KB per
 // workgroup), the register bound of __launch_bounds__ allows at least as many
-static int tile_slots(int tile) { return 256 * (tile == TILE_128x256 ? 1 : (tile == TILE_128x32 ? 3 : 2)); }      // (the 8-wave tile: one workgroup per CU)
+static int tile_slots(int tile) { return 256 * ((tile == TILE_128x256 || tile == TILE_256x256) ? 1 : (tile == TILE_128x32 ? 3 : 2)); }      // (the 8-wave tile: one workgroup per CU)
 
 // Tile quantisation: a launch of `tiles` equal tiles on `slots` resident workgroups takes ceil(tiles/slots)
 // rounds although the last one may be nearly empty (5416 tiles on 512 slots: 10.58 -> 11 rounds, 3.8 % of
@@ -1027,9 +1293,17 @@ size_t conv_split_slab_bytes(const ConvSplit& sp, int tile) {
     return sp.ksplit > 1 ? (size_t)sp.split_tiles * sp.ksplit * 128 * conv_tile_bn(tile) * sizeof(float) : 0;
 }
 
+// ConvParams::plain (finish_plain)
+static bool conv_epilogue_is_plain(const ConvParams& p) {
+    static const bool off = [] { const char* e = getenv("BYOLO_PLAIN_EPILOGUE"); return e && atoi(e) == 0; }();      // A/B knob: 0 = finish_tile everywhere
+    return !off && p.split == 1 && !p.addend && p.rep <= 1 && !(p.flags & (EPI_RESIDUAL | EPI_F32OUT | EPI_RAW)) && !p.mask_bits &&
+           ((p.N | p.ldc) & 3) == 0 && (p.N % 32) == 0;
+}
+
 template <int BM, int BN, int WM, int WN, bool SPLITCFG = false>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
     ConvParams q = p;
+    q.plain = conv_epilogue_is_plain(p);
     q.d_ntiles = make_fastdiv((uint32_t)(p.Npad / BN));
     q.d_cin = make_fastdiv((uint32_t)p.cin_tiles);
     q.d_ks = make_fastdiv((uint32_t)p.ksize);
@@ -1077,7 +1351,28 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
         return fast ? launch_one<BM, BN, WM, WN, true, false>(q, grid, st) : launch_one<BM, BN, WM, WN, false, false>(q, grid, st);
 }
 
+// the 256 x 256 shared-tap tile: whole tiles, one workgroup per CU walking the list; plain layers only (finish_plain)
+static hipError_t launch_kx3_big(const ConvParams& p, hipStream_t st) {
+    constexpr int BM = 256, BN = 256;
+    using BT = SplitTileKx<BM, BN, 2, 2>;
+    const bool fast = p.C1 == 0 && p.sh0 == 0 && p.ksize <= 3;
+    if (!p.split || p.kx3 != 1 || !fast || p.ksize != 3 || p.stride != 1 || (p.Npad % BN) != 0 || !conv_epilogue_is_plain(p) || p.f_wpk) return hipErrorInvalidValue;
+    ConvParams q = p;
+    q.d_ntiles = make_fastdiv((uint32_t)(p.Npad / BN));
+    q.d_cin = make_fastdiv((uint32_t)p.cin_tiles);
+    q.d_ks = make_fastdiv((uint32_t)p.ksize);
+    q.full_tiles = ((p.M + BM - 1) / BM) * (p.Npad / BN); q.split_tiles = 0; q.split_blocks = 0; q.ksplit = 1; q.sk_grid = 0;
+    q.d_ksplit = make_fastdiv(1u);
+    const int grid = std::min(q.full_tiles, 256);
+    auto k = conv_kx3_big_kernel<BM, BN, 2, 2>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), BT::LDS_BYTES, attr_done); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), BT::LDS_BYTES, st, q);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st) {
+    if (p.split && tile == TILE_256x256) return launch_kx3_big(p, st);
     if (p.split) {      // split-f16: the waves sit side by side along N (each fetches its own weight fragments, mfma_pipe.h)
         // (a 2 x 2 wave grid -- half the LDS fragment reads, every weight fragment fetched twice -- measured the same: 18.4 ms)
         switch (tile) {

@@ -47,6 +47,22 @@ __device__ __forceinline__ f32x4 bn_act4(const f32x4 a, const f32x4 sc, const f3
     }
     return v;
 }
+// the same with the fused multiply-add and the slope product as packed fp32 operations (v_pk_fma_f32 / v_pk_mul_f32: two values per
+// instruction, IEEE per element -- the bits of the scalar form); for the straight-line epilogues, which have the aligned register
+// pairs to spare (the kernels that sit at 256 registers keep the scalar form)
+__device__ __forceinline__ f32x4 bn_act4_pk(const f32x4 a, const f32x4 sc, const f32x4 sf, const bool (&keep)[4], float slope) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 v;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 a2 = {a[2 * h], a[2 * h + 1]}, f2 = {sf[2 * h], sf[2 * h + 1]};
+        const f32x2 s2 = {keep[2 * h] ? sc[2 * h] : 0.f, keep[2 * h + 1] ? sc[2 * h + 1] : 0.f};
+        const f32x2 x2 = __builtin_elementwise_fma(a2, s2, f2);
+        const f32x2 y2 = x2 * f32x2{slope, slope};
+        v[2 * h] = fmaxf(x2[0], y2[0]); v[2 * h + 1] = fmaxf(x2[1], y2[1]);
+    }
+    return v;
+}
 
 
 // max(m, |v0|, .., |v3|): two v_max3_f32 with |.| source modifiers (a NaN operand is ignored, as maxNum does)
@@ -59,13 +75,19 @@ __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
 // hi = RNE_f16(x), lo = RNE_f16(x - hi).  x is in the tensor's pre-scaled domain (byolo_api.hip folds the powers of two
 // into scale / shift); |x| >= 65520 overflows to infinity like any fp16.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// (hi as a packed pair by v_cvt_pk_f16_f32; lo = RNE_f16(x - hi) by v_fma_mix{lo,hi}_f16: fma(hi read as an f16 source, -1.0, x)
+//  computed in f32 -- exact, x - hi has at most 13 significant bits -- and rounded ONCE to f16 into the low / high half of the
+//  destination: 6 instructions per 4 values where convert / convert back / subtract / convert / pack took 13, and the same bits --
+//  tools/enc_mix_check.hip compares the two forms on 16.7 M random words with infinities, NaNs, the overflow boundary, subnormals)
 __device__ __forceinline__ f32x4 split_encode4(const f32x4 v) {
-    f16x4 hi, lo;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { hi[q] = (_Float16)v[q]; lo[q] = (_Float16)(v[q] - (float)hi[q]); }
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 h2 = __builtin_bit_cast(f32x2, hi), l2 = __builtin_bit_cast(f32x2, lo);
-    return f32x4{h2[0], h2[1], l2[0], l2[1]};
+    uint32_t h01, h23, l01, l23;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(v[0]), "v"(v[1]));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(v[2]), "v"(v[3]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(v[1]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(v[2]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(v[3]));
+    return f32x4{__builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23), __builtin_bit_cast(float, l01), __builtin_bit_cast(float, l23)};
 }
 __device__ __forceinline__ f32x4 split_decode4(const f32x4 w) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
