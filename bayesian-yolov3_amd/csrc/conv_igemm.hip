@@ -305,7 +305,9 @@ __device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f3
 // (mfma_pipe.h), the epilogue is the largest single cost after the MFMAs themselves.  Here: ONE decision per tile (DROP is a
 // template parameter), column block outermost so that one block's scale / shift vectors are live at a time, no branches inside.
 // Same arithmetic in the same order per value (epilogue.h): the same bits.
-template <int BM, int BN, int WM, int WN, bool DROP>
+// RES: + the residual (a split-f16 tensor shaped like the output: the darknet blocks' `inputs + shortcut`, lib_yolo/layers.py:505-507),
+// after the activation; a column block's residual groups of all rows are fetched before its arithmetic starts.
+template <int BM, int BN, int WM, int WN, bool DROP, bool RES = false>
 __device__ __forceinline__ void finish_plain(const ConvParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const uint32_t tile_m, const uint32_t tile_n) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -340,6 +342,15 @@ __device__ __forceinline__ void finish_plain(const ConvParams& p, f32x16 (&acc)[
             sc4[g] = *reinterpret_cast<const f32x4*>(p.scale + nb + j * 32 + 8 * g);
             sf4[g] = *reinterpret_cast<const f32x4*>(p.shift + nb + j * 32 + 8 * g);
         }
+        f32x4 res[RES ? TM : 1][4];
+        if constexpr (RES) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float* r = p.residual + (size_t)(row_m[i] < (uint32_t)p.M ? row_m[i] : 0u) * p.ldc + nb + j * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) res[i][g] = *reinterpret_cast<const f32x4*>(r + 8 * g);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (row_m[i] >= (uint32_t)p.M) continue;
@@ -354,7 +365,8 @@ __device__ __forceinline__ void finish_plain(const ConvParams& p, f32x16 (&acc)[
                 for (int q = 0; q < 4; ++q) a4[q] = acc[i][j][4 * g + q];
                 bool keep[4] = {true, true, true, true};
                 if constexpr (DROP) epi::keep4(drow, dn, p.k0, p.thr, keep);
-                const f32x4 v = epi::bn_act4_pk(a4, sc4[g], sf4[g], keep, slope);
+                f32x4 v = epi::bn_act4_pk(a4, sc4[g], sf4[g], keep, slope);
+                if constexpr (RES) v += epi::split_decode4(res[i][g]);
                 vmax = epi::absmax4(vmax, v);
                 *reinterpret_cast<f32x4*>(d + dn) = epi::split_encode4(v);
             }
@@ -363,10 +375,15 @@ __device__ __forceinline__ void finish_plain(const ConvParams& p, f32x16 (&acc)[
     if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
 }
 // the end of a tile of a split-f16 launch: the straight-line epilogue where the launch and the tile allow it
-template <int BM, int BN, int WM, int WN>
+// (WITH_RES = false: a kernel that never sees a residual -- the 8-wave tile of the head layers -- does not carry that instantiation,
+//  which cost it its last registers)
+template <int BM, int BN, int WM, int WN, bool WITH_RES = true>
 __device__ __forceinline__ void finish_split(const ConvParams& p, float* smem, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                              const uint32_t tile_m, const uint32_t tile_n, const TileShare sh) {
-    if (p.plain && sh.counter < 0) {
+    if (p.plain && sh.counter < 0 && (WITH_RES || !(p.flags & EPI_RESIDUAL))) {
+        if constexpr (WITH_RES) {
+            if (p.flags & EPI_RESIDUAL) { finish_plain<BM, BN, WM, WN, false, true>(p, acc, tile_m, tile_n); return; }      // (never with dropout: conv_epilogue_is_plain)
+        }
         if (p.flags & EPI_DROPOUT) finish_plain<BM, BN, WM, WN, true>(p, acc, tile_m, tile_n);
         else finish_plain<BM, BN, WM, WN, false>(p, acc, tile_m, tile_n);
     } else finish_tile<BM, BN, WM, WN, true>(p, smem, acc, tile_m, tile_n, sh);
@@ -611,11 +628,19 @@ __device__ __forceinline__ void fused_tail(const ConvParams& p, float* smem, f32
     asm volatile("" : "+v"(tid));                 // nothing below is computed before, or carried through, the K loop above
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     // ---- this layer's epilogue -> LDS -------------------------------------------------------------------------------------
-    {
-        const bool do_drop = p.flags & EPI_DROPOUT;
+    // (straight-line like finish_plain: the dropout decision once per tile, packed BN; rows past the end of the tensor hold
+    //  leaky(shift) -- their operand rows were zeros -- which the follower multiplies and never stores)
+    auto to_lds = [&](auto drop_tag) {
+        constexpr bool DROP = decltype(drop_tag)::value;
         const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
         const int nb = wave * 32 + 4 * lh;                    // first channel of the lane's group g = 0
         float vmax = 0.f;
+        f32x4 sc4[4], sf4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            sc4[g] = *reinterpret_cast<const f32x4*>(p.scale + nb + 8 * g);
+            sf4[g] = *reinterpret_cast<const f32x4*>(p.shift + nb + 8 * g);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t rr = (uint32_t)(i * 32 + li), m = tile_m * BM + rr;
@@ -623,16 +648,13 @@ __device__ __forceinline__ void fused_tail(const ConvParams& p, float* smem, f32
             const epi::DropRow drow(idx_row, p.k1);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int dn = 8 * g, n0 = nb + dn;
-                const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0);
-                const f32x4 sf4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
+                const int dn = 8 * g;
                 f32x4 a4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a4[q] = acc[i][0][4 * g + q];
                 bool keep[4] = {true, true, true, true};
-                if (do_drop) epi::keep4(drow, dn, p.k0, p.thr, keep);     // (injected masks: the planner does not fuse such a call)
-                f32x4 v = epi::bn_act4(a4, sc4, sf4, keep, slope);
-                if (m >= (uint32_t)p.M) v = f32x4{0.f, 0.f, 0.f, 0.f};        // rows past the end: never stored by the follower either
+                if constexpr (DROP) epi::keep4(drow, dn, p.k0, p.thr, keep);     // (injected masks: the planner does not fuse such a call)
+                const f32x4 v = epi::bn_act4_pk(a4, sc4[g], sf4[g], keep, slope);
                 vmax = epi::absmax4(vmax, v);
                 const f32x4 e = epi::split_encode4(v);
                 // K-tile `wave` of the follower's input; 4-channel group (lh + 2 g) of its 32 channels: hi at +8 q, lo at +64 + 8 q
@@ -643,7 +665,8 @@ __device__ __forceinline__ void fused_tail(const ConvParams& p, float* smem, f32
             }
         }
         if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
-    }
+    };
+    if (p.flags & EPI_DROPOUT) to_lds(std::true_type{}); else to_lds(std::false_type{});
     __syncthreads();
     // ---- the follower's GEMM: [128 x 256] x [256 x N2] ---------------------------------------------------------------------
     const BT2 bt(smem, tid);
@@ -678,9 +701,9 @@ __device__ __forceinline__ void fused_tail(const ConvParams& p, float* smem, f32
     step2(std::integral_constant<int, 15>{});
     __syncthreads();                              // every fragment is in registers: the next tile of this workgroup may stage again
     // ---- the follower's epilogue (the vector form of finish_tile: cout and row pitch are multiples of 4; no addend, no residual, one
-    // sample per row -- the planner fuses nothing else) ------------------------------------------------------------------------------
-    {
-        const bool do_drop = p.f_flags & EPI_DROPOUT, split_out = !(p.f_flags & EPI_F32OUT);
+    // sample per row -- the planner fuses nothing else); dropout and the output encoding decided once per tile ------------------------
+    auto follower = [&](auto drop_tag, auto split_tag) {
+        constexpr bool DROP = decltype(drop_tag)::value, SPLIT_OUT = decltype(split_tag)::value;
         const float slope = (p.f_flags & EPI_LEAKY) ? 0.1f : 1.f;
         const int nb = bt.wn * 32 + 4 * lh;
         float vmax = 0.f;
@@ -701,14 +724,19 @@ __device__ __forceinline__ void fused_tail(const ConvParams& p, float* smem, f32
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a4[q] = acc2[i][0][4 * g + q];
                 bool keep[4] = {true, true, true, true};
-                if (do_drop) epi::keep4(drow, dn, p.f_k0, p.f_thr, keep);
-                const f32x4 v = epi::bn_act4(a4, sc4, sf4, keep, slope);
-                if (split_out) vmax = epi::absmax4(vmax, v);
-                *reinterpret_cast<f32x4*>(d + dn) = split_out ? epi::split_encode4(v) : v;
+                if constexpr (DROP) epi::keep4(drow, dn, p.f_k0, p.f_thr, keep);
+                const f32x4 v = epi::bn_act4_pk(a4, sc4, sf4, keep, slope);
+                if constexpr (SPLIT_OUT) vmax = epi::absmax4(vmax, v);
+                if constexpr (SPLIT_OUT) *reinterpret_cast<f32x4*>(d + dn) = epi::split_encode4(v);
+                else *reinterpret_cast<f32x4*>(d + dn) = v;
             }
         }
-        if (split_out && p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.f_layer_idx); }
-    }
+        if (SPLIT_OUT && p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.f_layer_idx); }
+    };
+    if (p.f_flags & EPI_F32OUT) {                 // a detection head: plain fp32 rows
+        if (p.f_flags & EPI_DROPOUT) follower(std::true_type{}, std::false_type{}); else follower(std::false_type{}, std::false_type{});
+    } else if (p.f_flags & EPI_DROPOUT) follower(std::true_type{}, std::true_type{});
+    else follower(std::false_type{}, std::true_type{});
 }
 
 // 3x3 / stride-1 / one plain source, split-f16 (SplitTileKx in mfma_pipe.h): stages [sg_begin, sg_end) of the tile, a
@@ -865,7 +893,7 @@ __device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, 
                 fused = true;
             }
         }
-        if (!fused) finish_split<BM, BN, WM, WN>(p, smem, acc, cur_m, cur_n, sh);
+        if (!fused) finish_split<BM, BN, WM, WN, BN != 256>(p, smem, acc, cur_m, cur_n, sh);
         if (!more) return;
     }
 }
@@ -1296,8 +1324,8 @@ size_t conv_split_slab_bytes(const ConvSplit& sp, int tile) {
 // ConvParams::plain (finish_plain)
 static bool conv_epilogue_is_plain(const ConvParams& p) {
     static const bool off = [] { const char* e = getenv("BYOLO_PLAIN_EPILOGUE"); return e && atoi(e) == 0; }();      // A/B knob: 0 = finish_tile everywhere
-    return !off && p.split == 1 && !p.addend && p.rep <= 1 && !(p.flags & (EPI_RESIDUAL | EPI_F32OUT | EPI_RAW)) && !p.mask_bits &&
-           ((p.N | p.ldc) & 3) == 0 && (p.N % 32) == 0;
+    return !off && p.split == 1 && !p.addend && p.rep <= 1 && !(p.flags & (EPI_F32OUT | EPI_RAW)) && !p.mask_bits &&
+           !((p.flags & EPI_RESIDUAL) && (p.flags & EPI_DROPOUT)) && ((p.N | p.ldc) & 3) == 0 && (p.N % 32) == 0;
 }
 
 template <int BM, int BN, int WM, int WN, bool SPLITCFG = false>
@@ -1356,7 +1384,7 @@ static hipError_t launch_kx3_big(const ConvParams& p, hipStream_t st) {
     constexpr int BM = 256, BN = 256;
     using BT = SplitTileKx<BM, BN, 2, 2>;
     const bool fast = p.C1 == 0 && p.sh0 == 0 && p.ksize <= 3;
-    if (!p.split || p.kx3 != 1 || !fast || p.ksize != 3 || p.stride != 1 || (p.Npad % BN) != 0 || !conv_epilogue_is_plain(p) || p.f_wpk) return hipErrorInvalidValue;
+    if (!p.split || p.kx3 != 1 || !fast || p.ksize != 3 || p.stride != 1 || (p.Npad % BN) != 0 || !conv_epilogue_is_plain(p) || (p.flags & EPI_RESIDUAL) || p.f_wpk) return hipErrorInvalidValue;
     ConvParams q = p;
     q.d_ntiles = make_fastdiv((uint32_t)(p.Npad / BN));
     q.d_cin = make_fastdiv((uint32_t)p.cin_tiles);

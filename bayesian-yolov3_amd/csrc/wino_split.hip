@@ -214,53 +214,58 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
     }
 
     // ---- epilogue: lane = output tile li (+32 per block), 4 groups of 4 consecutive channels from 4 * lh (mfma_pipe.h) ----
-    const bool do_leaky = p.flags & EPI_LEAKY, do_drop = p.flags & EPI_DROPOUT;
-    const float slope = do_leaky ? 0.1f : 1.f;
-    const uint32_t tt = (uint32_t)(p.th * p.tw);
-    const int nb = (int)(ct * WINO_BN) + bt.wn * 32 + 4 * bt.lh;
-    float vmax = 0.f;
-    f32x4 sc4[4], sf4[4];
+    // Straight-line per dropout mode (0 none, 1 the library's hash, 2 injected bits), decided ONCE: vector instructions are paid in
+    // matrix-pipe time, and a block-uniform branch per channel group costs scalar spills and hazard no-ops (conv_igemm.hip finish_plain)
+    auto epilogue = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
+        const uint32_t tt = (uint32_t)(p.th * p.tw);
+        const int nb = (int)(ct * WINO_BN) + bt.wn * 32 + 4 * bt.lh;
+        float vmax = 0.f;
+        f32x4 sc4[4], sf4[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        sc4[g] = *reinterpret_cast<const f32x4*>(p.scale + nb + 8 * g);
-        sf4[g] = *reinterpret_cast<const f32x4*>(p.shift + nb + 8 * g);
-    }
+        for (int g = 0; g < 4; ++g) {
+            sc4[g] = *reinterpret_cast<const f32x4*>(p.scale + nb + 8 * g);
+            sf4[g] = *reinterpret_cast<const f32x4*>(p.shift + nb + 8 * g);
+        }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const uint32_t t = rt * (uint32_t)WINO_BM + (uint32_t)i * 32u + (uint32_t)bt.li;
-        if (t >= (uint32_t)p.P) continue;
-        const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
-        const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t t = rt * (uint32_t)WINO_BM + (uint32_t)i * 32u + (uint32_t)bt.li;
+            if (t >= (uint32_t)p.P) continue;
+            const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
+            const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const uint32_t oy = 2 * ty + (o >> 1), ox = 2 * tx + (o & 1);
-            if (oy >= (uint32_t)p.H || ox >= (uint32_t)p.W) continue;
-            const uint64_t pix = ((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox;
-            const uint64_t idx_row = p.idx_base + pix * (uint64_t)p.N + (uint64_t)nb;
-            const epi::DropRow drow(idx_row, p.k1);
-            float* d = p.y + (size_t)pix * p.N + nb;
+            for (int o = 0; o < 4; ++o) {
+                const uint32_t oy = 2 * ty + (o >> 1), ox = 2 * tx + (o & 1);
+                if (oy >= (uint32_t)p.H || ox >= (uint32_t)p.W) continue;
+                const uint64_t pix = ((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox;
+                const uint64_t idx_row = p.idx_base + pix * (uint64_t)p.N + (uint64_t)nb;
+                const epi::DropRow drow(idx_row, p.k1);
+                float* d = p.y + (size_t)pix * p.N + nb;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dn = 8 * g;
-                f32x4 a4;
+                for (int g = 0; g < 4; ++g) {
+                    const int dn = 8 * g;
+                    f32x4 a4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a4[q] = Y[o][i][4 * g + q];
-                bool keep[4] = {true, true, true, true};
-                if (do_drop) {
-                    if (p.mask_bits) {                                  // injected masks (conv_igemm.hip finish_tile)
+                    for (int q = 0; q < 4; ++q) a4[q] = Y[o][i][4 * g + q];
+                    bool keep[4] = {true, true, true, true};
+                    if constexpr (MODE == 2) {                              // injected masks (conv_igemm.hip finish_tile)
                         const uint32_t el = 2u * drow.gp_lo + (uint32_t)dn;
                         const uint32_t w = p.mask_bits[el >> 5] >> (el & 31u);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) keep[q] = (w >> q) & 1u;
-                    } else epi::keep4(drow, dn, p.k0, p.thr, keep);
+                    } else if constexpr (MODE == 1) epi::keep4(drow, dn, p.k0, p.thr, keep);
+                    const f32x4 v = epi::bn_act4(a4, sc4[g], sf4[g], keep, slope);
+                    vmax = epi::absmax4(vmax, v);
+                    *reinterpret_cast<f32x4*>(d + dn) = epi::split_encode4(v);
                 }
-                const f32x4 v = epi::bn_act4(a4, sc4[g], sf4[g], keep, slope);
-                vmax = epi::absmax4(vmax, v);
-                *reinterpret_cast<f32x4*>(d + dn) = epi::split_encode4(v);
             }
         }
-    }
-    if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
+        if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
+    };
+    if (!(p.flags & EPI_DROPOUT)) epilogue(std::integral_constant<int, 0>{});
+    else if (p.mask_bits) epilogue(std::integral_constant<int, 2>{});
+    else epilogue(std::integral_constant<int, 1>{});
 }
 
 bool wino_split_ok(int C, int N) { return C >= 128 && (C % 128) == 0 && N >= 128 && (N % 128) == 0; }     // K-tiles in groups of 4
