@@ -1027,20 +1027,10 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
                            : (tile == TILE_128x128 && (int64_t)((M + 127) / 128) * (s.Npad / 256) >= 4 * 256)))
             tile = TILE_128x256;
         if (p.fuse[si]) tile = TILE_128x256;                  // (decided before the arena was laid out, above)
-        // BYOLO_KX3_BIG (experiment): the 256 x 256 tile of four 512-register waves (conv_igemm.hip conv_tile_kx3_big) for unfused
-        // shared-tap launches of >= 4 rounds of 256 workgroups (2: every eligible launch)
-        { const char* kbe = getenv("BYOLO_KX3_BIG");
-          const int kx3_big = kbe ? atoi(kbe) : 0;
-          if (kx3_big && h->precision == 1 && s.kx3 && !p.fuse[si] && (s.Npad % 256) == 0 && (l.filters % 256) == 0 &&
-              s.mode == STEP_NORMAL && l.fused_residual < 0 && l.op == OP_CONV &&          // plain layers only (conv_igemm.hip finish_big)
-              (tile == TILE_128x128 || tile == TILE_128x64 || tile == TILE_128x256) &&
-              (kx3_big >= 2 || (int64_t)((M + 255) / 256) * (s.Npad / 256) >= 4 * 256))
-              tile = TILE_256x256; }
         p.tile[si] = tile;
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
         const bool sp = h->precision == 1, kx3 = sp && s.kx3;
         p.split[si] = conv_plan_split(M, s.Npad, kx3 ? KT / 3 : KT, tile, sp ? (kx3 ? 1.2 : 0.4) : 1.0);
-        if (tile == TILE_256x256) p.split[si] = ConvSplit{((M + 255) / 256) * (s.Npad / 256), 0, 0, 1};
         if (tile == TILE_128x256) p.split[si] = ConvSplit{((M + 127) / 128) * (s.Npad / 256), 0, 0, 1};      // whole tiles only: its workgroups walk the tile list (conv_igemm.hip WALK); a follower needs a finished tile
         slab = std::max(slab, conv_split_slab_bytes(p.split[si], tile));
     }
@@ -1730,7 +1720,7 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
             HIPCHK(h, launch_gemm_stream(q, st));
             continue;
         }
-        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile) + (tile == TILE_256x256 ? 5000 : (p.kx3 == 1 ? 3000 : (p.kx3 == 2 ? 2000 : (p.split ? 1000 : 0)))), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st, l.direct ? 1 : (sp.sk_grid > 0 ? -sp.sk_grid : sp.ksplit), l.direct ? 0 : sp.split_tiles); if (rc) return rc; }
+        if (per_step) { rc = mark_launch(h, s.layer, l.direct ? -1 : conv_tile_bn(tile) + (p.kx3 == 1 ? 3000 : (p.kx3 == 2 ? 2000 : (p.split ? 1000 : 0))), p.M, l.filters, (int64_t)l.ksize * l.ksize * (s.c_hi - s.c_lo), algo, st, l.direct ? 1 : (sp.sk_grid > 0 ? -sp.sk_grid : sp.ksplit), l.direct ? 0 : sp.split_tiles); if (rc) return rc; }
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, tile, st));
     }
     if (per_step) {

@@ -193,7 +193,7 @@ ConvSplit conv_plan_split(int M, int Npad, int KT, int tile, double tk_scale = 1
 size_t conv_split_slab_bytes(const ConvSplit& sp, int tile);
 
 // tile configuration ids
-enum : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_128x256 = 3, TILE_256x256 = 4 };      // 128x256: 8 waves, 256x256: 4 waves of 128x128; split-f16 shared-tap 3x3 only
+enum : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_128x256 = 3 };      // 128x256: 8 waves, split-f16 shared-tap 3x3 only
 int conv_tile_bn(int tile);           // BN of a tile config
 int conv_pick_tile(int N);            // tile config for cout = N
 int conv_split_tile(int tile, bool wide);  // split precision: 128-wide tiles exist for the shared-tap 3x3 and the 1x1 kernels only

@@ -898,195 +898,6 @@ __device__ __forceinline__ void conv_tile_kx3(const ConvParams& p, float* smem, 
     }
 }
 
-// The shared-tap 3x3 loop on a 256 x 256 block tile of FOUR waves, each a 128 x 128 wave tile in a 512-register wave (one wave
-// per SIMD): per MFMA a third of the LDS fragment reads and of the weight-fragment loads of the 128 x 32 wave tiles above (per
-// 16-channel step a wave reads 8 activation fragments and fetches 8 weight fragments for 48 MFMAs, against 8 + 4 for 12 there)
-// -- the matrix pipe of this precision runs against the socket's power cap, so operand traffic is clock.
-// Same stages, same K order, same MFMA order per accumulator: the same bits.
-//   * 256 accumulators per lane leave ~200 registers, so the weight fragments are double-buffered per STEP, not per K-tile: the
-//     fragments of step s of K-tile t+1 are fetched into the registers step s of K-tile t has just read (after its MFMAs in
-//     program order), one step = 48 MFMAs = ~1500 matrix-pipe cycles ahead of their use (the 1.2 MB of a 76x76 layer's weights
-//     sit in the XCD's L2); the per-row bookkeeping is packed;
-//   * whole tiles only, ONE workgroup per CU walking the tile list (as the 8-wave tile does);
-//   * the straight-line epilogue only (finish_plain: the general finish_tile keeps the scale / shift vectors of all 16 channel
-//     groups in registers -- 128 of them here -- and spilled; this library stays out of scratch memory): the
-//     planner sends only plain layers here.
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void conv_tile_kx3_big(const ConvParams& p, float* smem, const int first) {
-    using BT = SplitTileKx<BM, BN, WM, WN>;
-    constexpr int NT = BT::NT, TM = BT::TM, TN = BT::TN, A_LD = BT::A_LD, A_LDX = BT::A_LDX, ROWB = BT::ROWB;
-    const BT bt(smem);
-    const uint32_t n_tiles = (uint32_t)p.Npad / BN;
-    const uint32_t hw = (uint32_t)(p.Hout * p.Wout), W = (uint32_t)p.Wout;
-    int v = first;
-    uint32_t tile_m, tile_n;
-    auto locate = [&](int logical) { tile_m = fdiv((uint32_t)logical, p.d_ntiles); tile_n = (uint32_t)logical - tile_m * n_tiles; };
-    locate(xcd_remap(v, p.full_tiles));
-
-    // 256 accumulators leave this wave ~200 other registers: the per-row bookkeeping is packed.
-    //   a_row[j]  byte offset of input pixel (y - 1, x) of staging row j (a multiple of 16) | bit ky: input row y + ky - 1 exists
-    //   fa1       LDS offset of fragment row (block 0, kx = 1); block i is i * 32 rows further, kx = 0 / 2 one row before / after --
-    //   edge      or the stage's zero row where the pixel sits in the first / last image column: bit i (kx = 0), bit 4 + i (kx = 2)
-    uint32_t a_row[A_LDX];
-    uint32_t fa1, edge;
-    int ld_ky = 0, ld_c = 0;
-    uint32_t a_soff = 0, w_soff = 0, a_delta = 0, a_bit = 0;
-    const uint32_t w_step = (uint32_t)p.Npad * BK * 4;
-    const uint32_t zrow = (uint32_t)BT::ZROW * ROWB + bt.lh * 16;
-    auto setup = [&]() {
-#pragma unroll
-        for (int j = 0; j < A_LDX; ++j) {
-            const int rho = j < A_LD ? bt.a_r + (NT / 8) * j + 1 : (bt.a_r == 0 ? 0 : (bt.a_r == 1 ? BM + 1 : -1));
-            const int64_t mm = (int64_t)tile_m * BM - 1 + rho;
-            const bool ok = rho >= 0 && mm >= 0 && mm < (int64_t)p.M;
-            const uint32_t m = ok ? (uint32_t)mm : 0u;
-            const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
-            const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
-            unsigned vm = 0;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) vm |= ((unsigned)((int)oy + t - 1) < (unsigned)p.Hin) ? (1u << t) : 0u;
-            const uint32_t s0 = fdiv(sidx, p.d_sdiv0);
-            a_row[j] = (((((s0 * (uint32_t)p.Hs0 + (oy - 1u)) * (uint32_t)p.Ws0 + ox) * (uint32_t)p.C0) + bt.a_q * 4) * 4u) | (ok ? vm : 0u);
-        }
-        edge = 0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const uint32_t rr = bt.wm * TM * 32 + i * 32 + bt.li, m = tile_m * BM + rr;
-            const uint32_t sidx = fdiv(m, p.d_hw), rem = m - sidx * hw;
-            const uint32_t oy = fdiv(rem, p.d_wout), ox = rem - oy * W;
-            (void)oy;
-            edge |= (ox > 0 ? 0u : 1u << i) | (ox + 1 < W ? 0u : 16u << i);
-        }
-        fa1 = (bt.wm * TM * 32 + bt.li + 1) * ROWB + bt.lh * 16;
-        ld_ky = 0; ld_c = 0; a_soff = 0; a_delta = 0; a_bit = 1u;
-        w_soff = tile_n * (BN / 32) * SPLIT_WBLOCK;
-    };
-    setup();
-    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.src0, p.src0_bytes);
-    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.wpk, p.w_bytes);
-    f32x4 a_reg[A_LDX];
-    f16x8 bf[2][TN][2];                           // weight fragments of the two steps of the K-tile in progress (set = step)
-    auto next_stage = [&]() {                     // (scalar) the stage to load: filter row ld_ky, chunk ld_c
-        a_delta = (uint32_t)(ld_ky * p.Ws0 * p.C0) * 4u; a_bit = 1u << ld_ky;              // ky >= 3 (past the end): no bit
-        a_soff = (uint32_t)ld_c * (BK * 4);
-        if (++ld_c == p.cin_tiles) { ld_c = 0; ++ld_ky; }
-    };
-    auto load_a = [&]() {
-#pragma unroll
-        for (int j = 0; j < A_LDX; ++j)
-            a_reg[j] = buffer_load_x4(a_rsrc, (a_row[j] & a_bit) ? (a_row[j] & ~15u) + a_delta : CONV_OOB_OFFSET, a_soff);
-    };
-    auto load_b_step = [&](auto s_tag) {          // step S of the K-tile at w_soff
-        constexpr int S = decltype(s_tag)::value;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                bf[S][j][h] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, bt.b_voff, w_soff + (uint32_t)(j * SPLIT_WBLOCK + (S * 2 + h) * 1024), 0));
-    };
-    using c0 = std::integral_constant<int, 0>;
-    using c1 = std::integral_constant<int, 1>;
-    using c2 = std::integral_constant<int, 2>;
-    f32x16 acc[TM][TN];
-    // activation fragments by HALF steps (row blocks 0-1 / 2-3 of the wave's four): while one half multiplies (24 MFMAs) the other
-    // half's fragments are read -- 32 registers instead of the 64 of two whole steps
-    constexpr int HM = TM / 2;
-    f16x8 afA[HM][2], afB[HM][2];
-    auto read_half = [&](auto ap_tag, auto s_tag, auto q_tag, auto h_tag, f16x8 (&af)[HM][2]) {
-        constexpr int AP = decltype(ap_tag)::value, S = decltype(s_tag)::value, Q = decltype(q_tag)::value, H = decltype(h_tag)::value;
-#pragma unroll
-        for (int i = 0; i < HM; ++i) {
-            const uint32_t plain = fa1 + (uint32_t)(((H * HM + i) * 32 + Q - 1) * ROWB);
-            uint32_t fa = plain;
-            if constexpr (Q != 1) fa = (edge & ((Q == 0 ? 1u : 16u) << (H * HM + i))) ? zrow : plain;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                af[i][h] = *reinterpret_cast<const f16x8*>(bt.lds + fa + (AP * BT::A_STAGE + S * 32 + h * 64));
-        }
-    };
-    // hi*hi, hi*lo, lo*hi of the half's 2 x TN blocks, product-major (per accumulator the order of mfma_step_split)
-    auto mfma_half = [&](auto h_tag, const f16x8 (&af)[HM][2], const f16x8 (&b)[TN][2]) {
-        constexpr int H = decltype(h_tag)::value;
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-            for (int i = 0; i < HM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[H * HM + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j][pr == 2 ? 1 : 0], af[i][pr == 1 ? 1 : 0], acc[H * HM + i][j], 0, 0, 0);
-    };
-    next_stage(); load_a(); load_b_step(c0{}); load_b_step(c1{}); w_soff += w_step;
-
-    // K-tile Q (= kx) of a stage in activation buffer AP; on entry afA = rows 0-1 of its step 0, bf[0] / bf[1] = its two steps'
-    // weight fragments, w_soff at K-tile t+1
-    auto ktile = [&](auto ap_tag, auto q_tag) {
-        constexpr int AP = decltype(ap_tag)::value, Q = decltype(q_tag)::value;
-        constexpr int GH = 3 * HM * TN, NFH = 2 * HM;
-        using ap = std::integral_constant<int, AP>;
-        using apn = std::integral_constant<int, AP ^ 1>;
-        __builtin_amdgcn_sched_barrier(0);
-        read_half(ap{}, c0{}, q_tag, c1{}, afB);
-        if constexpr (Q == 2) bt.template store_stage<AP ^ 1>(a_reg);              // the next stage (fetched in K-tile 0)
-        mfma_half(c0{}, afA, bf[0]);
-        sched_interleave<GH, 0, NFH, Q == 2 ? A_LDX : 0>();
-        __builtin_amdgcn_sched_barrier(0);
-        read_half(ap{}, c1{}, q_tag, c0{}, afA);
-        mfma_half(c1{}, afB, bf[0]);
-        sched_interleave<GH, 0, NFH, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-        load_b_step(c0{});                                                         // step 0 of K-tile t+1, into the registers just read
-        __builtin_amdgcn_sched_barrier(0);
-
-        if constexpr (Q == 0) { next_stage(); load_a(); }
-        read_half(ap{}, c1{}, q_tag, c1{}, afB);                                   // the last read of this stage's buffer (Q == 2)
-        mfma_half(c0{}, afA, bf[1]);
-        sched_interleave<GH, Q == 0 ? A_LDX : 0, NFH, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (Q == 2) __syncthreads();                                     // the next stage is visible; this one is read out
-        if constexpr (Q < 2) read_half(ap{}, c0{}, std::integral_constant<int, Q + 1>{}, c0{}, afA);
-        else read_half(apn{}, c0{}, c0{}, c0{}, afA);
-        mfma_half(c1{}, afB, bf[1]);
-        sched_interleave<GH, 0, NFH, 0>();
-        __builtin_amdgcn_sched_barrier(0);
-        load_b_step(c1{});
-        w_soff += w_step;
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    const int NS = p.KT;
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        bt.template store_stage<0>(a_reg);
-        __syncthreads();
-        read_half(c0{}, c0{}, c0{}, c0{}, afA);
-        int sg = 0;
-        for (; sg + 1 < NS; sg += 2) {
-            ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{});
-            ktile(c1{}, c0{}); ktile(c1{}, c1{}); ktile(c1{}, c2{});
-        }
-        if (sg < NS) { ktile(c0{}, c0{}); ktile(c0{}, c1{}); ktile(c0{}, c2{}); }
-        __syncthreads();
-        // (no loads of the next tile in flight across the epilogue: with 256 accumulators live it has no registers to hold them)
-        if (p.flags & EPI_DROPOUT) finish_plain<BM, BN, WM, WN, true>(p, acc, tile_m, tile_n);
-        else finish_plain<BM, BN, WM, WN, false>(p, acc, tile_m, tile_n);
-        v += (int)gridDim.x;
-        if (v >= p.full_tiles) return;
-        locate(xcd_remap(v, p.full_tiles));
-        setup();
-        next_stage(); load_a(); load_b_step(c0{}); load_b_step(c1{}); w_soff += w_step;
-    }
-}
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 1) void conv_kx3_big_kernel(const ConvParams p) {      // one 512-register wave per SIMD
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x < p.full_tiles) conv_tile_kx3_big<BM, BN, WM, WN>(p, smem, (int)blockIdx.x);
-}
-
 // 1x1 / stride-1 convolution over ONE plain source, split-f16: K-tiles [kt_begin, kt_end) of the tile on a UNIFORM, tail-free loop.
 // These launches -- the 1x1 convolutions of the heads, the stacked half of the concat convolutions, the detection heads -- have
 // short K loops (8 .. 32 K-tiles) and stream their input from HBM, and they were waiting: for loads fetched one K-tile ahead
@@ -1230,7 +1041,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const ConvP
     }
 }
 
-int conv_tile_bn(int tile) { return (tile == TILE_128x256 || tile == TILE_256x256) ? 256 : (tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32)); }
+int conv_tile_bn(int tile) { return tile == TILE_128x256 ? 256 : (tile == TILE_128x128 ? 128 : (tile == TILE_128x64 ? 64 : 32)); }
 
 // split precision: the tile configuration a launch really runs on
 int conv_split_tile(int tile, bool wide) { return (tile == TILE_128x128 && !wide) ? TILE_128x64 : tile; }
@@ -1257,7 +1068,7 @@ static hipError_t launch_one(const ConvParams& p, int grid, hipStream_t st) {
 
 // workgroups of a tile configuration resident on the chip: LDS-limited (160 KB per CU; 73.7 / 55.3 / 46.1 KB per
 // workgroup), the register bound of __launch_bounds__ allows at least as many
-static int tile_slots(int tile) { return 256 * ((tile == TILE_128x256 || tile == TILE_256x256) ? 1 : (tile == TILE_128x32 ? 3 : 2)); }      // (the 8-wave tile: one workgroup per CU)
+static int tile_slots(int tile) { return 256 * (tile == TILE_128x256 ? 1 : (tile == TILE_128x32 ? 3 : 2)); }      // (the 8-wave tile: one workgroup per CU)
 
 // Tile quantisation: a launch of `tiles` equal tiles on `slots` resident workgroups takes ceil(tiles/slots)
 // rounds although the last one may be nearly empty (5416 tiles on 512 slots: 10.58 -> 11 rounds, 3.8 % of
@@ -1379,28 +1190,7 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
         return fast ? launch_one<BM, BN, WM, WN, true, false>(q, grid, st) : launch_one<BM, BN, WM, WN, false, false>(q, grid, st);
 }
 
-// the 256 x 256 shared-tap tile: whole tiles, one workgroup per CU walking the list; plain layers only (finish_plain)
-static hipError_t launch_kx3_big(const ConvParams& p, hipStream_t st) {
-    constexpr int BM = 256, BN = 256;
-    using BT = SplitTileKx<BM, BN, 2, 2>;
-    const bool fast = p.C1 == 0 && p.sh0 == 0 && p.ksize <= 3;
-    if (!p.split || p.kx3 != 1 || !fast || p.ksize != 3 || p.stride != 1 || (p.Npad % BN) != 0 || !conv_epilogue_is_plain(p) || (p.flags & EPI_RESIDUAL) || p.f_wpk) return hipErrorInvalidValue;
-    ConvParams q = p;
-    q.d_ntiles = make_fastdiv((uint32_t)(p.Npad / BN));
-    q.d_cin = make_fastdiv((uint32_t)p.cin_tiles);
-    q.d_ks = make_fastdiv((uint32_t)p.ksize);
-    q.full_tiles = ((p.M + BM - 1) / BM) * (p.Npad / BN); q.split_tiles = 0; q.split_blocks = 0; q.ksplit = 1; q.sk_grid = 0;
-    q.d_ksplit = make_fastdiv(1u);
-    const int grid = std::min(q.full_tiles, 256);
-    auto k = conv_kx3_big_kernel<BM, BN, 2, 2>;
-    static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), BT::LDS_BYTES, attr_done); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), BT::LDS_BYTES, st, q);
-    return hipGetLastError();
-}
-
 hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st) {
-    if (p.split && tile == TILE_256x256) return launch_kx3_big(p, st);
     if (p.split) {      // split-f16: the waves sit side by side along N (each fetches its own weight fragments, mfma_pipe.h)
         // (a 2 x 2 wave grid -- half the LDS fragment reads, every weight fragment fetched twice -- measured the same: 18.4 ms)
         switch (tile) {

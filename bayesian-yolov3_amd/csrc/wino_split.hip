@@ -203,13 +203,20 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
         run_point();
         const int I = xi >> 2, J = xi & 3;
         if constexpr (WS_ABL & 2) { if (xi != 15) continue; }
+        // as packed fp32 fused multiply-adds (v_pk_fma_f32: two accumulators per instruction, IEEE per element): fp32 vector
+        // instructions are paid in full in matrix-pipe time on this part (tools/mfma_valu_coexec_probe.hip), the fold is 128 of them per point
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const float c = cA(o >> 1, I) * cA(o & 1, J);
+            const f32x2 c2 = {c, c};
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Y[o][i][r] = __builtin_fmaf(c, M[i][0][r], Y[o][i][r]);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 y2 = __builtin_elementwise_fma(c2, f32x2{M[i][0][r], M[i][0][r + 1]}, f32x2{Y[o][i][r], Y[o][i][r + 1]});
+                    Y[o][i][r] = y2[0]; Y[o][i][r + 1] = y2[1];
+                }
         }
     }
 
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
 #pragma unroll
                         for (int q = 0; q < 4; ++q) keep[q] = (w >> q) & 1u;
                     } else if constexpr (MODE == 1) epi::keep4(drow, dn, p.k0, p.thr, keep);
-                    const f32x4 v = epi::bn_act4(a4, sc4[g], sf4[g], keep, slope);
+                    const f32x4 v = epi::bn_act4_pk(a4, sc4[g], sf4[g], keep, slope);
                     vmax = epi::absmax4(vmax, v);
                     *reinterpret_cast<f32x4*>(d + dn) = epi::split_encode4(v);
                 }

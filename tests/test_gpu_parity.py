@@ -538,34 +538,6 @@ def test_the_eight_wave_shared_tap_tile_computes_the_same_bits(monkeypatch, prec
     assert np.array_equal(wide["kept"].cpu().numpy(), base["kept"].cpu().numpy())
 
 
-def test_the_256x256_tile_computes_the_same_bits(monkeypatch, precision):
-    """BYOLO_KX3_BIG=2: every plain shared-tap 3x3 convolution with cout % 256 == 0 (the head convolutions) on the 256 x 256 tile of
-    four 512-register waves (conv_igemm.hip conv_tile_kx3_big: 128 x 128 wave tiles, weight fragments double-buffered per step,
-    activation fragments per half step, its own epilogue).  Same stages, same K order, same MFMA order per accumulator: rows and kept
-    indices bit for bit the default plan's -- with the library's dropout stream and with injected masks."""
-    if precision != "split":
-        pytest.skip("the shared-tap kernel belongs to the default precision")
-    monkeypatch.setenv("BYOLO_WINO_SPLIT", "0")            # the eligible layers would otherwise be Winograd
-    monkeypatch.setenv("BYOLO_KSPLIT", "0")
-    monkeypatch.setenv("BYOLO_STREAMK", "0")
-    monkeypatch.setenv("BYOLO_B2B", "0")
-    torch = _torch()
-    for v, B in (("bayesian_yolov3_aleatoric", 2), ("yolov3_aleatoric", 3)):
-        monkeypatch.setenv("BYOLO_KX3_BIG", "0")
-        _, base, _, _ = _run(v, B, keep_all=False)
-        monkeypatch.setenv("BYOLO_KX3_BIG", "2")
-        m, big, _, imgs = _run(v, B, keep_all=False)
-        m.engine.set_profiling(2)
-        m.run(torch.from_numpy(imgs).cuda(), seed=42)
-        torch.cuda.synchronize()
-        var = [s["variant"] for s in m.engine.step_profile()]
-        m.engine.set_profiling(0)
-        assert var.count(5256) >= 6, "the 256 x 256 tile did not run: %s" % var
-        a, b = big["boxes"].cpu().numpy(), base["boxes"].cpu().numpy()
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), v
-        assert np.array_equal(big["kept"].cpu().numpy(), base["kept"].cpu().numpy())
-
-
 def test_back_to_back_fusion_computes_the_same_bits(monkeypatch, precision):
     """BYOLO_B2B=2: every shared-tap 3x3 convolution with 256 output channels whose output is read by ONE 1x1 convolution /
     detection head runs that follower inside its own launch (conv_igemm.hip fused_tail: epilogue -> hi/lo rows in LDS -> second MFMA
