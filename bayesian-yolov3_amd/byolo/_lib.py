@@ -84,7 +84,8 @@ PROTOTYPES = {
     "byolo_copy_status": (_i32, [_vp, _vp, _vp]),
     "byolo_png_decode_batch": (_i32, [_P(_vp), _P(_sz), _i32, _i32, _i32, _i32, _vp, _i32, _P(_i32), _P(_i32)]),
     "byolo_feed_records": (_i32, [_P(_i32), _P(_i64), _P(_i64), _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _P(_i32), _P(_i32)]),
-    "byolo_encode_gt": (_i32, [_vp, _i32, _P(_i32), _P(ctypes.c_double), _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "byolo_encode_gt": (_i32, [_vp, _i32, _P(_i32), _P(ctypes.c_double), _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "byolo_encode_gt_workspace_bytes": (_sz, [_i32, _i32]),
     "byolo_loss_workspace_bytes": (_sz, []),
     "byolo_loss": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
     "byolo_format_ecp_json": (_i64, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _P(_cp), _i32, _vp, _sz]),

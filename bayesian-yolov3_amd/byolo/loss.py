@@ -77,13 +77,15 @@ def encode_gt(det_layers, boxes, labels, counts=None, ign_thresh=0.7, engine=Non
     obj = torch.empty((B, N), dtype=torch.float32, device=dev)
     ign = torch.empty((B, N), dtype=torch.float32, device=dev)
     cls = torch.empty((B, N), dtype=torch.int32, device=dev)
+    ws_bytes = int(lib.byolo_encode_gt_workspace_bytes(B, mb))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         check(_handle(engine), lib.byolo_encode_gt(
             _handle(engine), n, hw, pr, ctypes.c_void_p(boxes.data_ptr() if mb else 0), ctypes.c_void_p(labels.data_ptr() if mb else 0),
             ctypes.c_void_p(cnt.data_ptr() if cnt is not None else 0), B, mb, float(ign_thresh),
             ctypes.c_void_p(loc.data_ptr()), ctypes.c_void_p(obj.data_ptr()), ctypes.c_void_p(cls.data_ptr()),
-            ctypes.c_void_p(ign.data_ptr()), ctypes.c_void_p(stream)))
+            ctypes.c_void_p(ign.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws_bytes, ctypes.c_void_p(stream)))
     return GroundTruth(det_layers, loc, obj, cls, ign)
 
 

@@ -1845,10 +1845,13 @@ extern "C" int32_t byolo_sort_nms(byolo_t* h, const float* d_boxes, int32_t B, i
 extern "C" int32_t byolo_encode_gt(byolo_t* h, int32_t n_layers, const int32_t* layer_hw, const double* priors_hw,
                                    const float* d_boxes, const int32_t* d_labels, const int32_t* d_counts, int32_t B,
                                    int32_t max_boxes, float ign_thresh, float* d_loc, float* d_obj, int32_t* d_cls,
-                                   float* d_ign, void* stream) {
+                                   float* d_ign, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (!layer_hw || !priors_hw || !d_loc || !d_obj || !d_cls || !d_ign) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: null argument");
     if (n_layers < 1 || n_layers > 4) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: 1 .. 4 detection layers");
-    if (B < 1 || max_boxes < 0 || (max_boxes > 0 && (!d_boxes || !d_labels))) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: bad batch / boxes");
+    if (B < 1 || B > 65535 || max_boxes < 0 || (max_boxes > 0 && (!d_boxes || !d_labels))) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: bad batch / boxes");
+    if (max_boxes > 0 && (!d_workspace || workspace_bytes < encode_gt_workspace_bytes(B, max_boxes)))
+        return fail(h, BYOLO_ERR_NOMEM, "byolo_encode_gt: workspace below byolo_encode_gt_workspace_bytes(B, max_boxes)");
+    if (max_boxes > 0 && (reinterpret_cast<uintptr_t>(d_boxes) & 15) != 0) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: d_boxes must be 16-byte aligned");
     if (h) HIPCHK(h, hipSetDevice(h->device));
     EncodeGtParams p; memset(&p, 0, sizeof p);
     int64_t n = 0;
@@ -1866,11 +1869,13 @@ extern "C" int32_t byolo_encode_gt(byolo_t* h, int32_t n_layers, const int32_t* 
     }
     if (n > (int64_t)1 << 28) return fail(h, BYOLO_ERR_ARG, "byolo_encode_gt: too many prior boxes");
     p.boxes = d_boxes; p.labels = d_labels; p.counts = d_counts; p.B = B; p.max_boxes = max_boxes; p.n_layers = n_layers; p.N = (int)n;
-    p.ign_thresh = ign_thresh; p.loc = d_loc; p.obj = d_obj; p.cls = d_cls; p.ign = d_ign;
+    p.ign_thresh = ign_thresh; p.loc = d_loc; p.obj = d_obj; p.cls = d_cls; p.ign = d_ign; p.best = reinterpret_cast<unsigned*>(d_workspace);
     hipError_t e = launch_encode_gt(p, reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(h, BYOLO_ERR_HIP, "byolo_encode_gt: %s", hipGetErrorString(e));
     return BYOLO_OK;
 }
+
+extern "C" size_t byolo_encode_gt_workspace_bytes(int32_t B, int32_t max_boxes) { return encode_gt_workspace_bytes(B, max_boxes); }
 
 extern "C" size_t byolo_loss_workspace_bytes(void) { return loss_workspace_bytes() + 64; }
 

@@ -254,7 +254,9 @@ struct EncodeGtParams {
     double ph[4][3], pw[4][3];          // priors as the Python doubles of lib_yolo/yolov3.py
     float ign_thresh;
     float* loc; float* obj; int32_t* cls; float* ign;      // [B, N, 4], [B, N], [B, N], [B, N]
+    unsigned* best;          // workspace [B, max_boxes]: the maximum IoU of every box over all prior boxes, as float bits
 };
+size_t encode_gt_workspace_bytes(int B, int max_boxes);
 hipError_t launch_encode_gt(const EncodeGtParams& p, hipStream_t st);
 constexpr int LOSS_MAX_BLOCKS = 1024;
 struct LossParams {

@@ -1,7 +1,7 @@
 // train_kernels.hip -- ground-truth encoding and the training loss
 //
-//   encode_gt_kernel   lib_yolo/tfdata.py:77-171 `encode_boxes` (with `create_prior_data` :16-75 over lib_yolo/data.py:125-166
-//                      and `calc_iou` :174-189): the sequential `tf.while_loop` over an image's boxes, one workgroup per image
+//   encode_gt_*_kernel lib_yolo/tfdata.py:77-171 `encode_boxes` (with `create_prior_data` :16-75 over lib_yolo/data.py:125-166
+//                      and `calc_iou` :174-189): the sequential `tf.while_loop` over an image's boxes, one thread per prior box
 //   loss_kernel        lib_yolo/layers.py:126-188 `loss_tf` on the tensors of `split_detection(_aleatoric)` (:11-84), one
 //                      detection layer per launch; optionally d(loc + obj + cls) / d(raw output)
 //
@@ -53,67 +53,77 @@ __device__ __forceinline__ float calc_iou(const PriorBox& b, float r0, float r1,
 // lib_yolo/tfdata.py:7-11
 __device__ __forceinline__ float logit_tf(float x) { return -logf((1.f / x) - 1.f); }
 
-constexpr int ENC_THREADS = 1024;
+// Two launches, one thread per (image, prior box) in both; the prior box is computed once per thread (double arithmetic) and
+// kept in registers while the thread walks the image's boxes in order, like the reference's sequential tf.while_loop:
+//   encode_gt_max_kernel   tf.reduce_max(iou) of every box over ALL prior boxes of all layers -> best[image][box] (wave maximum,
+//                          then one atomic maximum per wave and box on the IoU's bit pattern: IoUs are >= 0, so unsigned order =
+//                          float order; NaN never wins, like a maximum over numbers)
+//   encode_gt_assign_kernel the loop body (tfdata.py:109-149) with its loop variables in registers, one store at the end
+constexpr int ENC_THREADS = 256;
 
-__global__ __launch_bounds__(ENC_THREADS) void encode_gt_kernel(const EncodeGtParams p) {
-    __shared__ float red[ENC_THREADS / 64];
-    __shared__ float best_s;
-    const int img = blockIdx.x, tid = threadIdx.x;
-    const int N = p.N;
+__global__ __launch_bounds__(ENC_THREADS) void encode_gt_max_kernel(const EncodeGtParams p) {
+    const int img = blockIdx.y, n = blockIdx.x * ENC_THREADS + threadIdx.x;
+    const int cnt = min(max(p.counts ? p.counts[img] : p.max_boxes, 0), p.max_boxes);
+    const float* bb = p.boxes + (size_t)img * p.max_boxes * 4;
+    const bool live = n < p.N;
+    const PriorBox b = prior_box(p, live ? n : 0);
+    for (int g = 0; g < cnt; ++g) {
+        const float4 r = reinterpret_cast<const float4*>(bb)[g];
+        float m = live ? calc_iou(b, r.x, r.y, r.z, r.w) : -1.f;
+        m = fmaxf(m, -1.f);                                            // NaN -> -1
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0 && m >= 0.f) atomicMax(p.best + (size_t)img * p.max_boxes + g, __float_as_uint(m));
+    }
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void encode_gt_assign_kernel(const EncodeGtParams p) {
+    const int img = blockIdx.y, n = blockIdx.x * ENC_THREADS + threadIdx.x;
+    if (n >= p.N) return;
     const int cnt = min(max(p.counts ? p.counts[img] : p.max_boxes, 0), p.max_boxes);
     const float* bb = p.boxes + (size_t)img * p.max_boxes * 4;
     const int32_t* lab = p.labels + (size_t)img * p.max_boxes;
-    float* loc = p.loc + (size_t)img * N * 4;
-    float* obj = p.obj + (size_t)img * N;
-    float* ign = p.ign + (size_t)img * N;
-    int32_t* cls = p.cls + (size_t)img * N;
-    // the loop variables of the tf.while_loop (tfdata.py:87-93) live in the output arrays of this image
-    for (int n = tid; n < N; n += ENC_THREADS) {
-        reinterpret_cast<float4*>(loc)[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-        obj[n] = 0.f; cls[n] = 0; ign[n] = 1.f;
-    }
+    const unsigned* best = p.best + (size_t)img * p.max_boxes;
+    const PriorBox b = prior_box(p, n);
+    // the loop variables of the tf.while_loop (tfdata.py:87-93)
+    float4 loc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float obj = 0.f, ign = 1.f;
+    int32_t cls = 0;
     const float eps = 1e-7f, hi = (float)(1 - 1e-7);
     for (int g = 0; g < cnt; ++g) {
-        const float r0 = bb[4 * g], r1 = bb[4 * g + 1], r2 = bb[4 * g + 2], r3 = bb[4 * g + 3];
-        // pass 1: tf.reduce_max(iou) over every prior box of every layer (NaN never wins, like a max over numbers)
-        float m = -INFINITY;
-        for (int n = tid; n < N; n += ENC_THREADS) {
-            const float iou = calc_iou(prior_box(p, n), r0, r1, r2, r3);
-            m = fmaxf(m, iou);
-        }
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if ((tid & 63) == 0) red[tid >> 6] = m;
-        __syncthreads();
-        if (tid == 0) { float b = red[0]; for (int i = 1; i < ENC_THREADS / 64; ++i) b = fmaxf(b, red[i]); best_s = b; }
-        __syncthreads();
-        const float best = best_s;
-        // pass 2: the loop body (tfdata.py:109-149)
+        const float4 r = reinterpret_cast<const float4*>(bb)[g];
+        const float r0 = r.x, r1 = r.y, r2 = r.z, r3 = r.w;
         const float w = r3 - r1, h = r2 - r0, x = (r3 + r1) / 2.f, y = (r2 + r0) / 2.f;
-        for (int n = tid; n < N; n += ENC_THREADS) {
-            const PriorBox b = prior_box(p, n);
-            const float dx = b.lw * (x - b.cx), dy = b.lh * (y - b.cy);
-            const float iou = calc_iou(b, r0, r1, r2, r3);
-            const bool om = (iou >= best) && dx >= 0.f && dx <= 1.f && dy >= 0.f && dy <= 1.f;
-            if (om) {
-                float4 l;
-                l.x = logit_tf(fminf(fmaxf(dx, eps), hi));
-                l.y = logit_tf(fminf(fmaxf(dy, eps), hi));
-                l.z = logf(fmaxf(w / b.pw, eps));
-                l.w = logf(fmaxf(h / b.ph, eps));
-                reinterpret_cast<float4*>(loc)[n] = l;
-                cls[n] = lab[g];
-                obj[n] = 1.f;
-            }
-            if (iou >= p.ign_thresh) ign[n] = 0.f;
+        const float dx = b.lw * (x - b.cx), dy = b.lh * (y - b.cy);
+        const float iou = calc_iou(b, r0, r1, r2, r3);
+        const float mx = __uint_as_float(best[g]);
+        const bool om = (iou >= mx) && dx >= 0.f && dx <= 1.f && dy >= 0.f && dy <= 1.f;
+        if (om) {
+            loc.x = logit_tf(fminf(fmaxf(dx, eps), hi));
+            loc.y = logit_tf(fminf(fmaxf(dy, eps), hi));
+            loc.z = logf(fmaxf(w / b.pw, eps));
+            loc.w = logf(fmaxf(h / b.ph, eps));
+            cls = lab[g];
+            obj = 1.f;
         }
-        __syncthreads();
+        if (iou >= p.ign_thresh) ign = 0.f;
     }
-    for (int n = tid; n < N; n += ENC_THREADS) ign[n] = fmaxf(ign[n], obj[n]);      // tfdata.py:156
+    const size_t o = (size_t)img * p.N + n;
+    reinterpret_cast<float4*>(p.loc)[o] = loc;
+    p.obj[o] = obj; p.cls[o] = cls;
+    p.ign[o] = fmaxf(ign, obj);                                        // tfdata.py:156
 }
 
+size_t encode_gt_workspace_bytes(int B, int max_boxes) { return (size_t)std::max(B, 1) * std::max(max_boxes, 1) * sizeof(unsigned); }
+
 hipError_t launch_encode_gt(const EncodeGtParams& p, hipStream_t st) {
-    if (p.B < 1 || p.N < 1 || p.n_layers < 1 || p.n_layers > 4 || p.max_boxes < 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(encode_gt_kernel, dim3((unsigned)p.B), dim3(ENC_THREADS), 0, st, p);
+    if (p.B < 1 || p.N < 1 || p.n_layers < 1 || p.n_layers > 4 || p.max_boxes < 0 || p.B > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((p.N + ENC_THREADS - 1) / ENC_THREADS), (unsigned)p.B);
+    if (p.max_boxes > 0) {
+        if (!p.best) return hipErrorInvalidValue;
+        if (hipError_t e = hipMemsetAsync(p.best, 0, encode_gt_workspace_bytes(p.B, p.max_boxes), st); e != hipSuccess) return e;
+        hipLaunchKernelGGL(encode_gt_max_kernel, grid, dim3(ENC_THREADS), 0, st, p);
+    }
+    hipLaunchKernelGGL(encode_gt_assign_kernel, grid, dim3(ENC_THREADS), 0, st, p);
     return hipGetLastError();
 }
 

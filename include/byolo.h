@@ -239,11 +239,13 @@ BYOLO_API int32_t byolo_sort_nms(byolo_t* h, const float* d_boxes, int32_t B, in
  * boxes of all layers back to back, inside a layer in the reference's [row, col, box] order (N = sum of lh * lw * 3): loc [B,N,4]
  * (logit / log targets), obj [B,N], cls [B,N] (int32), ign [B,N]; layer k's slice reshapes to the reference's
  * gt_k['loc'] [lh,lw,3,4] etc.  Later boxes overwrite earlier ones that claim the same prior box, as the reference's
- * sequential tf.while_loop does.  The masks are bit-identical to a float32 evaluation of the reference's formulas. */
+ * sequential tf.while_loop does.  The masks are bit-identical to a float32 evaluation of the reference's formulas.  d_boxes 16-byte
+ * aligned; d_workspace >= byolo_encode_gt_workspace_bytes(B, max_boxes) (every box's maximum IoU over all prior boxes). */
 BYOLO_API int32_t byolo_encode_gt(byolo_t* h, int32_t n_layers, const int32_t* layer_hw, const double* priors_hw,
                                   const float* d_boxes, const int32_t* d_labels, const int32_t* d_counts, int32_t B,
                                   int32_t max_boxes, float ign_thresh, float* d_loc, float* d_obj, int32_t* d_cls,
-                                  float* d_ign, void* stream);
+                                  float* d_ign, void* d_workspace, size_t workspace_bytes, void* stream);
+BYOLO_API size_t  byolo_encode_gt_workspace_bytes(int32_t B, int32_t max_boxes);
 /* byolo_loss = lib_yolo/layers.py:126-188 `loss_tf` for ONE detection layer on its raw output d_raw [S,lh,lw,pitch]
  * (pitch = floats per cell, 0 = dense; the library's own storage pads, see byolo_layer_output), split as
  * lib_yolo/layers.py:11-84 does: kind BYOLO_DET_STANDARD (loc 4, obj, cls C per prior) or BYOLO_DET_ALEATORIC (loc 4,
