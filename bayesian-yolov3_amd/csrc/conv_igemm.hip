@@ -1134,7 +1134,8 @@ size_t conv_split_slab_bytes(const ConvSplit& sp, int tile) {
 
 // ConvParams::plain (finish_plain)
 static bool conv_epilogue_is_plain(const ConvParams& p) {
-    static const bool off = [] { const char* e = getenv("BYOLO_PLAIN_EPILOGUE"); return e && atoi(e) == 0; }();      // A/B knob: 0 = finish_tile everywhere
+    const char* e = getenv("BYOLO_PLAIN_EPILOGUE");      // A/B knob, read per launch (tests flip it inside one process): 0 = finish_tile everywhere
+    const bool off = e && atoi(e) == 0;
     return !off && p.split == 1 && !p.addend && p.rep <= 1 && !(p.flags & (EPI_F32OUT | EPI_RAW)) && !p.mask_bits &&
            !((p.flags & EPI_RESIDUAL) && (p.flags & EPI_DROPOUT)) && ((p.N | p.ldc) & 3) == 0 && (p.N % 32) == 0;
 }

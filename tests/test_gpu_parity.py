@@ -538,6 +538,33 @@ def test_the_eight_wave_shared_tap_tile_computes_the_same_bits(monkeypatch, prec
     assert np.array_equal(wide["kept"].cpu().numpy(), base["kept"].cpu().numpy())
 
 
+def test_the_straight_line_epilogues_compute_the_same_bits(monkeypatch, precision):
+    """conv_igemm.hip finish_plain (one decision per tile, packed BN, with and without dropout / residual) against the general
+    finish_tile (BYOLO_PLAIN_EPILOGUE=0) on every launch of the three reference models, and on the Bayesian model at 320 x 320 with
+    the unfused shared-tap head layers: rows, kept indices, raw detection outputs and two backbone taps bit for bit."""
+    if precision != "split":
+        pytest.skip("the straight-line epilogues belong to the default precision")
+    torch = _torch()
+
+    def everything(plain, v, B, **kw):
+        monkeypatch.setenv("BYOLO_PLAIN_EPILOGUE", plain)
+        m, out, _, _ = _run(v, B, keep_all=True, **kw)
+        parts = [out["boxes"].cpu().numpy(), out["kept"].cpu().numpy(), out["count"].cpu().numpy()]
+        parts += [dl.raw_output.cpu().numpy() for dl in m.det_layers] + [m.engine.layer_output(i).cpu().numpy() for i in (4, 36, 74)]
+        return parts
+    for v in VARIANTS:
+        a, b = everything("0", v, 2), everything("1", v, 2)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), v
+    from byolo import synth
+    monkeypatch.setenv("BYOLO_B2B", "0")
+    monkeypatch.setenv("BYOLO_WINO_SPLIT", "0")
+    imgs = synth.synthetic_images(2, 320, 320, seed=5)
+    a, b = (everything(k, "bayesian_yolov3_aleatoric", 2, T=4, H=320, W=320, imgs=imgs) for k in ("0", "1"))
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
 def test_back_to_back_fusion_computes_the_same_bits(monkeypatch, precision):
     """BYOLO_B2B=2: every shared-tap 3x3 convolution with 256 output channels whose output is read by ONE 1x1 convolution /
     detection head runs that follower inside its own launch (conv_igemm.hip fused_tail: epilogue -> hi/lo rows in LDS -> second MFMA
