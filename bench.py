@@ -218,12 +218,10 @@ def entry_point_leg(cfg, device, n_frames=512, distinct=32, extras=True):
             b = io.BytesIO()
             Image.fromarray(f).save(b, format="PNG", compress_level=1)
             enc.append(b.getvalue())
-        shards = [[], []]
-        for i in range(n_frames):
-            shards[i % 2].append(du.make_example({"image/encoded": enc[i % distinct], "image/filename": "frame_%05d.png" % i,
-                                                  "image/height": H, "image/width": W}))
-        for k, recs in enumerate(shards):
-            du.write_tfrecords(os.path.join(tmp, "ecp-day-val-%05d-of-00002" % k), recs)
+        for k in range(2):                       # records are generated as they are written: a long run does not hold them in memory
+            du.write_tfrecords(os.path.join(tmp, "ecp-day-val-%05d-of-00002" % k),
+                               (du.make_example({"image/encoded": enc[i % distinct], "image/filename": "frame_%05d.png" % i,
+                                                 "image/height": H, "image/width": W}) for i in range(k, n_frames, 2)))
         t_gen = time.perf_counter() - t0
         threads = max(1, min(24, (os.cpu_count() or 1) - 2))             # the reference's default cpu_thread_cnt is 24
         config = {"checkpoint_path": tmp, "run_id": "bench", "step": "last", "weights": "synthetic", "full_img_size": [H, W, 3],

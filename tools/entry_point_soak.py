@@ -23,13 +23,19 @@ def main():
     a = ap.parse_args()
     import bench
     cfg = dict(bench.CONFIGS[4])
-    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
-    short = bench.entry_point_leg(cfg, 0, n_frames=256, extras=False)
-    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    import gc
+
+    def rss_now():                                # resident set NOW (ru_maxrss is a high-water mark: it cannot show that a run gave memory back)
+        return int(open("/proc/self/statm").read().split()[1]) * 4096 / 1e6
+    rss = {"start": rss_now()}
+    short = bench.entry_point_leg(cfg, 0, n_frames=512, extras=False)          # warms every pool: engine, pinned buffers, allocator arenas
+    gc.collect(); rss["after_512_frames"] = rss_now()
     long = bench.entry_point_leg(cfg, 0, n_frames=a.frames, extras=False)
-    rss2 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
-    out = {"short_run": short, "long_run": long, "max_rss_mb": {"start": rss0 / 1024.0, "after_256_frames": rss1 / 1024.0,
-                                                                 "after_%d_frames" % a.frames: rss2 / 1024.0}}
+    gc.collect(); rss["after_%d_more_frames" % a.frames] = rss_now()
+    again = bench.entry_point_leg(cfg, 0, n_frames=a.frames, extras=False)
+    gc.collect(); rss["after_another_%d_frames" % a.frames] = rss_now()
+    out = {"short_run": short, "long_run": long, "long_run_again": again, "rss_mb": rss,
+           "max_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0}
     if a.gpus2:
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BYOLO_DIST_BACKEND="gloo", BYOLO_DIST_SHARE_DEVICE="1")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
