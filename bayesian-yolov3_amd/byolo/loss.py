@@ -89,9 +89,6 @@ def encode_gt(det_layers, boxes, labels, counts=None, ign_thresh=0.7, engine=Non
     return GroundTruth(det_layers, loc, obj, cls, ign)
 
 
-_WS = {}
-
-
 def detection_loss(raw, kind, cls_cnt, gt, aleatoric_loss=False, want_grad=False, engine=None):
     """byolo_loss for one detection layer.  raw: CUDA float32 [S,lh,lw,F] (dense).  gt: a dict of GroundTruth.layer(k) or any
     dict of CUDA tensors loc [S,lh,lw,3,4], obj / ign [S,lh,lw,3], cls [S,lh,lw,3] int32.  Returns {'loc','obj','cls'} as
@@ -117,9 +114,7 @@ def detection_loss(raw, kind, cls_cnt, gt, aleatoric_loss=False, want_grad=False
     out = torch.empty(3, dtype=torch.float64, device=dev)
     grad = torch.empty_like(raw) if want_grad else None
     nbytes = int(lib.byolo_loss_workspace_bytes())
-    ws = _WS.get(dev)
-    if ws is None or ws.numel() < nbytes:
-        ws = _WS[dev] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # per call (24 KB from torch's stream-ordered pool): calls on several streams do not share partial sums
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         check(_handle(engine), lib.byolo_loss(
