@@ -89,14 +89,24 @@ struct View { Src s[2]; int n = 0; };
 //                 concat or double upsample, a view used as a residual shortcut) is copied into a tensor of its own;
 //   STEP_ADD      a residual add that cannot ride in a convolution's epilogue (its left operand is not a convolution,
 //                 or that convolution's output has other readers) runs as an element-wise kernel.
-enum StepMode { STEP_NORMAL = 0, STEP_REP = 1, STEP_PARTIAL = 2, STEP_MAIN = 3, STEP_GATHER = 4, STEP_ADD = 5 };
+// And one that the reference's Bayesian model does need (round 4): the stacked half of its two concat convolutions is an
+// UPSAMPLED tensor, and a 1x1 convolution commutes with nearest-neighbour upsampling -- its GEMM belongs at the source's
+// resolution, a quarter of the rows:
+//   STEP_PARTIAL with `low`  the stacked half, convolved per SAMPLE at the source's resolution into an auxiliary raw-accumulator
+//                 tensor [S, H/2, W/2, N] (it also owns the layer's scale / shift arrays);
+//   STEP_FINISH   output pixel (s, y, x) = epilogue(low[s, y/2, x/2] + partial[image, y, x]): an element-wise kernel
+//                 (conv_kernels.hip finish_upsampled_kernel).  The same two numbers added in the same order as STEP_MAIN's
+//                 accumulator + addend, the same epilogue arithmetic: the same bits.  BYOLO_LOWMAIN=0 keeps STEP_MAIN.
+enum StepMode { STEP_NORMAL = 0, STEP_REP = 1, STEP_PARTIAL = 2, STEP_MAIN = 3, STEP_GATHER = 4, STEP_ADD = 5, STEP_FINISH = 6 };
 struct Step {
     int layer; View in;
     int mode = STEP_NORMAL;
     bool is_conv() const { return mode <= STEP_MAIN; }
     int c_lo = 0, c_hi = 0;        // input-channel range of the layer's Cin this launch convolves
     int out_tensor = -1;           // tensor id written (layer index, or n_layers + aux index)
-    int addend_tensor = -1;        // STEP_MAIN: the PARTIAL result
+    int addend_tensor = -1;        // STEP_MAIN / STEP_FINISH: the PARTIAL result
+    bool low = false;              // STEP_PARTIAL: the stacked half at the source's resolution (per sample, output H/2 x W/2)
+    int low_tensor = -1;           // STEP_FINISH: that launch's result
     size_t w_off = 0; int Npad = 0, tile = 0;   // packed weights of this launch
     bool wino_ok = false;          // 3x3 / stride 1 over one plain source: Winograd F(2x2,3x3) is possible
     size_t wino_off = 0;           // the 16 transformed weight matrices U[xi], each packed [Cin/32][Npad][32]
@@ -105,7 +115,7 @@ struct Step {
 };
 // per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
 struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; int bm = 0, bn = 0; /* split precision: output tiles / channels per workgroup */ };
-struct AuxTensor { int H, W, C; };
+struct AuxTensor { int H, W, C; bool stacked = false; };      // stacked: one row per SAMPLE pixel (else per image pixel)
 
 struct Plan {
     int B = -1, T = -1;
@@ -588,6 +598,27 @@ static int32_t lower_once(byolo_t* h) {
                 main.in.n = 1; main.in.s[0] = st.in.s[1 - kt];
                 main.c_lo = kt == 0 ? st.in.s[0].C : 0; main.c_hi = main.c_lo + st.in.s[1 - kt].C;
                 st = main;
+                // the stacked half is an upsampled tensor and the convolution is 1x1: multiply at the source's resolution
+                // (STEP_PARTIAL with `low`), finish element-wise at the output's (STEP_FINISH)
+                const char* lme = getenv("BYOLO_LOWMAIN");
+                if ((!lme || atoi(lme) != 0) && l.ksize == 1 && l.stride == 1 && st.in.s[0].sh == 1 && st.in.s[0].layer >= 0 &&
+                    !st.in.s[0].tile && (l.H & 1) == 0 && (l.W & 1) == 0 && (l.filters & 3) == 0 && l.fused_residual < 0 && (st.in.s[0].C % 32) == 0) {
+                    Step lowst = st; lowst.mode = STEP_PARTIAL; lowst.low = true; lowst.addend_tensor = -1;
+                    lowst.in.s[0].sh = 0;
+                    h->aux.push_back({l.H / 2, l.W / 2, l.filters, true});
+                    lowst.out_tensor = n + (int)h->aux.size() - 1;
+                    h->last_use.push_back(-1);
+                    const int lidx = (int)h->steps.size();
+                    h->last_use[lowst.in.s[0].layer] = lidx;
+                    h->steps.push_back(lowst);
+                    Step fin; fin.layer = i; fin.mode = STEP_FINISH; fin.out_tensor = l.out_tensor;
+                    fin.low_tensor = lowst.out_tensor; fin.addend_tensor = part.out_tensor;
+                    fin.c_lo = st.c_lo; fin.c_hi = st.c_hi;
+                    const int fidx = (int)h->steps.size();
+                    h->last_use[fin.low_tensor] = fidx; h->last_use[fin.addend_tensor] = fidx;
+                    h->steps.push_back(fin);
+                    continue;
+                }
             }
         }
         const int step_idx = (int)h->steps.size();
@@ -722,7 +753,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
         st.w_off = off; off += align_up((size_t)K * st.Npad, 64);      // tile / Npad / wino_ok: set by lower()
         l.tile = st.tile; l.Npad = st.Npad;
         if (st.wino_ok) { st.wino_off = off; off += align_up((size_t)16 * Cs * st.Npad, 64); }
-        if (st.mode == STEP_PARTIAL) continue;                  // raw accumulators: no scale / shift
+        if (st.mode == STEP_PARTIAL && !st.low) continue;       // raw accumulators: no scale / shift (the `low` launch owns the layer's, for its STEP_FINISH)
         l.scale_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);   // readable (zeros) up to Npad
         l.shift_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
         if (l.drop_ordinal >= 0) { l.scalek_off = off; off += align_up((size_t)std::max(N, st.Npad), 64); }
@@ -860,7 +891,7 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
                     for (int xi = 0; xi < 16; ++xi) d[(size_t)xi * xi_stride] = u16[xi];
                 }
         }
-        if (st.mode == STEP_PARTIAL) continue;
+        if (st.mode == STEP_PARTIAL && !st.low) continue;
         fold_layer(h, l, sc, sf);
         if (h->precision == 1) fold_split(l, sc, sf);
         memcpy(blob.data() + l.scale_off, sc.data(), sizeof(float) * N);
@@ -902,9 +933,9 @@ static int layer_pitch(const Layer& l) { return (l.op == OP_DETECTION && !l.dire
 
 static int64_t tensor_bytes(const byolo_t* h, int id, int B, int T) {
     const int n = (int)h->layers.size();
-    if (id >= n) {                                                // auxiliary: one row per IMAGE pixel
+    if (id >= n) {                                                // auxiliary: one row per IMAGE pixel (stacked: per sample pixel)
         const AuxTensor& a = h->aux[id - n];
-        return (int64_t)align_up((size_t)((int64_t)B * a.H * a.W * a.C) * sizeof(float), 256);
+        return (int64_t)align_up((size_t)((int64_t)B * (a.stacked ? T : 1) * a.H * a.W * a.C) * sizeof(float), 256);
     }
     const Layer& l = h->layers[id];
     const int64_t S = l.stacked ? (int64_t)B * T : B;
@@ -914,9 +945,9 @@ static int64_t tensor_bytes(const byolo_t* h, int id, int B, int T) {
 // rows (M) and K-tiles of one launch -- the same arithmetic as fill_conv
 static void step_geometry(const byolo_t* h, const Step& st, int B, int T, int* M, int* KT) {
     const Layer& l = h->layers[st.layer];
-    const bool per_image = st.mode == STEP_REP || st.mode == STEP_PARTIAL;
+    const bool per_image = st.mode == STEP_REP || (st.mode == STEP_PARTIAL && !st.low);
     const int64_t S = (l.stacked && !per_image) ? (int64_t)B * T : B;
-    *M = (int)(S * l.H * l.W);
+    *M = (int)(S * (l.H >> (st.low ? 1 : 0)) * (l.W >> (st.low ? 1 : 0)));
     *KT = l.ksize * l.ksize * ((st.c_hi - st.c_lo) / 32);
 }
 
@@ -1031,6 +1062,7 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
         const bool sp = h->precision == 1, kx3 = sp && s.kx3;
         p.split[si] = conv_plan_split(M, s.Npad, kx3 ? KT / 3 : KT, tile, sp ? (kx3 ? 1.2 : 0.4) : 1.0);
+        if (s.low) p.split[si] = ConvSplit{((M + 127) / 128) * (s.Npad / conv_tile_bn(tile)), 0, 0, 1};      // whole tiles: the accumulation order of a STEP_MAIN tile
         if (tile == TILE_128x256) p.split[si] = ConvSplit{((M + 127) / 128) * (s.Npad / 256), 0, 0, 1};      // whole tiles only: its workgroups walk the tile list (conv_igemm.hip WALK); a follower needs a finished tile
         slab = std::max(slab, conv_split_slab_bytes(p.split[si], tile));
     }
@@ -1262,12 +1294,13 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.Hs0 = Hs[0]; p.Ws0 = Wsz[0]; p.Hs1 = Hs[1]; p.Ws1 = Wsz[1];
     p.sh0 = sh[0]; p.sh1 = sh[1]; p.sdiv0 = sdiv[0]; p.sdiv1 = sdiv[1];
     p.Hin = Hs[0] << sh[0]; p.Win = Wsz[0] << sh[0];
-    p.Hout = l.H; p.Wout = l.W;
+    const int lsh = st.low ? 1 : 0;                               // the `low` launch: output at the source's resolution
+    p.Hout = l.H >> lsh; p.Wout = l.W >> lsh;
     p.ksize = l.ksize; p.stride = l.stride; p.pad = l.ksize == 3 ? 1 : 0;
     // rows of this launch: MC samples for stacked layers, IMAGES for the de-duplicated launches
-    const bool per_image = st.mode == STEP_REP || st.mode == STEP_PARTIAL;
+    const bool per_image = st.mode == STEP_REP || (st.mode == STEP_PARTIAL && !st.low);
     const int64_t S = (l.stacked && !per_image) ? (int64_t)B * T : B;
-    p.M = (int)(S * l.H * l.W);
+    p.M = (int)(S * p.Hout * p.Wout);
     p.N = layer_pitch(l); p.Npad = st.Npad; p.ldc = layer_pitch(l);      // (a detection head: padded to a multiple of 4, <= Npad)
     p.cin_tiles = (st.c_hi - st.c_lo) / 32; p.KT = l.ksize * l.ksize * p.cin_tiles;
     p.wpk = dptr(h, st.w_off);
@@ -1278,7 +1311,7 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     p.src0_bytes = (uint32_t)((uint64_t)nsrc[0] * Hs[0] * Wsz[0] * Cs[0] * 4);
     p.src1_bytes = Cs[1] ? (uint32_t)((uint64_t)nsrc[1] * Hs[1] * Wsz[1] * Cs[1] * 4) : p.src0_bytes;
     p.w_bytes = (uint32_t)((uint64_t)p.KT * p.Npad * 32 * 4);
-    p.d_hw = make_fastdiv((uint32_t)(l.H * l.W)); p.d_wout = make_fastdiv((uint32_t)l.W);
+    p.d_hw = make_fastdiv((uint32_t)(p.Hout * p.Wout)); p.d_wout = make_fastdiv((uint32_t)p.Wout);
     p.d_sdiv0 = make_fastdiv((uint32_t)sdiv[0]); p.d_sdiv1 = make_fastdiv((uint32_t)sdiv[1]);
     p.rep = st.mode == STEP_REP ? T : 1;
     // matrix-pipe launches: 1 = split-f16 operands; direct launches: bit 0 = the sources are hi/lo tensors, bit 1 = so is the output
@@ -1291,6 +1324,31 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     } else { p.addend = nullptr; p.addend_T = 1; }
     p.d_addT = make_fastdiv((uint32_t)p.addend_T);
     p.status = h->precision == 1 ? h->d_status : nullptr; p.layer_idx = st.layer;
+}
+
+// STEP_FINISH: mode 0 the raw sum (calibration), 1 / 2 the layer's epilogue with fp32 / hi-lo output
+static void fill_finish(const byolo_t* h, const Step& st, char* ws, int B, int T, int mode, bool drop, const byolo_drop_keys& keys,
+                        const uint32_t* mask_bits, bool inject, FinishParams& f) {
+    const Layer& l = h->layers[st.layer];
+    memset(&f, 0, sizeof f);
+    f.low = reinterpret_cast<const float*>(ws + h->plan.off[st.low_tensor]);
+    f.part = st.addend_tensor >= 0 ? reinterpret_cast<const float*>(ws + h->plan.off[st.addend_tensor]) : nullptr;
+    f.dst = reinterpret_cast<float*>(ws + h->plan.off[st.out_tensor]);
+    f.T = l.stacked ? T : 1; f.S = B * f.T; f.H = l.H; f.W = l.W; f.N = l.filters;
+    f.mode = mode;
+    if (mode == 0) { f.scale = h->d_ones; f.shift = h->d_zeros; }
+    else {
+        f.flags = EPI_LEAKY;
+        f.scale = dptr(h, l.scale_off); f.shift = dptr(h, l.shift_off);
+        if (drop) {
+            f.flags |= EPI_DROPOUT; f.k0 = keys.k0; f.k1 = keys.k1; f.thr = keys.thr; f.mask_bits = mask_bits;
+            f.idx_base = inject ? 0 : (uint64_t)h->first_image * (uint64_t)f.T * l.H * l.W * l.filters;
+            f.scale = dptr(h, l.scalek_off);
+        }
+    }
+    f.status = h->precision == 1 ? h->d_status : nullptr; f.layer_idx = st.layer;
+    f.d_hw = make_fastdiv((uint32_t)(l.H * l.W / 4)); f.d_w = make_fastdiv((uint32_t)(l.W / 2));      // of the source's grid
+    f.d_n4 = make_fastdiv((uint32_t)(l.filters / 4)); f.d_T = make_fastdiv((uint32_t)f.T);
 }
 
 // STEP_GATHER / STEP_ADD (fill_conv has resolved the sources, the output extent and the destination)
@@ -1673,7 +1731,7 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
         // ALGORITHMIC FLOPs the step stands for (graph as written): the whole layer on all MC
         // samples for a de-duplicated launch, nothing for the auxiliary partial launch
         const int64_t S_all = l.stacked ? (int64_t)B * T : B;
-        algo = s.mode == STEP_PARTIAL ? 0.0 : 2.0 * (double)(S_all * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);
+        algo = (s.mode == STEP_PARTIAL && !s.low) ? 0.0 : 2.0 * (double)(S_all * l.H * l.W) * l.filters * (double)(l.ksize * l.ksize * l.Cin);      // (the `low` launch carries the layer's)
         return BYOLO_OK;
     };
     for (size_t si = 0; si < h->steps.size(); ++si) {
@@ -1684,6 +1742,25 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
             HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); backbone_marked = true;
         }
         ConvParams p;
+        if (s.mode == STEP_FINISH) {
+            FinishParams f;
+            byolo_drop_keys keys{0, 0, 0};
+            const bool drop = l.drop_ordinal >= 0 && dropout_on;
+            const uint32_t* bits = nullptr;
+            if (drop) {
+                keys = byolo_layer_keys(seed, (uint32_t)l.drop_ordinal, (double)h->cfg.drop_prob);
+                if (inject) {
+                    int64_t n_el = 0;
+                    const int64_t off = mask_layout(h, B, T, l.drop_ordinal, &n_el);
+                    if (n_el >= ((int64_t)1 << 32)) return fail(h, BYOLO_ERR_ARG, "byolo_forward: injected masks index a dropout tensor with 32 bits; layer '%s' has %lld elements", l.scope.c_str(), (long long)n_el);
+                    bits = d_mask_bits + off / 32;
+                }
+            }
+            fill_finish(h, s, ws, B, T, h->precision == 1 ? 2 : 1, drop, keys, bits, inject, f);
+            if (per_step) { rc = mark_launch(h, s.layer, -5, (int64_t)f.S * f.H * f.W, f.N, 0, 0.0, st); if (rc) return rc; }
+            HIPCHK(h, launch_finish_upsampled(f, st));
+            continue;
+        }
         if (!s.is_conv()) { fill_conv(h, s, d_img, ws, B, T, p); rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
         int tile = 0; double algo = 0.0;
         rc = prep(si, p, tile, algo); if (rc) return rc;
@@ -1927,16 +2004,23 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
         HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st));
     for (const Step& s : h->steps) {
         Layer& l = h->layers[s.layer];
-        ConvParams p; fill_conv(h, s, d_img, ws, B, 1, p);
-        if (!s.is_conv()) { int32_t rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
         const bool split = h->precision == 1;
+        ConvParams p;
+        if (s.mode == STEP_FINISH) {                                       // the raw sum of the two halves, then the statistics below
+            FinishParams f; fill_finish(h, s, ws, B, 1, 0, false, byolo_drop_keys{0, 0, 0}, nullptr, false, f);
+            HIPCHK(h, launch_finish_upsampled(f, st));
+            p.dst = f.dst; p.M = f.S * f.H * f.W;
+        } else {
+        fill_conv(h, s, d_img, ws, B, 1, p);
+        if (!s.is_conv()) { int32_t rc = run_aux_step(h, s, p, st); if (rc) return rc; continue; }
         const int ctile = split ? conv_split_tile(s.tile, s.kx3 || s.p1) : s.tile;
         if (l.op == OP_DETECTION) { if (split) p.flags |= EPI_F32OUT; HIPCHK(h, launch_conv_igemm(p, ctile, st)); continue; }
         // raw conv output (+ addend for STEP_MAIN), fp32; split precision: the accumulators, ACT_SCALE * 2^wshift * conv
         p.scale = h->d_ones; p.shift = h->d_zeros; p.flags = split ? (s.mode == STEP_PARTIAL ? EPI_RAW : EPI_F32OUT) : 0;
         if (split && l.direct) p.split &= 1;                               // direct launch: plain fp32 output here
         HIPCHK(h, l.direct ? launch_conv_direct(p, st) : launch_conv_igemm(p, ctile, st));
-        if (s.mode == STEP_PARTIAL) continue;                              // half of a split conv: statistics at STEP_MAIN
+        if (s.mode == STEP_PARTIAL) continue;                              // half of a split conv: statistics at STEP_MAIN / STEP_FINISH
+        }
         const int N = l.filters;
         HIPCHK(h, launch_channel_stats(p.dst, p.M, N, d_mean, d_var, d_tmp, st));
         HIPCHK(h, hipMemcpyAsync(h->params[l.p_mean].data.data(), d_mean, sizeof(float) * N, hipMemcpyDeviceToHost, st));

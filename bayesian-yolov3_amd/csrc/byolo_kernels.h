@@ -205,6 +205,20 @@ hipError_t launch_u8_to_f32(const uint8_t* src, float* dst, int64_t n, hipStream
 hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mul, hipStream_t st, unsigned* status = nullptr);   // hi/lo pairs of mul * src
 hipError_t launch_split_to_f32(const float* src, float* dst, int64_t n, float mul, hipStream_t st);   // dst[i] = mul * (hi + lo) of a split-f16 tensor
 hipError_t launch_conv_direct(const ConvParams& p, hipStream_t st);   // small-cin (stem) direct conv
+// The finish of a 1x1 concat convolution whose stacked half is an UPSAMPLED tensor (byolo_api.hip STEP_FINISH): a 1x1 convolution
+// commutes with nearest-neighbour upsampling, so that half was multiplied at the source's resolution (`low`, raw accumulators
+// [S, H/2, W/2, N]); here every output pixel (s, y, x) takes low[s, y/2, x/2] + part[s / T, y, x] (the T-invariant half, raw
+// accumulators per image, or null) through the convolution's epilogue -- the arithmetic, in the order, of finish_tile.
+struct FinishParams {
+    const float* low; const float* part; float* dst;
+    int S, H, W, N, T;
+    const float* scale; const float* shift;
+    int flags; uint32_t k0, k1, thr; uint64_t idx_base; const uint32_t* mask_bits;
+    unsigned* status; int layer_idx;
+    int mode;                         // 0 the raw fp32 sum (BN calibration), 1 epilogue with fp32 output (fp32 mode), 2 epilogue with hi/lo output
+    FastDiv d_hw, d_w, d_n4, d_T;     // (H / 2) * (W / 2), W / 2, N / 4, T
+};
+hipError_t launch_finish_upsampled(const FinishParams& p, hipStream_t st);
 
 // ---- calibration helpers -------------------------------------------------------------------
 // per-channel mean / population variance of x [M][C]  -> stats [2][C] (double accumulation)

@@ -209,6 +209,66 @@ __global__ __launch_bounds__(256) void view_gather_kernel(const ConvParams p) {
         p.dst[gid] = v;
     }
 }
+// STEP_FINISH (byolo_kernels.h FinishParams): thread = (source pixel, 4-channel group) -> its 2 x 2 output pixels: one load of the
+// low-resolution accumulators, four loads of the per-image partial sums and four 16-byte stores in flight per thread (HBM-bound)
+template <int MODE>
+__global__ __launch_bounds__(256) void finish_upsampled_kernel(const FinishParams p) {
+    const uint32_t n4 = (uint32_t)p.N >> 2, W = (uint32_t)p.W, hw = (uint32_t)(p.H * p.W), lw = W >> 1, lhw = hw >> 2;
+    const uint64_t total = (uint64_t)p.S * lhw * n4;
+    const bool do_drop = p.flags & EPI_DROPOUT;
+    const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
+    float vmax = 0.f;
+    for (uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * 256u) {
+        const uint32_t lm = (uint32_t)(gid / n4), g = (uint32_t)(gid - (uint64_t)lm * n4);        // (rows < 2^31: check_run)
+        const uint32_t s = fdiv(lm, p.d_hw), lr = lm - s * lhw;                                   // d_hw divides by lhw, d_w by lw
+        const uint32_t ly = fdiv(lr, p.d_w), lx = lr - ly * lw;
+        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(p.low + (size_t)lm * p.N + 4 * g);
+        const size_t part_img = (size_t)fdiv(s, p.d_T) * hw;
+        uint32_t r[4];
+        f32x4 a4[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            r[o] = (2 * ly + (uint32_t)(o >> 1)) * W + 2 * lx + (uint32_t)(o & 1);
+            a4[o] = lo4;
+            if (p.part) a4[o] += *reinterpret_cast<const f32x4*>(p.part + (part_img + r[o]) * p.N + 4 * g);
+        }
+        f32x4 sc4, sf4;
+        if constexpr (MODE != 0) { sc4 = *reinterpret_cast<const f32x4*>(p.scale + 4 * g); sf4 = *reinterpret_cast<const f32x4*>(p.shift + 4 * g); }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const size_t m = (size_t)s * hw + r[o];
+            float* d = p.dst + m * p.N + 4 * g;
+            if constexpr (MODE == 0) { *reinterpret_cast<f32x4*>(d) = a4[o]; continue; }
+            bool keep[4] = {true, true, true, true};
+            if (do_drop) {
+                const uint64_t idx = p.idx_base + (uint64_t)m * (uint64_t)p.N + 4u * g;
+                const epi::DropRow drow(idx, p.k1);
+                if (p.mask_bits) {                                      // injected masks (conv_igemm.hip finish_tile)
+                    const uint32_t el = 2u * drow.gp_lo;
+                    const uint32_t w = p.mask_bits[el >> 5] >> (el & 31u);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) keep[q] = (w >> q) & 1u;
+                } else epi::keep4(drow, 0, p.k0, p.thr, keep);
+            }
+            const f32x4 v = epi::bn_act4(a4[o], sc4, sf4, keep, slope);
+            if constexpr (MODE == 2) { vmax = epi::absmax4(vmax, v); *reinterpret_cast<f32x4*>(d) = epi::split_encode4(v); }
+            else *reinterpret_cast<f32x4*>(d) = v;
+        }
+    }
+    if constexpr (MODE == 2) {
+        if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
+    }
+}
+hipError_t launch_finish_upsampled(const FinishParams& p, hipStream_t st) {
+    if ((p.N & 3) || (p.H & 1) || (p.W & 1) || p.S < 1 || p.T < 1 || !p.low || !p.dst) return hipErrorInvalidValue;
+    const uint64_t total = (uint64_t)p.S * (p.H >> 1) * (p.W >> 1) * (p.N >> 2);
+    const unsigned grid = (unsigned)std::min<uint64_t>((total + 255) / 256, 256u * 64u);
+    if (p.mode == 0) hipLaunchKernelGGL(finish_upsampled_kernel<0>, dim3(grid), dim3(256), 0, st, p);
+    else if (p.mode == 1) hipLaunchKernelGGL(finish_upsampled_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(finish_upsampled_kernel<2>, dim3(grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void tensor_add_kernel(const float* a, const float* b, float* d, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = a[i] + b[i];
 }

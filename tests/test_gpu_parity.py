@@ -565,6 +565,39 @@ def test_the_straight_line_epilogues_compute_the_same_bits(monkeypatch, precisio
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
 
 
+def test_the_upsampled_concat_half_at_the_sources_resolution_computes_the_same_bits(monkeypatch, precision):
+    """A 1x1 convolution commutes with nearest-neighbour upsampling: the stacked half of the Bayesian model's two concat convolutions
+    (lib_yolo/yolov3.py:569-572, :600-603: route [upsampled, stacked skip] -> 1x1) is multiplied at the source's resolution and
+    finished element-wise at the output's (byolo_api.hip STEP_PARTIAL `low` + STEP_FINISH, conv_kernels.hip finish_upsampled_kernel).
+    Against BYOLO_LOWMAIN=0 (the STEP_MAIN launch over the upsampled view): rows, kept indices and raw detection outputs bit for bit,
+    in both precisions, at two sizes, after a device-side BN calibration (which runs the same steps in their raw mode)."""
+    torch = _torch()
+    from byolo import synth
+
+    def run(knob, H, W, T, B):
+        monkeypatch.setenv("BYOLO_LOWMAIN", knob)
+        v = "bayesian_yolov3_aleatoric"
+        _, m = build_model(v, H, W, T=T)
+        eng = m.engine
+        eng.set_params(synth.base_params(eng.param_shapes(), v, 2, seed=7))
+        eng.finalize()
+        x = torch.from_numpy(synth.synthetic_images(B, H, W, seed=77)).cuda()
+        eng.calibrate_bn(x[:1])
+        stats = {k: v_ for k, v_ in eng.get_params().items() if k.endswith("moving_variance") and "det_net_3/conv/" in k}
+        eng.set_profiling(2)
+        out = eng.forward(x, T=T, seed=9, want_boxes=True, want_nms=True)
+        torch.cuda.synchronize()
+        var = [s_["variant"] for s_ in eng.step_profile()]
+        eng.set_profiling(0)
+        return [out["boxes"].cpu().numpy(), out["kept"].cpu().numpy(), out["count"].cpu().numpy()] + list(stats.values()), var
+    for (H, W, T, B) in ((64, 96, 3, 2), (160, 224, 4, 3)):
+        a, va = run("0", H, W, T, B)
+        b, vb = run("1", H, W, T, B)
+        assert va.count(-5) == 0 and vb.count(-5) == 2, "the finish launches did not run: %s" % vb
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), (H, W, precision)
+
+
 def test_back_to_back_fusion_computes_the_same_bits(monkeypatch, precision):
     """BYOLO_B2B=2: every shared-tap 3x3 convolution with 256 output channels whose output is read by ONE 1x1 convolution /
     detection head runs that follower inside its own launch (conv_igemm.hip fused_tail: epilogue -> hi/lo rows in LDS -> second MFMA
