@@ -9,7 +9,7 @@
 //   V[xi][p][c] = (B^T d B)[xi]        wino_split_input_kernel: one 4x4 input patch per output tile p, fp32 arithmetic on the
 //                                      decoded hi + lo values, V stored as hi/lo pairs again (scale 1: |V| <= 4 |d| sits in
 //                                      the fp16 range the activations' 4 * value occupies)
-//   M[xi]       = V[xi] . U[xi]        wino_split_kernel: per transform point a 128 x 128 x C GEMM on
+//   M[xi]       = V[xi] . U[xi]        wino_split_kernel: per transform point a 64 x 256 x C GEMM (per workgroup) on
 //                                      v_mfma_f32_32x32x16_f16 (x_hi u_hi + x_hi u_lo + x_lo u_hi, fp32 accumulation) ...
 //   Y           = A^T M A              ... whose accumulators are folded, point after point, into the four 2x2-output
 //                                      accumulators with the coefficients of A^T . A (0, +-1); after point 15 the lanes hold
@@ -20,9 +20,12 @@
 //
 // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
 //
-// A workgroup (4 waves side by side along N, each 128 x 32) owns 128 output tiles x 128 channels and keeps 4 x 64 output
-// accumulators + 64 product accumulators per lane: a 512-register kernel, one wave per SIMD.  Numerics: emulated around
-// the oracle before it was built (tests/test_split_numerics.py: 0.62 of the bound from float64 where float32 sits at 0.98).
+// The default workgroup (8 waves side by side along N, each 64 x 32) owns 64 output tiles x 256 channels and keeps 4 x 32
+// output accumulators + 32 product accumulators per lane (about 230 registers, two waves per SIMD); the template also builds
+// 64 x 128 (4 waves) and 128 x 128 (4 waves of 128 x 32: 473 registers, one wave per SIMD; measured slower).  Five accumulator
+// sets per tile element pin the tile at 64 x 256 per CU, and its weight-fragment stream (32 KB per 768 matrix-pipe cycles through
+// the vector L1) is what bounds the launch: DESIGN.md 3.6.  Numerics: emulated around the oracle before the kernel was built
+// (tests/test_split_numerics.py: 0.62 of the bound from float64 where float32 sits at 0.98).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "byolo_kernels.h"
@@ -41,8 +44,6 @@ using namespace pipe;
 #define BYOLO_WS_ABLATE 0
 #endif
 static constexpr int WS_ABL = BYOLO_WS_ABLATE;
-
-// output tiles per workgroup (rows of the transform-domain GEMM)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // input transform: thread = (tile p, 4 channels): 16 x 16-byte loads, 16 x 16-byte stores; hi/lo groups in and out
