@@ -15,12 +15,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/byolo.h"
@@ -706,6 +708,27 @@ static void wino_scales(const byolo_t* h, const Layer& l, std::vector<float>& sc
     scale_keep(h, sk);
 }
 
+// byolo_finalize packs ~62 M weights (hi/lo fragments, Winograd U in double): independent per launch, so on the host's cores.
+// BYOLO_FINALIZE_THREADS: worker threads (default: the cores, at most 32; 1 = in the calling thread).  The packed bytes do not
+// depend on it (every element is computed by the same expression; tasks write disjoint ranges).
+template <class F>
+static bool parallel_tasks(int n, F&& f) {
+    const char* e = getenv("BYOLO_FINALIZE_THREADS");
+    const int want = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    const int nt = std::min(n, std::max(1, std::min(want, 32)));
+    std::atomic<int> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&] {
+        try { for (int i; (i = next.fetch_add(1)) < n;) f(i); }
+        catch (...) { ok = false; }
+    };
+    std::vector<std::thread> th;
+    try { for (int t = 1; t < nt; ++t) th.emplace_back(work); } catch (...) {}      // (no more threads to be had: fewer workers)
+    work();
+    for (auto& t : th) t.join();
+    return ok;
+}
+
 extern "C" int32_t byolo_finalize(byolo_t* h) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_finalize: null handle");
     if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
@@ -766,80 +789,103 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
     std::vector<float> sc, sf;
     h->img_split = false;
     if (h->precision == 1) {
-        for (auto& l : h->layers) {
-            if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
+        const char* ple = getenv("BYOLO_WSHIFT_PER_LAYER");
+        const bool per_layer = ple && atoi(ple);
+        const bool ok = parallel_tasks((int)h->layers.size(), [&](int li) {
+            Layer& l = h->layers[li];
+            if (l.op != OP_CONV && l.op != OP_DETECTION) return;
             // a direct convolution reads the image as it is (fp32); a matrix-pipe convolution reads a hi/lo copy of it
             l.in_scale = (l.direct && l.prev < 0) ? 1.f : ACT_SCALE;
-            if (!l.direct && l.prev < 0) h->img_split = true;
             // One power of two PER OUTPUT CHANNEL (folded into scale[n], exactly): the column's largest |w'| lands in
             // [2^13, 2^14), so a filter whose weights are 2^-10 of its neighbours' -- a checkpoint whose BN gammas absorbed the
             // scale, e.g. -- keeps its 22 bits.  (One shift per layer gave such a column 12.)  Clamped: 2^shift stays finite.
             const Param& k = h->params[l.p_kernel];
             const int N = l.filters;
             const size_t rows = k.data.size() / (size_t)N;          // HWIO == [K][N]
+            std::vector<float> mx((size_t)N, 0.f);
+            for (size_t r = 0; r < rows; ++r) {
+                const float* kr = k.data.data() + r * N;
+                for (int n = 0; n < N; ++n) mx[n] = std::max(mx[n], std::fabs(kr[n]));
+            }
             l.wshift.assign((size_t)N, 0);
             l.wshift_u.clear();
             for (int n = 0; n < N; ++n) {
-                float mx = 0.f;
-                for (size_t r = 0; r < rows; ++r) mx = std::max(mx, std::fabs(k.data[r * N + n]));
                 int e = 0;
-                if (mx > 0.f) (void)std::frexp(mx, &e);            // mx = m * 2^e, m in [0.5, 1)
-                l.wshift[n] = mx > 0.f ? std::min(126, std::max(-126, 14 - e)) : 0;      // 2^shift and 2^-shift are normal floats
+                if (mx[n] > 0.f) (void)std::frexp(mx[n], &e);      // mx = m * 2^e, m in [0.5, 1)
+                l.wshift[n] = mx[n] > 0.f ? std::min(126, std::max(-126, 14 - e)) : 0;      // 2^shift and 2^-shift are normal floats
             }
             // BYOLO_WSHIFT_PER_LAYER=1 (A/B in tests/test_robustness.py): one shift per layer, from the layer's largest weight
-            const char* ple = getenv("BYOLO_WSHIFT_PER_LAYER");
-            if (ple && atoi(ple)) {
+            if (per_layer) {
                 int lo = 127;
-                for (int n = 0; n < N; ++n) { bool any = false; for (size_t r = 0; r < rows && !any; ++r) any = k.data[r * N + n] != 0.f; if (any) lo = std::min(lo, l.wshift[n]); }
+                for (int n = 0; n < N; ++n) if (mx[n] > 0.f) lo = std::min(lo, l.wshift[n]);
                 l.wshift.assign((size_t)N, lo == 127 ? 0 : lo);
             }
-        }
+        });
+        if (!ok) return fail(h, BYOLO_ERR_NOMEM, "byolo_finalize: out of host memory");
+        for (const auto& l : h->layers)
+            if ((l.op == OP_CONV || l.op == OP_DETECTION) && !l.direct && l.prev < 0) h->img_split = true;
     }
-    for (auto& st : h->steps) {
+    // Tasks: (step, 0) packs the launch's weights, (step, 1) its Winograd-domain weights; the largest first.  Every task writes its
+    // own range of the blob and its own step / layer fields (a Winograd launch is the only step of its layer).
+    struct PackTask { int step, kind; double cost; };
+    std::vector<PackTask> tasks;
+    for (size_t si = 0; si < h->steps.size(); ++si) {
+        const Step& st = h->steps[si];
         if (!st.is_conv()) continue;
         const Layer& l = h->layers[st.layer];
+        const double k = (double)l.ksize * l.ksize * (st.c_hi - st.c_lo) * l.filters;
+        tasks.push_back({(int)si, 0, k});
+        if (st.wino_ok) tasks.push_back({(int)si, 1, 2.0 * 16 / 9 * k});
+    }
+    std::stable_sort(tasks.begin(), tasks.end(), [](const PackTask& a, const PackTask& b) { return a.cost > b.cost; });
+    const bool packed = parallel_tasks((int)tasks.size(), [&](int ti) {
+        Step& st = h->steps[tasks[ti].step];
+        const Layer& l = h->layers[st.layer];
         const int Cs = st.c_hi - st.c_lo, taps = l.ksize * l.ksize, N = l.filters;
-        st.kx3 = false; st.p1 = false;
         const float* w = h->params[l.p_kernel].data.data();     // HWIO == [K][N], k = (ky*ks + kx)*Cin + c
-        float* dst = blob.data() + st.w_off;
-        if (l.direct) memcpy(dst, w, sizeof(float) * (size_t)taps * l.Cin * N);
-        else if (h->precision == 1) {
-            static const bool kx3_on = [] { const char* e = getenv("BYOLO_KX3"); return !e || atoi(e) != 0; }();
-            st.kx3 = kx3_on && l.ksize == 3 && l.stride == 1 && st.in.n == 1 && st.in.s[0].sh == 0 && st.in.s[0].layer >= 0 && st.Npad >= 64 &&
-                     (st.mode == STEP_NORMAL || st.mode == STEP_REP);
-            const char* p1e = getenv("BYOLO_P1");
-            const bool p1_on = !p1e || atoi(p1e) != 0;
-            st.p1 = p1_on && l.ksize == 1 && l.stride == 1 && st.in.n == 1 && st.in.s[0].layer >= 0 && st.Npad >= 64;
-            const int cts = Cs / 32;
-            // split-f16 weights (mfma_pipe.h): w' = w * 2^wshift with the layer's largest |w'| in [2^13, 2^14), each
-            // element as hi = RNE_f16(w'), lo = RNE_f16(w' - hi), in FRAGMENT ORDER: [K-tile][32-column block][step s]
-            // [plane: hi, lo][lane = 32 * half + column][8 fp16: k = 32 kt + 16 s + 8 half + 0..7] -- the operand
-            // registers of v_mfma_f32_32x32x16_f16 as one coalesced 1 KB load per (step, plane).
-            // K-tile order: (tap, chunk); shared-tap launches: (ky, chunk, kx)
-            _Float16* d16 = reinterpret_cast<_Float16*>(dst);
-            std::vector<float> ws((size_t)N);
-            for (int nn = 0; nn < N; ++nn) ws[nn] = ldexpf(1.f, l.wshift[nn]);
-            const size_t blocks = st.Npad / 32;
-            for (int tap = 0; tap < taps; ++tap)
-                for (int c = 0; c < Cs; ++c) {
-                    const int kk = c & 31, step = kk >> 4, half = (kk >> 3) & 1, e = kk & 7;
-                    const int kt = st.kx3 ? ((tap / 3) * cts + (c >> 5)) * 3 + tap % 3 : tap * cts + (c >> 5);
-                    const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
-                    for (int nn = 0; nn < N; ++nn) {
-                        const float v = wr[nn] * ws[nn];
-                        const _Float16 hi = (_Float16)v;
-                        _Float16* d = d16 + (((size_t)kt * blocks + (nn >> 5)) * 4 + step * 2) * 512 + (half * 32 + (nn & 31)) * 8 + e;
-                        d[0] = hi; d[512] = (_Float16)(v - (float)hi);
+        if (tasks[ti].kind == 0) {
+            st.kx3 = false; st.p1 = false;
+            float* dst = blob.data() + st.w_off;
+            if (l.direct) memcpy(dst, w, sizeof(float) * (size_t)taps * l.Cin * N);
+            else if (h->precision == 1) {
+                static const bool kx3_on = [] { const char* e = getenv("BYOLO_KX3"); return !e || atoi(e) != 0; }();
+                st.kx3 = kx3_on && l.ksize == 3 && l.stride == 1 && st.in.n == 1 && st.in.s[0].sh == 0 && st.in.s[0].layer >= 0 && st.Npad >= 64 &&
+                         (st.mode == STEP_NORMAL || st.mode == STEP_REP);
+                const char* p1e = getenv("BYOLO_P1");
+                const bool p1_on = !p1e || atoi(p1e) != 0;
+                st.p1 = p1_on && l.ksize == 1 && l.stride == 1 && st.in.n == 1 && st.in.s[0].layer >= 0 && st.Npad >= 64;
+                const int cts = Cs / 32;
+                // split-f16 weights (mfma_pipe.h): w' = w * 2^wshift with the layer's largest |w'| in [2^13, 2^14), each
+                // element as hi = RNE_f16(w'), lo = RNE_f16(w' - hi), in FRAGMENT ORDER: [K-tile][32-column block][step s]
+                // [plane: hi, lo][lane = 32 * half + column][8 fp16: k = 32 kt + 16 s + 8 half + 0..7] -- the operand
+                // registers of v_mfma_f32_32x32x16_f16 as one coalesced 1 KB load per (step, plane).
+                // K-tile order: (tap, chunk); shared-tap launches: (ky, chunk, kx)
+                _Float16* d16 = reinterpret_cast<_Float16*>(dst);
+                std::vector<float> ws((size_t)N);
+                for (int nn = 0; nn < N; ++nn) ws[nn] = ldexpf(1.f, l.wshift[nn]);
+                const size_t blocks = st.Npad / 32;
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int c = 0; c < Cs; ++c) {
+                        const int kk = c & 31, step = kk >> 4, half = (kk >> 3) & 1, e = kk & 7;
+                        const int kt = st.kx3 ? ((tap / 3) * cts + (c >> 5)) * 3 + tap % 3 : tap * cts + (c >> 5);
+                        const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
+                        for (int nn = 0; nn < N; ++nn) {
+                            const float v = wr[nn] * ws[nn];
+                            const _Float16 hi = (_Float16)v;
+                            _Float16* d = d16 + (((size_t)kt * blocks + (nn >> 5)) * 4 + step * 2) * 512 + (half * 32 + (nn & 31)) * 8 + e;
+                            d[0] = hi; d[512] = (_Float16)(v - (float)hi);
+                        }
                     }
-                }
-        } else {
-            for (int tap = 0; tap < taps; ++tap)
-                for (int c = 0; c < Cs; ++c) {                  // this launch's channel slice of every tap
-                    const int k = tap * Cs + c, kt = k >> 5, kk = k & 31;
-                    const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
-                    float* d = dst + ((size_t)kt * st.Npad) * 32 + kk;
-                    for (int nn = 0; nn < N; ++nn) d[(size_t)nn * 32] = wr[nn];
-                }
+            } else {
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int c = 0; c < Cs; ++c) {                  // this launch's channel slice of every tap
+                        const int k = tap * Cs + c, kt = k >> 5, kk = k & 31;
+                        const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
+                        float* d = dst + ((size_t)kt * st.Npad) * 32 + kk;
+                        for (int nn = 0; nn < N; ++nn) d[(size_t)nn * 32] = wr[nn];
+                    }
+            }
+            return;
         }
         if (st.wino_ok && h->precision == 1 && wino_split_ok(Cs, N) && st.Npad == N) {
             // Winograd in split arithmetic (wino_split.hip): U[xi][c][n] = (G g G^T)[xi] in double, rounded once; one power of two per
@@ -854,10 +900,13 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
                 }
             Layer& lw = h->layers[st.layer];
             lw.wshift_u.assign((size_t)N, 0);
-            std::vector<float> wsu((size_t)N);
+            std::vector<float> wsu((size_t)N), mxu((size_t)N, 0.f);
+            for (size_t r = 0; r < (size_t)16 * Cs; ++r) {
+                const float* ur = U.data() + r * N;
+                for (int nn = 0; nn < N; ++nn) mxu[nn] = std::max(mxu[nn], std::fabs(ur[nn]));
+            }
             for (int nn = 0; nn < N; ++nn) {
-                float mx = 0.f;
-                for (size_t r = 0; r < (size_t)16 * Cs; ++r) mx = std::max(mx, std::fabs(U[r * N + nn]));
+                const float mx = mxu[nn];
                 int e = 0;
                 if (mx > 0.f) (void)std::frexp(mx, &e);
                 lw.wshift_u[nn] = mx > 0.f ? std::min(126, std::max(-126, 14 - e)) : 0;
@@ -891,6 +940,12 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
                     for (int xi = 0; xi < 16; ++xi) d[(size_t)xi * xi_stride] = u16[xi];
                 }
         }
+    });
+    if (!packed) return fail(h, BYOLO_ERR_NOMEM, "byolo_finalize: out of host memory");
+    for (auto& st : h->steps) {
+        if (!st.is_conv()) continue;
+        const Layer& l = h->layers[st.layer];
+        const int N = l.filters;
         if (st.mode == STEP_PARTIAL && !st.low) continue;
         fold_layer(h, l, sc, sf);
         if (h->precision == 1) fold_split(l, sc, sf);

@@ -598,6 +598,22 @@ def test_the_upsampled_concat_half_at_the_sources_resolution_computes_the_same_b
             assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), (H, W, precision)
 
 
+def test_finalize_packs_the_same_weights_on_one_thread_and_on_all(monkeypatch, precision):
+    """byolo_finalize packs the weights (hi/lo fragments, Winograd-domain weights in double, per-channel shifts) as independent tasks on
+    the host's cores (byolo_api.hip parallel_tasks, BYOLO_FINALIZE_THREADS): rows, kept indices, raw detection outputs and two
+    backbone taps are the same bits with one worker and with three, Winograd forced onto every eligible layer."""
+    monkeypatch.setenv("BYOLO_WINO_SPLIT", "2")
+    monkeypatch.setenv("BYOLO_WINOGRAD", "1")
+
+    def everything(threads):
+        monkeypatch.setenv("BYOLO_FINALIZE_THREADS", threads)
+        m, out, _, _ = _run("bayesian_yolov3_aleatoric", 2, keep_all=True)
+        return [out["boxes"].cpu().numpy(), out["kept"].cpu().numpy(), out["count"].cpu().numpy()] + \
+               [dl.raw_output.cpu().numpy() for dl in m.det_layers] + [m.engine.layer_output(i).cpu().numpy() for i in (36, 74)]
+    for x, y in zip(everything("1"), everything("3")):
+        assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32)), precision
+
+
 def test_back_to_back_fusion_computes_the_same_bits(monkeypatch, precision):
     """BYOLO_B2B=2: every shared-tap 3x3 convolution with 256 output channels whose output is read by ONE 1x1 convolution /
     detection head runs that follower inside its own launch (conv_igemm.hip fused_tail: epilogue -> hi/lo rows in LDS -> second MFMA
