@@ -5,7 +5,7 @@
     loss           lib_yolo/layers.py:126-188 (`loss_tf`) on the dict of `split_detection` / `split_detection_aleatoric`
                    (lib_yolo/layers.py:11-84)
     loss_grad      d(loc + obj + cls) / d(raw detection output): what `optimizer.minimize` (lib_yolo/train.py:88) would
-                   back-propagate into the network -- analytic, checked against finite differences in tests/test_loss_oracle.py
+                   back-propagate into the network -- analytic, checked against finite differences in tests/test_loss.py
     l2_regularization   `tf.contrib.layers.l2_regularizer(l2_scale)` on every kernel and the detection biases
                    (lib_yolo/model.py:27, lib_yolo/layers.py:553-554, :604, :612): scale * sum(w ** 2) / 2 per tensor
 
