@@ -307,19 +307,35 @@ static int32_t begin_add(byolo_t* h, const char* what) {
     return BYOLO_OK;
 }
 
-extern "C" int32_t byolo_add_conv(byolo_t* h, const char* scope, int32_t filters, int32_t ksize, int32_t stride,
-                                  int32_t norm_flags) {
+// No C++ exception leaves the C-ABI: a host allocation that fails (a graph of absurd sizes) is BYOLO_ERR_NOMEM, like a workspace
+// that is too small -- the caller is a ctypes / cgo / JNI binding that cannot unwind.
+template <class F>
+static int32_t guarded(byolo_t* h, const char* what, F&& f) {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(h, BYOLO_ERR_NOMEM, "%s: out of host memory", what); }
+    catch (const std::exception& e) { return fail(h, BYOLO_ERR_ARG, "%s: %s", what, e.what()); }
+}
+
+// Bounds of a convolution this library will hold on the host (the reference's largest: 1024 channels, 4.7 M weights): beyond them a
+// call is a mistake (filters = INT_MAX would otherwise be a 200 GB std::vector filled with zeros)
+static constexpr int MAX_CHANNELS = 1 << 16;
+static constexpr int64_t MAX_KERNEL_WEIGHTS = (int64_t)1 << 28;
+
+static int32_t add_conv_impl(byolo_t* h, const char* scope, int32_t filters, int32_t ksize, int32_t stride, int32_t norm_flags) {
     int32_t rc = begin_add(h, "byolo_add_conv"); if (rc) return rc;
     // lib_yolo/layers.py:546-547: assert kernel_size in [1,3], strides in [1,2]
     if (!scope || !(ksize == 1 || ksize == 3)) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: invalid kernel size");
     if (!(stride == 1 || stride == 2)) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: invalid strides");
     if (stride == 2 && ksize != 3) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: invalid kernel size (layers.py:629)");
     if (filters < 1) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: filters < 1");
+    if (filters > MAX_CHANNELS) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: more than %d filters", MAX_CHANNELS);
     if (!(norm_flags & BYOLO_NORM_BN)) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: BN-less conv layers are not on this path");
     Layer l; l.op = OP_CONV; l.scope = scope; l.filters = filters; l.ksize = ksize; l.stride = stride; l.norm = norm_flags;
     l.prev = (int)h->layers.size() - 1;
     int C, H, W; bool st; input_shape(h, l.prev, C, H, W, st);
     if (stride == 2 && ((H | W) & 1)) return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: stride 2 needs even input size");
+    if ((int64_t)ksize * ksize * C * filters > MAX_KERNEL_WEIGHTS)
+        return fail(h, BYOLO_ERR_ARG, "byolo_add_conv: a kernel of %lld weights (limit 2^28)", (long long)ksize * ksize * C * filters);
     l.Cin = C; l.C = filters; l.H = H / stride; l.W = W / stride; l.stacked = st;
     const std::string s(scope);
     l.p_kernel = add_param(h, s + "/conv2d/kernel", {ksize, ksize, C, filters}, 0.f);
@@ -331,6 +347,10 @@ extern "C" int32_t byolo_add_conv(byolo_t* h, const char* scope, int32_t filters
     if (norm_flags & BYOLO_NORM_DROPOUT) l.drop_ordinal = h->n_dropout++;
     h->layers.push_back(l);
     return (int32_t)h->layers.size() - 1;
+}
+extern "C" int32_t byolo_add_conv(byolo_t* h, const char* scope, int32_t filters, int32_t ksize, int32_t stride,
+                                  int32_t norm_flags) {
+    return guarded(h, "byolo_add_conv", [&] { return add_conv_impl(h, scope, filters, ksize, stride, norm_flags); });
 }
 
 extern "C" int32_t byolo_add_residual(byolo_t* h, int32_t shortcut) {
@@ -363,6 +383,7 @@ extern "C" int32_t byolo_add_route(byolo_t* h, const int32_t* routes, int32_t n)
         if (a.H != b.H || a.W != b.W || a.stacked != b.stacked)
             return fail(h, BYOLO_ERR_ARG, "byolo_add_route: concat shape mismatch");
         l.C = a.C + b.C;
+        if (l.C > MAX_CHANNELS) return fail(h, BYOLO_ERR_ARG, "byolo_add_route: more than %d channels", MAX_CHANNELS);
     }
     h->layers.push_back(l);
     return (int32_t)h->layers.size() - 1;
@@ -397,7 +418,7 @@ static void row_layout(int kind, int C, int& D, int& obj, int& cls) {
     else { D = 21 + C; obj = 14; cls = 17; }
 }
 
-extern "C" int32_t byolo_add_detection(byolo_t* h, const char* scope, int32_t kind, const float* priors_hw) {
+static int32_t add_detection_impl(byolo_t* h, const char* scope, int32_t kind, const float* priors_hw) {
     int32_t rc = begin_add(h, "byolo_add_detection"); if (rc) return rc;
     if (!scope || !priors_hw || kind < 0 || kind > 2) return fail(h, BYOLO_ERR_ARG, "byolo_add_detection: bad argument");
     Layer l; l.op = OP_DETECTION; l.scope = scope; l.prev = (int)h->layers.size() - 1; l.det_kind = kind;
@@ -419,6 +440,9 @@ extern "C" int32_t byolo_add_detection(byolo_t* h, const char* scope, int32_t ki
     if (l.p_kernel < 0 || l.p_bias < 0) return fail(h, BYOLO_ERR_ARG, "byolo_add_detection: duplicate scope '%s'", scope);
     h->layers.push_back(l);
     return (int32_t)h->layers.size() - 1;
+}
+extern "C" int32_t byolo_add_detection(byolo_t* h, const char* scope, int32_t kind, const float* priors_hw) {
+    return guarded(h, "byolo_add_detection", [&] { return add_detection_impl(h, scope, kind, priors_hw); });
 }
 
 extern "C" int32_t byolo_mark_backbone_end(byolo_t* h) {
@@ -729,7 +753,7 @@ static bool parallel_tasks(int n, F&& f) {
     return ok;
 }
 
-extern "C" int32_t byolo_finalize(byolo_t* h) {
+static int32_t finalize_impl(byolo_t* h) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_finalize: null handle");
     if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
     // Every parameter must be a number.  The reference would carry an inf / NaN from a checkpoint (tf.train.Saver.restore,
@@ -976,6 +1000,9 @@ extern "C" int32_t byolo_finalize(byolo_t* h) {
     h->finalized = true;
     h->plan.B = -1; h->plan.T = -1; ++h->plan_epoch;            // kernel choices depend on what was packed: plan again
     return BYOLO_OK;
+}
+extern "C" int32_t byolo_finalize(byolo_t* h) {
+    return guarded(h, "byolo_finalize", [&] { return finalize_impl(h); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1296,7 +1323,7 @@ static int32_t check_run(byolo_t* h, int32_t B, int32_t T, const char* what, boo
     return BYOLO_OK;
 }
 
-extern "C" int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t* out) {
+static int32_t workspace_bytes_impl(byolo_t* h, int32_t B, int32_t T, size_t* out) {
     if (h && B >= 1 && T >= 1) {                       // a batch beyond byolo_max_images runs in pieces (byolo_forward): the largest piece's arena
         if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
         const int64_t cap = piece_cap(h, T);
@@ -1324,6 +1351,9 @@ extern "C" int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_
     }
     *out = std::max(h->plan.total, h->wsm_total);
     return BYOLO_OK;
+}
+extern "C" int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t* out) {
+    return guarded(h, "byolo_workspace_bytes", [&] { return workspace_bytes_impl(h, B, T, out); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1594,7 +1624,7 @@ static int64_t mask_layout(const byolo_t* h, int B, int T, int ordinal, int64_t*
 
 extern "C" int32_t byolo_num_dropout(const byolo_t* h) { return h ? h->n_dropout : BYOLO_ERR_ARG; }
 
-extern "C" int32_t byolo_mask_layout(byolo_t* h, int32_t B, int32_t T, int32_t ordinal, int64_t* bit_offset, int64_t* elements) {
+static int32_t mask_layout_impl(byolo_t* h, int32_t B, int32_t T, int32_t ordinal, int64_t* bit_offset, int64_t* elements) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_mask_layout: null handle");
     if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }          // (layer shapes / dropout ordinals exist after lowering)
     if (B < 1 || T < 1 || ordinal < 0 || ordinal > h->n_dropout) return fail(h, BYOLO_ERR_ARG, "byolo_mask_layout: bad argument");
@@ -1603,6 +1633,9 @@ extern "C" int32_t byolo_mask_layout(byolo_t* h, int32_t B, int32_t T, int32_t o
     if (bit_offset) *bit_offset = off;
     if (elements) *elements = n;
     return BYOLO_OK;
+}
+extern "C" int32_t byolo_mask_layout(byolo_t* h, int32_t B, int32_t T, int32_t ordinal, int64_t* bit_offset, int64_t* elements) {
+    return guarded(h, "byolo_mask_layout", [&] { return mask_layout_impl(h, B, T, ordinal, bit_offset, elements); });
 }
 
 // the status words after everything enqueued on `st` so far; BLOCKS until the stream is idle
@@ -1677,7 +1710,7 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
 // A batch beyond byolo_max_images(h, T) -- the convolutions address their sources with 32-bit byte offsets -- runs as consecutive
 // pieces of at most that many images in the SAME workspace: images are independent end to end (the NMS is per image) and every
 // piece draws the dropout masks of its position in the logical batch (first_image), so the result does not depend on the cut.
-extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
+static int32_t forward_impl(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
                                  const uint32_t* d_mask_bits, void* d_workspace, size_t workspace_bytes, float* d_boxes, float* d_rows,
                                  int32_t* d_kept, int32_t* d_count, void* stream) {
     if (h && h->finalized && B >= 1 && T >= 1) {
@@ -1703,6 +1736,11 @@ extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int3
         }
     }
     return forward_piece(h, d_img, B, T, seed, dropout_on, d_mask_bits, d_workspace, workspace_bytes, d_boxes, d_rows, d_kept, d_count, stream);
+}
+extern "C" int32_t byolo_forward(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
+                                 const uint32_t* d_mask_bits, void* d_workspace, size_t workspace_bytes, float* d_boxes, float* d_rows,
+                                 int32_t* d_kept, int32_t* d_count, void* stream) {
+    return guarded(h, "byolo_forward", [&] { return forward_impl(h, d_img, B, T, seed, dropout_on, d_mask_bits, d_workspace, workspace_bytes, d_boxes, d_rows, d_kept, d_count, stream); });
 }
 
 static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
@@ -2042,7 +2080,7 @@ extern "C" int32_t byolo_loss(byolo_t* h, int32_t kind, int32_t aleatoric_loss, 
 // ------------------------------------------------------------------------------------------------
 // data-dependent BN initialisation for synthetic weights
 // ------------------------------------------------------------------------------------------------
-extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B, void* d_workspace, size_t workspace_bytes,
+static int32_t calibrate_bn_impl(byolo_t* h, const float* d_img, int32_t B, void* d_workspace, size_t workspace_bytes,
                                       void* stream) {
     int32_t rc = check_run(h, B, 1, "byolo_calibrate_bn"); if (rc) return rc;
     if (!d_img || !d_workspace) return fail(h, BYOLO_ERR_ARG, "byolo_calibrate_bn: null argument");
@@ -2112,6 +2150,10 @@ extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B,
     HIPCHK(h, hipStreamSynchronize(st));
     return BYOLO_OK;
 }
+extern "C" int32_t byolo_calibrate_bn(byolo_t* h, const float* d_img, int32_t B, void* d_workspace, size_t workspace_bytes,
+                                      void* stream) {
+    return guarded(h, "byolo_calibrate_bn", [&] { return calibrate_bn_impl(h, d_img, B, d_workspace, workspace_bytes, stream); });
+}
 
 // ------------------------------------------------------------------------------------------------
 // profiling / cost model
@@ -2168,12 +2210,15 @@ extern "C" int32_t byolo_set_first_image(byolo_t* h, int64_t first_image) {
     return BYOLO_OK;
 }
 
-extern "C" int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images) {
+static int32_t max_images_impl(byolo_t* h, int32_t T, int32_t* max_images) {
     if (!h || !max_images) return BYOLO_ERR_ARG;
     if (T < 1) return fail(h, BYOLO_ERR_ARG, "byolo_max_images: T must be >= 1");
     if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
     *max_images = (int32_t)piece_cap(h, T);
     return BYOLO_OK;
+}
+extern "C" int32_t byolo_max_images(byolo_t* h, int32_t T, int32_t* max_images) {
+    return guarded(h, "byolo_max_images", [&] { return max_images_impl(h, T, max_images); });
 }
 
 extern "C" int32_t byolo_num_steps(const byolo_t* h) {
@@ -2223,7 +2268,7 @@ extern "C" int32_t byolo_stage_ms(byolo_t* h, float ms[4]) {
     return BYOLO_OK;
 }
 
-extern "C" int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops) {
+static int32_t flops_impl(byolo_t* h, int32_t B, int32_t T, double* flops) {
     if (!h || !flops || B < 1 || T < 1) return BYOLO_ERR_ARG;
     double f = 0;
     for (const auto& l : h->layers) {
@@ -2233,6 +2278,9 @@ extern "C" int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops) 
     }
     *flops = f;
     return BYOLO_OK;
+}
+extern "C" int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops) {
+    return guarded(h, "byolo_flops", [&] { return flops_impl(h, B, T, flops); });
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -116,6 +116,47 @@ def test_graph_errors():
     assert e2.workspace_bytes(1, 1) > 0
 
 
+def test_absurd_sizes_are_refused_not_allocated():
+    """A builder call with a size no network has is a status, never a 200 GB std::vector (filters = INT_MAX used to be one: on a host
+    with enough memory to start filling it, the random builder sweep -- tools/fuzz_builder.py -- took the machine down) and never a C++
+    exception through the C-ABI.  Child process under an address-space limit: the refusal must not depend on the allocation failing."""
+    import os
+    import resource
+    import subprocess
+    import sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+from byolo import Engine, ByoloError
+e = Engine((96, 64, 3), 2)
+for args, what in ((("a", 2**31 - 1, 3, 1, 1), "filters"), (("a", 1 << 20, 1, 1, 1), "filters"), (("a", 65536, 3, 1, 1), None)):
+    try:
+        e.add_conv(*args)
+        assert what is None, args
+    except ByoloError as ex:
+        assert what and what in str(ex), (args, str(ex))
+try:
+    e.add_conv("b", 65536, 3, 1, 1)           # 9 * 65536 * 65536 weights
+    raise SystemExit("a 38 G-weight kernel was accepted")
+except ByoloError as ex:
+    assert "weights" in str(ex), str(ex)
+e.add_conv("c", 32, 1, 1, 1)
+e.add_detection("d/detection", 0, [(0.1, 0.1)] * 3)
+for b, t in ((2**31 - 1, 2**31 - 1), (1 << 20, 30), (8, 1 << 20)):
+    try:
+        e.workspace_bytes(b, t)
+    except ByoloError:
+        pass
+print("OK")
+""" % os.path.join(REPO, "bayesian-yolov3_amd")
+
+    def limit():
+        resource.setrlimit(resource.RLIMIT_AS, (16 << 30, 16 << 30))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, preexec_fn=limit)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+
+
 def test_views_get_tensors_where_a_loader_cannot_express_them():
     """Route / upsample / stack layers are views inside the next convolution's loader; where that is not enough -- a
     view as residual shortcut (once read as if it were a tensor: a device fault), a concat of a concat, an upsample of
