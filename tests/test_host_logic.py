@@ -157,6 +157,18 @@ print("OK")
     assert p.returncode == 0 and p.stdout.strip().endswith("OK"), (p.returncode, p.stdout[-500:], p.stderr[-1500:])
 
 
+def test_random_builder_call_sequences_return_statuses():
+    """tools/fuzz_builder.py (random call sequences against the graph-builder half of the C-ABI; no device needed; every child under an
+    address-space limit), a short sweep: no crash, no inconsistent size."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "tools", "fuzz_builder.py"), "--runs", "10", "--seed", "150"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "0 crashed or inconsistent" in p.stdout, (p.stdout[-1500:], p.stderr[-500:])
+
+
 def test_views_get_tensors_where_a_loader_cannot_express_them():
     """Route / upsample / stack layers are views inside the next convolution's loader; where that is not enough -- a
     view as residual shortcut (once read as if it were a tensor: a device fault), a concat of a concat, an upsample of

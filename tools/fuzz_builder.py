@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """fuzz_builder.py -- random call sequences against the graph-builder half of the C-ABI (no GPU needed): whatever the
 arguments, a call returns a status (ByoloError on the Python side) -- it never crashes the process, and a graph that
-lowers reports consistent sizes.  Each sequence runs in a child process so that a crash is reported, not suffered.
+lowers reports consistent sizes.  Each sequence runs in a child process (no device, 32 GB address-space limit) so that a crash or a
+runaway allocation is reported, not suffered.
 
     python tools/fuzz_builder.py --runs 300 --seed 1
 """
@@ -65,6 +66,11 @@ print("OK %%d calls succeeded, %%d refused" %% (ok, err))
 '''
 
 
+def _limit():
+    import resource
+    resource.setrlimit(resource.RLIMIT_AS, (32 << 30, 32 << 30))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--runs", type=int, default=100)
@@ -74,7 +80,10 @@ def main():
     tot_ok = tot_err = 0
     for r in range(a.runs):
         code = CHILD % {"pkg": os.path.join(REPO, "bayesian-yolov3_amd"), "seed": a.seed * 100003 + r}
-        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        # no device (the builder half needs none) and an address-space limit: a call that tries to allocate the world is a reported
+        # crash of the child, not the end of the machine (round 4: filters = INT_MAX was a 232 GB vector)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, preexec_fn=_limit,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
         line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
         if p.returncode != 0 or not line.startswith("OK"):
             bad += 1
