@@ -109,7 +109,9 @@ BYOLO_API int32_t byolo_abi_version(void);
  * (model.py:52-81 -> layers.conv, lib_yolo/layers.py:545-575): conv(no bias) -> [dropout] -> BN
  * (eps 1e-5) -> leaky-ReLU(0.1).  stride 2 = pad(1,1)+VALID (layers.py:533-537, :616-635).
  * `scope` = TF variable scope of the layer ("darknet53/conv_3", ...): names its variables
- * "<scope>/conv2d/kernel", "<scope>/batch_normalization/{gamma,beta,moving_mean,moving_variance}". */
+ * "<scope>/conv2d/kernel", "<scope>/batch_normalization/{gamma,beta,moving_mean,moving_variance}".
+ * At most 65 536 filters and 2^28 weights per kernel (the reference's largest: 1024 / 4.7 M): beyond, BYOLO_ERR_ARG.
+ * No entry point lets a C++ exception out: a host allocation that fails is BYOLO_ERR_NOMEM. */
 BYOLO_API int32_t byolo_add_conv(byolo_t* h, const char* scope, int32_t filters, int32_t ksize, int32_t stride,
                        int32_t norm_flags);
 /* make_residual_layer (model.py:91-94, layers.py:505-507) */
@@ -137,7 +139,8 @@ BYOLO_API int32_t byolo_param_info(const byolo_t* h, int32_t i, const char** nam
 BYOLO_API int32_t byolo_set_param(byolo_t* h, const char* name, const float* h_data, int64_t count);
 BYOLO_API int32_t byolo_get_param(const byolo_t* h, const char* name, float* h_data, int64_t count);
 /* fold BN (+ 1/keep_prob) into per-channel scale/shift, repack kernels for the MFMA tiles, upload.
- * May be called again after further byolo_set_param calls. */
+ * May be called again after further byolo_set_param calls.  Packs on the host's cores (environment
+ * BYOLO_FINALIZE_THREADS: default all, at most 32; the packed bytes do not depend on it). */
 BYOLO_API int32_t byolo_finalize(byolo_t* h);
 
 /* ---- run: one sess.run([nms_op]) (inference_epistemic.py:76, inference_aleatoric.py:75) ------ */
