@@ -43,7 +43,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "bayesian-yolov3_amd"))
 
-CONFIGS = {   # BASELINE.json configs[1..4]  (per-GPU batch)
+CONFIGS = {   # BASELINE.json configs[0..4]  (per-GPU batch)
+    # configs[0]: the reference's CPU-runnable plumbing case (inference_standard_yolov3.py, one image) -- run on the device as well
+    1: dict(variant="yolov3", H=416, W=416, B=1, T=1, nms=0),
     2: dict(variant="yolov3_aleatoric", H=416, W=416, B=8, T=1, nms=0),
     3: dict(variant="bayesian_yolov3_aleatoric", H=416, W=416, B=16, T=10, nms=0),
     4: dict(variant="bayesian_yolov3_aleatoric", H=608, W=608, B=8, T=30, nms=0),
@@ -59,7 +61,9 @@ PEAK_F16_MFMA = 2500e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, d
 SUSTAINED_F16_MFMA = 1756e12
 
 
-def build(cfg, device, precision=None):
+def build(cfg, device, precision=None, params=None):
+    """The benchmark's model: seeded random weights, BN statistics calibrated on the device (or `params`: the complete parameter
+    set of an engine built here before -- the other precision of the same configuration computes on the SAME weights)."""
     from lib_yolo import yolov3, model
     from byolo import synth
     import torch
@@ -71,6 +75,10 @@ def build(cfg, device, precision=None):
     eng = m.engine
     if precision is not None:
         eng.set_precision(precision)
+    if params is not None:
+        eng.set_params(params)
+        eng.finalize()
+        return m
     eng.set_params(synth.base_params(eng.param_shapes(), cfg["variant"], 2, seed=7))
     eng.finalize()
     calib = torch.from_numpy(synth.synthetic_images(2, cfg["H"], cfg["W"], seed=999)).to("cuda:%d" % device)
@@ -101,37 +109,68 @@ def cpu_baseline(cfg, params, n_img=1):
                       % (n_img, cfg["H"], cfg["W"], cfg["T"], dt)}, boxes.numpy(), kept
 
 
-def parity_note(cfg, eng, x, oracle_rows, oracle_kept):
-    """The oracle rows of the cpu_baseline leg (image 0 of the benchmark batch, dropout seed 42) against one more device
-    forward of the SAME batch with that seed: worst distance per column group in units of the bound, kept indices."""
+def parity_check(cfg, eng, x, ref32, ref64=None, oracle_kept=None, seconds=None):
+    """THE PARITY CONTRACT (oracle/report.py) on image 0 of a batch, dropout seed 42: one more device forward of the SAME batch
+    against the oracle rows `ref32` (float32 CPU restatement) and, where given, `ref64` (the same in float64 = the exact value of
+    the reference's graph).  Per column group: the worst value in units of the bound 1e-4 * max(1, |ref|), the largest ABSOLUTE
+    error, the largest RELATIVE error over |ref| > 1, the allowance and whether it holds:
+        vs_float64: 1 (literal);   vs_float32: max(1, F(g)), F = `float32_vs_float64` measured here (1 where no float64 run).
+    Tail: the oracle's NMS on the DEVICE's rows must keep exactly what the device kept.  `ok` = everything holds; bench.py exits
+    non-zero after printing its line when any leg's `ok` is false."""
     import numpy as np
-    from oracle import report
     import torch
-    from oracle import cpu_ref
+    from oracle import report, cpu_ref
     r = eng.forward(x, T=cfg["T"], seed=42, want_boxes=True, want_nms=True, first_image=0)
     got = r["boxes"][:1].cpu().numpy()
     n = int(r["count"][0, 0])
     kept = r["kept"][0, :n].cpu().numpy()
-    rep = report.rows_report(got, oracle_rows[:1], cfg["variant"])
-    # tail: the oracle's NMS on the DEVICE's rows must keep exactly what the device kept; against the oracle's NMS of the ORACLE's
-    # rows the greedy visiting order may flip between near-tied scores, so that comparison is a count of differing boxes
+    ref32 = np.asarray(ref32)[:1]
+    floor = report.rows_report(ref32, np.asarray(ref64)[:1], cfg["variant"]) if ref64 is not None else None
+    vs32, ok32 = report.check(report.rows_report(got, ref32, cfg["variant"]), report.allowance(floor))
+    pat = bool(np.array_equal(np.isnan(got), np.isnan(ref32)) and np.array_equal(np.isinf(got), np.isinf(ref32)))
+    # the oracle's NMS on the DEVICE's rows must keep exactly what the device kept; against the oracle's NMS of the ORACLE's rows the
+    # greedy visiting order may flip between near-tied scores, so that comparison is a count of differing boxes
     tail = cpu_ref.nms_batch(torch.from_numpy(got), cfg["variant"], two_class=bool(cfg["nms"]))[0][1]
-    ok = oracle_kept[0][1]
-    return {"compared": "image 0 of the benchmark batch, all %d pre-NMS rows, dropout seed 42; device (%s) vs the float32 oracle"
-                        % (got.shape[1], eng.precision),
-            "bound": "1e-4 * max(1, |ref|)", "worst_in_bounds": {k: round(v["worst_in_bounds"], 3) for k, v in rep.items()},
-            "max_abs_err": {k: float("%.3g" % v["max_abs_err"]) for k, v in rep.items()},
-            "nan_inf_pattern_equal": bool(np.array_equal(np.isfinite(got), np.isfinite(oracle_rows[:1]))),
-            "kept_indices_bit_exact_vs_oracle_nms_on_device_rows": bool(n == len(tail) and np.array_equal(kept, tail)),
-            "kept_boxes": n, "kept_boxes_oracle_rows": int(len(ok)),
-            "kept_set_symmetric_difference_vs_oracle_rows": int(len(set(kept.tolist()) ^ set(np.asarray(ok).tolist())))}
+    tail_ok = bool(n == len(tail) and np.array_equal(kept, tail))
+    res = {"compared": "image 0 of the batch, all %d pre-NMS rows, dropout seed 42; device (%s)%s"
+                       % (got.shape[1], eng.precision, "" if seconds is None else "; %.1f s of host time for the oracle" % seconds),
+           "bound": "1e-4 * max(1, |ref|); allowance 1 vs float64, max(1, float32_vs_float64) vs float32 (oracle/report.py)",
+           "vs_float32": vs32, "nan_inf_pattern_equal": pat, "kept_indices_bit_exact_vs_oracle_nms_on_device_rows": tail_ok, "kept_boxes": n}
+    ok = ok32 and pat and tail_ok
+    if ref64 is not None:
+        vs64, ok64 = report.check(report.rows_report(got, np.asarray(ref64)[:1], cfg["variant"]))
+        res["vs_float64"] = vs64
+        res["float32_vs_float64"] = {k: round(v["worst_in_bounds"], 3) for k, v in floor.items()}
+        ok = ok and ok64
+    res["worst_in_bounds"] = {k: v["worst_in_bounds"] for k, v in vs32.items()}            # (the round-4 field, kept)
+    if oracle_kept is not None:
+        okk = oracle_kept[0][1]
+        res["kept_boxes_oracle_rows"] = int(len(okk))
+        res["kept_set_symmetric_difference_vs_oracle_rows"] = int(len(set(kept.tolist()) ^ set(np.asarray(okk).tolist())))
+    res["ok"] = bool(ok)
+    return res
 
 
-def other_config_leg(num, device, steps=5, warmup=2, oracle=True):
+def oracle_rows(cfg, params, f64=False):
+    """Image 0 of the configuration's batch through the CPU restatement with dropout seed 42; (rows, seconds)."""
+    import torch
+    from oracle import cpu_ref
+    from byolo import synth
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    dt = torch.float64 if f64 else torch.float32
+    imgs = synth.synthetic_images(1, cfg["H"], cfg["W"], seed=1234)
+    t0 = time.time()
+    with torch.no_grad():
+        ref, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params, dt), imgs, cfg["variant"], T=cfg["T"], seed=42, dtype=dt)
+    return ref.numpy(), time.time() - t0
+
+
+def other_config_leg(num, device, steps=5, warmup=2, oracle="f32"):
     """One of the other BASELINE configs (parity-test cases, not the headline), timed the way the headline is -- whole steps
     alternating over two HIP streams, inputs resident, `steps` timed steps -- so that every configuration BASELINE.json names has
-    a driver-run number; `parity` = image 0 against the float32 oracle per column group in units of the bound (configs whose
-    oracle image takes seconds on the host), kept indices against the oracle's NMS on the device's rows."""
+    a driver-run number; `parity` = parity_check on image 0 (oracle "f32": against the float32 oracle at the literal bound; "f64":
+    additionally against the float64 run, whose distance from the float32 one is then the float32 comparison's allowance;
+    False: the oracle image takes minutes on the host -- tests/test_gpu_bench_shapes.py covers the shape)."""
     import numpy as np
     import torch
     from byolo import synth
@@ -167,24 +206,12 @@ def other_config_leg(num, device, steps=5, warmup=2, oracle=True):
            "range_status": "ok" if flags == 0 else "RANGE (layer %d): invalid" % layer}
     if oracle:
         try:
-            from oracle import cpu_ref, report
-            torch.set_num_threads(min(os.cpu_count() or 1, 64))
-            imgs = synth.synthetic_images(1, cfg["H"], cfg["W"], seed=1234)
-            t0 = time.time()
-            with torch.no_grad():
-                ref, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(eng.get_params()), imgs, cfg["variant"], T=T, seed=42)
-            r = eng.forward(x, T=T, seed=42, want_boxes=True, want_nms=True, first_image=0)
-            got = r["boxes"][:1].cpu().numpy()
-            n = int(r["count"][0, 0])
-            rep = report.rows_report(got, ref.numpy()[:1], cfg["variant"])
-            tail = cpu_ref.nms_batch(torch.from_numpy(got), cfg["variant"], two_class=bool(cfg["nms"]))[0][1]
-            res["parity"] = {"compared": "image 0, all %d pre-NMS rows, dropout seed 42; device (%s) vs the float32 oracle (%.1f s of host time)"
-                                         % (got.shape[1], eng.precision, time.time() - t0),
-                             "worst_in_bounds": {k: round(v["worst_in_bounds"], 3) for k, v in rep.items()},
-                             "nan_inf_pattern_equal": bool(np.array_equal(np.isfinite(got), np.isfinite(ref.numpy()[:1]))),
-                             "kept_indices_bit_exact_vs_oracle_nms_on_device_rows": bool(n == len(tail) and np.array_equal(r["kept"][0, :n].cpu().numpy(), tail))}
+            p = eng.get_params()
+            ref32, t32 = oracle_rows(cfg, p)
+            ref64, t64 = oracle_rows(cfg, p, f64=True) if oracle == "f64" else (None, 0.0)
+            res["parity"] = parity_check(cfg, eng, x, ref32, ref64, seconds=t32 + t64)
         except Exception as e:
-            res["parity"] = {"error": repr(e)}
+            res["parity"] = {"error": repr(e), "ok": None}        # the oracle leg itself failed: unknown, not a parity failure
     else:
         res["parity"] = "see profiles/*_parity_table.json (tests/test_gpu_bench_shapes.py at this shape; the oracle image takes minutes on the host)"
     eng.close()
@@ -382,6 +409,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the 5-step timings of BASELINE configs 2, 3, 5 and the reference's default frame")
     ap.add_argument("--entry-frames", type=int, default=512,
                     help="frames of the entry_point leg (inference_epistemic.inference over generated TFRecord shards); 0 = skip it")
+    ap.add_argument("--quick-parity", action="store_true", help="skip the minute-long float32 oracle image of configs[4] (1024x1024, T=50)")
     ap.add_argument("--no-dropout", action="store_true",
                     help="[experiment, not the metric] skip the dropout masks: isolates the epilogue's RNG cost")
     ap.add_argument("--dump-steps", default=None, help="write the per-launch table (layer, variant, M, N, K, ms, TF/s) here")
@@ -680,9 +708,10 @@ def main():
                 line["fp32_mode"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_other_configs and args.config == 4 and not args.batch and args.scaling == "weak":
             line["other_configs"] = {}
-            for num, name, orc in ((2, "configs[1]", True), (3, "configs[2]", True), (5, "configs[4]", False), (6, "reference default frame (inference_epistemic.py:218-221)", False)):
+            for num, name, orc in ((1, "configs[0]", "f64"), (2, "configs[1]", "f64"), (3, "configs[2]", "f64"), (5, "configs[4]", "f32"),
+                                   (6, "reference default frame (inference_epistemic.py:218-221)", False)):
                 try:
-                    line["other_configs"][name] = other_config_leg(num, device, oracle=orc and not args.no_cpu_baseline)
+                    line["other_configs"][name] = other_config_leg(num, device, oracle=orc and not args.no_cpu_baseline and (orc if num != 5 or not args.quick_parity else False))
                 except Exception as e:
                     line["other_configs"][name] = {"img_s": None, "error": repr(e)}
         if world == 1 and args.entry_frames > 0 and not args.batch and args.scaling == "weak":
@@ -711,13 +740,21 @@ def main():
             try:
                 line["cpu_baseline"], o_rows, o_kept = cpu_baseline(cfg, eng.get_params())
                 eng.set_profiling(0)
-                line["parity_note"] = parity_note(cfg, eng, x, o_rows, o_kept)
+                line["parity_note"] = parity_check(cfg, eng, x, o_rows, None, o_kept)
             except Exception as e:          # the CPU leg must never cost the GPU number
                 line.setdefault("cpu_baseline", {"value": None, "unit": "img/s", "cores": os.cpu_count(), "kind": "port",
                                                  "sample": "failed: %r" % (e,)})
-                line["parity_note"] = {"error": repr(e)}
+                line["parity_note"] = {"error": repr(e), "ok": None}
         line["range_status"] = "ok (byolo_status after the timed region: no activation left the split-f16 range)" if eng.precision == "split" else "n/a (fp32 mode)"
+        # every parity leg of the line against its stated allowance (the line used to print 1.27 and exit 0)
+        legs = {"parity_note": line.get("parity_note")}
+        legs.update({"other_configs/" + k: v.get("parity") for k, v in (line.get("other_configs") or {}).items() if isinstance(v, dict)})
+        failed = sorted(k for k, v in legs.items() if isinstance(v, dict) and v.get("ok") is False)
+        line["parity_ok"] = not failed
+        if failed:
+            line["parity_failed"] = failed
         print(json.dumps(line))
+        parity_exit = 3 if failed else 0
         if args.dump_steps and per_launch:
             with open(args.dump_steps, "w") as f:
                 f.write("| # | layer | variant | M | N | K | ms | executed TF/s | algorithmic TF/s |\n|---|---|---|---|---|---|---|---|---|\n")
@@ -729,6 +766,9 @@ def main():
     if pg:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and parity_exit:
+        sys.stderr.write("bench.py: parity beyond the stated allowance in %s (see the line's parity fields)\n" % ", ".join(failed))
+        sys.exit(parity_exit)
 
 
 if __name__ == "__main__":
