@@ -33,6 +33,8 @@ class Engine:
         self._ws = None
         self._ws_key = None
         self.finalized = False
+        self._graph = []                 # the builder calls in order: twin() replays them on a second handle
+        self._twin = None
 
     # ---- arithmetic of the convolution stack (include/byolo.h: BYOLO_PREC_*) ----------------------------
     @property
@@ -111,7 +113,32 @@ class Engine:
             buf[off // 32: off // 32 + bits.size // 4] = bits.view("<u4")
         return buf
 
+    def twin(self, precision="f32"):
+        """A SECOND handle with the same graph and the same parameters (calibrated BN statistics included), finalized in the other
+        arithmetic and kept for the life of this engine: both weight packs stay resident (2 x 246 MB for the reference's models),
+        so ONE batch whose activations leave the split-f16 range is re-run in fp32 without re-packing anything, and the batches
+        after it stay in the default precision (byolo/inference.py, lib_yolo/model.py Model.run).  Parameters are copied when the
+        twin is made: call drop_twin() after changing this engine's parameters."""
+        if self._twin is not None and self._twin.precision == precision:
+            return self._twin
+        self.drop_twin()
+        t = Engine((self.cfg.img_h, self.cfg.img_w, self.cfg.img_c), self.cfg.cls_cnt, self.cfg.drop_prob, self.cfg.max_out,
+                   self.cfg.iou_thresh, self.cfg.nms_mode, bool(self.cfg.keep_all_outputs), self.device)
+        for name, args in self._graph:
+            getattr(t, name)(*args)
+        t.set_precision(precision)
+        t.set_params(self.get_params())
+        t.finalize()
+        self._twin = t
+        return t
+
+    def drop_twin(self):
+        if self._twin is not None:
+            self._twin.close()
+            self._twin = None
+
     def close(self):
+        self.drop_twin() if getattr(self, "_twin", None) is not None else None
         if getattr(self, "_h", None) and self._h.value:
             lib.byolo_destroy(self._h)
             self._h = ctypes.c_void_p()
@@ -124,28 +151,35 @@ class Engine:
 
     # ---- graph construction (lib_yolo/model.py ModelBuilder.make_*) -------------------------
     def add_conv(self, scope, filters, ksize, stride, norm_flags):
+        self._graph.append(('add_conv', (scope, filters, ksize, stride, norm_flags)))
         return check(self._h, lib.byolo_add_conv(self._h, scope.encode(), filters, ksize, stride, norm_flags))
 
     def add_residual(self, shortcut):
+        self._graph.append(('add_residual', (shortcut,)))
         return check(self._h, lib.byolo_add_residual(self._h, shortcut))
 
     def add_route(self, routes):
+        self._graph.append(('add_route', (list(routes),)))
         arr = (ctypes.c_int32 * len(routes))(*[int(r) for r in routes])
         return check(self._h, lib.byolo_add_route(self._h, arr, len(routes)))
 
     def add_upsample(self):
+        self._graph.append(('add_upsample', ()))
         return check(self._h, lib.byolo_add_upsample(self._h))
 
     def add_stack(self, src):
+        self._graph.append(('add_stack', (src,)))
         return check(self._h, lib.byolo_add_stack(self._h, int(src)))
 
     def add_detection(self, scope, kind, priors_hw):
+        self._graph.append(('add_detection', (scope, kind, [tuple(p) for p in priors_hw])))
         flat = [float(v) for p in priors_hw for v in p]
         assert len(flat) == 6, "exactly 3 priors (h, w) per detection layer"
         arr = (ctypes.c_float * 6)(*flat)
         return check(self._h, lib.byolo_add_detection(self._h, scope.encode(), int(kind), arr))
 
     def mark_backbone_end(self):
+        self._graph.append(('mark_backbone_end', ()))
         check(self._h, lib.byolo_mark_backbone_end(self._h))
 
     # ---- parameters ------------------------------------------------------------------------------
@@ -162,6 +196,7 @@ class Engine:
         return out
 
     def set_param(self, name, value):
+        self.drop_twin()                                  # a twin holds a copy of the parameters
         a = np.ascontiguousarray(value, dtype=np.float32)
         check(self._h, lib.byolo_set_param(self._h, name.encode(), a.ctypes.data, a.size))
 
@@ -331,6 +366,7 @@ class Engine:
         return out
 
     def calibrate_bn(self, img):
+        self.drop_twin()
         self._check_img(img)
         torch = _torch()
         B = int(img.shape[0])

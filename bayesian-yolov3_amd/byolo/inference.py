@@ -86,6 +86,20 @@ def bbox_to_ecp_format(bbox, img_size, model, config, variant):
     return out
 
 
+def _is_stock(fn, variant):
+    """True iff `fn` is an entry script's unedited `bbox_to_ecp_format`: its body is exactly the delegate into this module."""
+    import inspect
+    import sys
+    try:
+        src = inspect.getsource(fn)
+    except (OSError, TypeError):
+        return False
+    body = [l.strip() for l in src.splitlines()[1:] if l.strip() and not l.strip().startswith('#')]
+    g = getattr(fn, '__globals__', {})
+    return (body == ['return _inf.bbox_to_ecp_format(bbox, img_size, model, config, VARIANT)'] and g.get('VARIANT') == variant
+            and g.get('_inf') is sys.modules[__name__])
+
+
 # ---------------------------------------------------------------------------------------------------
 # checkpoints
 # ---------------------------------------------------------------------------------------------------
@@ -190,10 +204,18 @@ class InferenceLoop:
     masks one GPU would draw on the whole batch), ONE all-gather per batch (RCCL over xGMI) assembles the final box list -- and
     every rank's range status -- on every rank, and every rank writes the files of ITS images (rank 0 creates the directory).
 
-    BYOLO_ERR_RANGE (an activation beyond what split-f16 holds): all ranks read the same gathered status words, so they switch
-    to the fp32 mode TOGETHER, re-run the batches in flight and carry on in fp32 (`self.stats['precision_switches']`)."""
+    BYOLO_ERR_RANGE (an activation beyond what split-f16 holds): all ranks read the same gathered status words, so they act
+    TOGETHER: the offending global batch -- that batch only -- is re-run in the fp32 mode on every rank (on a second handle that
+    holds the same parameters packed for fp32: both packs stay resident, nothing is re-packed in mid-stream), the batches that
+    were in flight behind it are re-run in the default precision (the status word is sticky: their own verdict was lost), and the
+    run carries on in split-f16.  `stats['precision_switches']` counts both directions (two per such batch), `stats['fp32_batches']`
+    lists the batches; one JSON file per image regardless (`inference_epistemic.py:84-92`).  (Round 4 switched the whole job to
+    fp32 -- 0.49 x the throughput -- for the rest of the run.)
 
-    stock_to_ecp = None          # the script's own bbox_to_ecp_format: set by its Inference class
+    A feed failure on ONE rank (a corrupt record, a bad PNG in its block; every rank reads only its own records): the rank sends
+    a 'feed failed' status word in the batch's all-gather instead of rows, every rank sees it and all of them raise together
+     -- none is left waiting in a collective for a peer that is gone."""
+
 
     def __init__(self, yolo, config, variant, to_ecp, batched):
         from lib_yolo import dataset_utils
@@ -244,25 +266,36 @@ class InferenceLoop:
             restore(self.model, self.checkpoint)
 
     # ---- one batch: enqueue everything, wait for nothing ----------------------------------------------------------
-    def _enqueue(self, shard, step, slot):
+    FEED_FAILED = 1 << 30            # status flag of a rank whose feed raised: travels in the batch's all-gather like the range flags
+
+    def _enqueue(self, shard, step, slot, precision=None):
+        """A shard with `error` set: this rank's feed failed at this batch -- it still takes part in the batch's collective, with the
+        FEED_FAILED word instead of rows; every rank (this one included) raises when it retires the batch."""
         import contextlib
         import torch
         from byolo import dist as bdist
         eng = self.model.engine
-        n_loc = int(shard.u8.shape[0])
+        failed = getattr(shard, 'error', None) is not None
+        n_loc = 0 if failed else int(shard.u8.shape[0])
         bl = bdist.padded_block(shard.n_global, self.world)       # images per rank in the gathered buffer
         words = bl * self.cap * self.D + bl * self.cap + bl * 2 + 2
         send = slot.send[:words]
         rows, kept, count, status = slot.views(send, bl, self.cap, self.D)
         with (torch.cuda.stream(slot.stream) if self.cuda else contextlib.nullcontext()):
+            ran = eng
             if n_loc:
                 slot.u8[:n_loc].copy_(torch.from_numpy(shard.u8), non_blocking=True)          # pinned -> device, 1 byte per value
                 x = eng.normalize_u8(slot.u8[:n_loc], out=slot.img[:n_loc])                   # decode_img's * (1/255), on the device
-                self.model.run(x, seed=self.seed + step, want_boxes=False, first_image=shard.lo, slot=slot.ws_slot,
-                               out={'rows': rows[:n_loc], 'kept': kept[:n_loc], 'count': count[:n_loc]})
+                kw = {} if precision is None else {'precision': precision}
+                res = self.model.run(x, seed=self.seed + step, want_boxes=False, first_image=shard.lo, slot=slot.ws_slot,
+                                     out={'rows': rows[:n_loc], 'kept': kept[:n_loc], 'count': count[:n_loc]}, **kw)
+                ran = (res or {}).get('engine') or eng
             if n_loc < bl:
                 count[n_loc:].zero_()                             # padding images of a short block: nothing kept
-            eng.copy_status(status)                               # this rank's range status rides in the same buffer
+            if failed:
+                status[0] = self.FEED_FAILED; status[1] = -1
+            else:
+                ran.copy_status(status)                           # this rank's range status rides in the same buffer
             recv = send
             if self.pg:                                           # ONE collective per global batch
                 recv = slot.recv[:self.world * words]
@@ -271,7 +304,7 @@ class InferenceLoop:
             host.copy_(recv, non_blocking=True)
             if self.cuda:
                 slot.event.record(slot.stream)
-        return dict(shard=shard, step=step, slot=slot, bl=bl, words=words, n_loc=n_loc, host=host)
+        return dict(shard=shard, step=step, slot=slot, bl=bl, words=words, n_loc=n_loc, host=host, precision=precision)
 
     # ---- ... and its completion: the only place the host waits for the device ---------------------------------------
     def _complete(self, job):
@@ -285,6 +318,11 @@ class InferenceLoop:
         per_rank = job['host'].view(-1, words)
         for r in range(per_rank.shape[0]):
             flags = int(slot.views(per_rank[r], bl, self.cap, self.D)[3][0])
+            if flags & self.FEED_FAILED:
+                err = getattr(job['shard'], 'error', None)
+                if err is not None:
+                    raise err                                     # this rank's own feed error, at the batch it belongs to
+                raise RuntimeError('rank %d could not read its records of batch %d (see that rank\'s error): all ranks stop' % (r, job['step']))
             if flags:
                 self._range_rank = r
                 return False
@@ -295,26 +333,32 @@ class InferenceLoop:
         job['shard'].release()                                    # the frames have left the feed's buffer
         self._write_async(boxes, job['shard'].names)
         self.stats['images'] += job['n_loc']
+        self.stats['steady'].append((time.perf_counter(), self.stats['images']))
         return True
 
-    def _switch_to_fp32(self, jobs):
-        """Every rank runs this on the same batch (they all read the same gathered status words)."""
+    def _redo_out_of_range(self, jobs):
+        """Every rank runs this on the same batch (they all read the same gathered status words).  jobs[0] is the batch whose
+        status words came back raised; the others were enqueued behind it."""
         import torch
         eng = self.model.engine
-        logging.warning('rank %d reported BYOLO_ERR_RANGE in batch %d: all ranks switch to the fp32 mode and re-run from that batch',
-                        self._range_rank, jobs[0]['step'])
+        logging.warning('rank %d reported BYOLO_ERR_RANGE in batch %d: every rank re-runs THAT batch in the fp32 mode; the run stays in %s',
+                        self._range_rank, jobs[0]['step'], getattr(eng, 'precision', '?'))
         if self.cuda:
-            for j in jobs:                                        # whatever is still in flight ran in the old arithmetic
+            for j in jobs:                                        # whatever is still in flight ran with the sticky words raised
                 j['slot'].event.synchronize()
-        eng.clear_status()
-        eng.set_precision('f32')
-        self.model.finalize()                                     # re-packs the handle's parameters (incl. calibrated statistics) for fp32
-        eng.set_async(True)
-        self.stats['precision_switches'] += 1
-        for j in jobs:
+        eng.clear_status()                                        # on torch's current stream ...
+        if self.cuda:
+            torch.cuda.synchronize(self.dev)                      # ... while the re-runs' copy_status sits on the slots' streams (ADVICE r4)
+        self.stats['precision_switches'] += 1                     # -> fp32
+        redo = self._enqueue(jobs[0]['shard'], jobs[0]['step'], jobs[0]['slot'], precision='f32')
+        if not self._complete(redo):
+            raise RuntimeError('BYOLO_ERR_RANGE in the fp32 mode: a raw detection output is inf / NaN (batch %d)' % jobs[0]['step'])
+        self.stats['precision_switches'] += 1                     # -> back to the default precision
+        self.stats['fp32_batches'].append(jobs[0]['step'])
+        for j in jobs[1:]:
             redo = self._enqueue(j['shard'], j['step'], j['slot'])
             if not self._complete(redo):
-                raise RuntimeError('BYOLO_ERR_RANGE in the fp32 mode: a raw detection output is inf / NaN (batch %d)' % j['step'])
+                self._redo_out_of_range([redo])
 
     def run(self):
         import collections
@@ -326,6 +370,7 @@ class InferenceLoop:
         self.pg = torch.distributed.is_initialized()      # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
         self._load_weights()
         eng = self.model.engine
+        was_async = getattr(eng, '_async', False)
         eng.set_async(True)                               # no host wait inside forward(): the status words travel with the rows
         self.dev = eng.torch_device                       # (a CPU stand-in engine in the gloo tests names its own)
         self.cuda = str(self.dev).startswith('cuda')
@@ -333,7 +378,7 @@ class InferenceLoop:
         self.cap = eng.out_cap
         self.seed = int(self.config.get('seed', 0))
         self.stats = dict(images=0, batches=0, wait_feed_s=0.0, wait_device_s=0.0, wait_writer_s=0.0, precision_switches=0,
-                          native_json=False, device=getattr(eng, 'device', None), rank=rank, world=world)
+                          fp32_batches=[], steady=[], native_json=False, device=getattr(eng, 'device', None), rank=rank, world=world)
         bl_max = bdist.padded_block(self.batch_size, world)
         slots = [_Slot(self, k, bl_max, world if self.pg else 1) for k in range(2)]
         self._writer_setup()
@@ -343,12 +388,14 @@ class InferenceLoop:
 
         inflight = collections.deque()
         t_start = time.perf_counter()
-        feed = self.dataset.iter_shards_u8(rank, world, alloc=pinned, extra_buffers=len(slots) + 1)
+        feed = self.dataset.iter_shards_u8(rank, world, alloc=pinned, extra_buffers=len(slots) + 1, errors='yield')
         step = 0
         with ThreadPoolExecutor(max_workers=self.writer_threads, thread_name_prefix='byolo-writer') as self._pool:
             try:
                 while True:
                     t0 = time.perf_counter()
+                    # (a block this rank cannot read / check / decode arrives as a Shard with `error` set: the rank takes part in
+                    # that batch's all-gather with the FEED_FAILED word, and EVERY rank raises when it retires the batch -- ADVICE r4)
                     shard = next(feed, None)              # ends like tf.errors.OutOfRangeError
                     self.stats['wait_feed_s'] += time.perf_counter() - t0
                     if shard is None:
@@ -363,10 +410,18 @@ class InferenceLoop:
                     self._retire(inflight)
             finally:
                 feed.close()
+                eng.set_async(was_async)                  # a later Model.run() on this engine checks its status again
             self._writer_drain(0)
         self.stats['batches'] = step
         self.stats['loop_s'] = time.perf_counter() - t_start
         self.stats['precision'] = getattr(eng, 'precision', None)
+        # steady-state rate: images completed after the pipeline's fill (the first quarter of the batches, at least two) / the time
+        # they took -- the loop's wall time also holds the fill: the first decode, the first H2D, the first forward's plan
+        pts = self.stats.pop('steady')
+        k = min(len(pts) - 1, max(2, len(pts) // 4))
+        if k >= 1 and len(pts) > k and pts[-1][0] > pts[k][0]:
+            self.stats['steady_img_s'] = (pts[-1][1] - pts[k][1]) / (pts[-1][0] - pts[k][0])
+            self.stats['steady_images'] = pts[-1][1] - pts[k][1]
         logging.info('Processed {} batches.'.format(step))
         if self.pg:
             torch.distributed.barrier()                   # the files exist when any rank returns
@@ -378,7 +433,7 @@ class InferenceLoop:
             return
         jobs = list(inflight)
         inflight.clear()
-        self._switch_to_fp32(jobs)
+        self._redo_out_of_range(jobs)
 
     # ---- writer ---------------------------------------------------------------------------------------------------------
     def _writer_setup(self):
@@ -386,7 +441,12 @@ class InferenceLoop:
         self.writer_threads = max(1, int(self.config.get('writer_threads', 4)))
         self._pending = collections.deque()
         self._formatter = None
-        if self.stock_to_ecp is not None and self.to_ecp is self.stock_to_ecp:
+        # the native formatter writes what the SCRIPT'S OWN, UNEDITED bbox_to_ecp_format returns.  The reference invites users to
+        # edit that function (inference_epistemic.py:131 ff.: extra fields, other keys): `_is_stock` reads the function's SOURCE
+        # -- the stock one is a one-line delegate to this module -- so an edited or replaced function sends its dicts through
+        # json.dumps (the check used to compare the script's attribute with itself and was always true).
+        # config['native_json'] = False forces json.dumps as well.
+        if _is_stock(self.to_ecp, self.variant) and self.config.get('native_json', True):
             try:
                 from byolo import hostio
                 self._formatter = hostio.EcpJsonFormatter(self.variant, self.img_size, self.model.cls_cnt, self.model.obj_idx,
@@ -395,6 +455,7 @@ class InferenceLoop:
             except ValueError as e:                       # a label table the native formatter does not write
                 logging.info('ECP JSON through json.dumps: %s', e)
         self.stats['native_json'] = self._formatter is not None
+        logging.info('ECP JSON writer: %s', 'native formatter (byolo_format_ecp_json)' if self._formatter is not None else 'json.dumps of to_ecp dicts')
 
     def _write_async(self, boxes, files):
         for bxs, filename in zip(boxes, files):

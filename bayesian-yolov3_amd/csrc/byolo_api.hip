@@ -314,6 +314,7 @@ static int32_t guarded(byolo_t* h, const char* what, F&& f) {
     try { return f(); }
     catch (const std::bad_alloc&) { return fail(h, BYOLO_ERR_NOMEM, "%s: out of host memory", what); }
     catch (const std::exception& e) { return fail(h, BYOLO_ERR_ARG, "%s: %s", what, e.what()); }
+    catch (...) { return fail(h, BYOLO_ERR_ARG, "%s: an exception that is not a std::exception", what); }      // nothing crosses the C-ABI (include/byolo.h)
 }
 
 // Bounds of a convolution this library will hold on the host (the reference's largest: 1024 channels, 4.7 M weights): beyond them a
@@ -733,12 +734,16 @@ static void wino_scales(const byolo_t* h, const Layer& l, std::vector<float>& sc
 }
 
 // byolo_finalize packs ~62 M weights (hi/lo fragments, Winograd U in double): independent per launch, so on the host's cores.
-// BYOLO_FINALIZE_THREADS: worker threads (default: the cores, at most 32; 1 = in the calling thread).  The packed bytes do not
+// BYOLO_FINALIZE_THREADS: worker threads (default: the cores / LOCAL_WORLD_SIZE, at most 32; 1 = in the calling thread).  The packed bytes do not
 // depend on it (every element is computed by the same expression; tasks write disjoint ranges).
 template <class F>
 static bool parallel_tasks(int n, F&& f) {
     const char* e = getenv("BYOLO_FINALIZE_THREADS");
-    const int want = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    // one process per GPU: the N ranks of a node finalize at the same time -- each takes its share of the hardware threads
+    // (LOCAL_WORLD_SIZE is what torchrun exports; 8 ranks x 32 packing threads on one host was round 4's default)
+    const char* lw = getenv("LOCAL_WORLD_SIZE");
+    const int ranks = std::max(1, lw ? atoi(lw) : 1);
+    const int want = e ? atoi(e) : std::max(1, (int)std::thread::hardware_concurrency() / ranks);
     const int nt = std::min(n, std::max(1, std::min(want, 32)));
     std::atomic<int> next{0};
     std::atomic<bool> ok{true};

@@ -12,6 +12,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <charconv>
 #include <cmath>
@@ -71,18 +72,24 @@ bool unfilter_row(int ft, uint8_t* cur, const uint8_t* prev, size_t n) {
 struct BufPool {
     std::mutex m;
     std::vector<std::vector<uint8_t>> free;
+    size_t held = 0;                                   // bytes parked in `free`
+    // at most one scratch buffer per hardware thread and 256 MB in total stay parked (a 1024 x 1920 x 3 frame is 6 MB; round 4
+    // kept up to 128 buffers of the largest size ever asked for: ~0.75 GB for the life of the process -- ADVICE r4)
+    const size_t max_bufs = std::max(4u, std::min(128u, std::thread::hardware_concurrency()));
+    static constexpr size_t MAX_HELD = (size_t)256 << 20;
     std::vector<uint8_t> get(size_t n) {
         std::vector<uint8_t> b;
         {
             std::lock_guard<std::mutex> g(m);
-            if (!free.empty()) { b = std::move(free.back()); free.pop_back(); }
+            if (!free.empty()) { b = std::move(free.back()); free.pop_back(); held -= b.capacity(); }
         }
+        if (b.capacity() < n) b.clear();               // growth must not copy the old contents
         if (b.size() < n) b.resize(n);
         return b;
     }
     void put(std::vector<uint8_t>&& b) {
         std::lock_guard<std::mutex> g(m);
-        if (free.size() < 128) free.push_back(std::move(b));
+        if (free.size() < max_bufs && held + b.capacity() <= MAX_HELD) { held += b.capacity(); free.push_back(std::move(b)); }
     }
 };
 BufPool g_pool;

@@ -41,8 +41,6 @@ def concat_bbox(net_out):
 
 
 class Inference(_inf.InferenceLoop):
-    stock_to_ecp = staticmethod(bbox_to_ecp_format)     # written by the native formatter unless replaced (byolo/inference.py)
-
     def __init__(self, yolo, config):
         super().__init__(yolo, config, VARIANT, bbox_to_ecp_format, batched=True)
 

@@ -250,10 +250,11 @@ class _RecordFile:
         return memoryview(data)[:length]
 
 
-Shard = collections.namedtuple('Shard', 'u8 names lo n_global release')
+Shard = collections.namedtuple('Shard', 'u8 names lo n_global release error', defaults=(None,))
 Shard.__doc__ = """One rank's block of one global batch: u8 [n_local,H,W,C] uint8 (a view of a batch buffer: call release() when
 the frames have left it -- the buffer then goes back to the feeder), the block's file names, its offset `lo` in the global
-batch (-> first_image: the dropout stream position) and the global batch's size."""
+batch (-> first_image: the dropout stream position) and the global batch's size.  `error` (iter_shards_u8(errors='yield')
+only): the exception that reading / checking / decoding this rank's records of the batch raised -- the shard is then empty."""
 
 
 class TestingDataset:
@@ -270,6 +271,11 @@ class TestingDataset:
         self.shape = tuple(config['full_img_size'])
         self.verify_crc = info.get('verify_crc', True)
         self.threads = max(1, int(config.get('cpu_thread_cnt', 1)))          # num_parallel_calls of the map stage (:196)
+        # one process per GPU: N ranks x cpu_thread_cnt decode threads must fit the host (8 x 24 = 192 on a 256-thread node is fine,
+        # 8 x 24 on a 64-thread one is not): at most the rank's share of the hardware threads (LOCAL_WORLD_SIZE: torchrun)
+        local_world = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1))
+        self.threads = max(1, min(self.threads, (os.cpu_count() or 1) // local_world))
+        self._per_call = self.threads
         self.prefetch = int(info.get('prefetch', 0))                         # batches decoded ahead (:199 prefetches 1); 0 = derive it (iter_shards_u8)
         self.placeholder = _model.Placeholder((self.batch_size,) + self.shape)
 
@@ -323,7 +329,7 @@ class TestingDataset:
         h, w, c = self.shape
         assert buf.dtype == np.uint8 and buf.flags['C_CONTIGUOUS'] and buf.shape[0] >= n and tuple(buf.shape[1:]) == self.shape
         rc = _lib.lib.byolo_feed_records(fds, offs, lens, n, int(bool(self.verify_crc)), h, w, c, ctypes.c_void_p(buf.ctypes.data),
-                                         self.threads, names, cap, status, found)
+                                         self._per_call, names, cap, status, found)
         if rc < 0:
             raise ValueError('byolo_feed_records: bad argument (full_img_size {})'.format(self.shape))
         out = []
@@ -354,7 +360,7 @@ class TestingDataset:
             sh.release()
             yield x, sh.names
 
-    def iter_shards_u8(self, rank, world, alloc=None, extra_buffers=2):
+    def iter_shards_u8(self, rank, world, alloc=None, extra_buffers=2, errors='raise'):
         """Yields a `Shard` per global batch: the frames of this rank's contiguous block (byolo.dist.shard_range; may be empty
         for a last, short batch).  alloc(shape) -> uint8 ndarray provides the batch buffers (the driver passes pinned memory);
         `prefetch` + 1 + extra_buffers of them circulate: `prefetch` decoded or being decoded ahead of the consumer,
@@ -364,12 +370,19 @@ class TestingDataset:
         decode pool TOGETHER (each on min(cpu_thread_cnt, images of its block) native threads) and are handed over in order --
         at the reference's default batch_size = 1 (inference_epistemic.py:222) a 1024 x 1920 frame is 50 ms of inflate on one
         core, so one batch at a time would feed 20 img/s to a device that takes 41.  `prefetch` defaults to
-        max(2, cpu_thread_cnt / images per block), at most 16."""
+        max(2, cpu_thread_cnt / images per block), at most 16.
+
+        errors='raise': a record of this rank's block that cannot be read / checked / decoded raises here, at its batch's position.
+        errors='yield': the batch arrives as an empty Shard carrying the exception (`error`) and the iteration goes on -- the
+        multi-GPU driver needs that: the other ranks read only THEIR records and are about to enter the batch's collective, so
+        this rank must take part in it (with a 'feed failed' status word) instead of leaving (byolo/inference.py)."""
         from concurrent.futures import ThreadPoolExecutor
         from byolo.dist import shard_range
         alloc = alloc or (lambda shape: np.empty(shape, dtype=np.uint8))
         cap = max(1, shard_range(self.batch_size, 0, world)[1])              # the largest block of a full batch
         prefetch = self.prefetch if self.prefetch > 0 else max(2, min(16, -(-self.threads // cap)))
+        # `prefetch` calls decode at once: each gets its share of cpu_thread_cnt (a block of 64 images used to start 2 x 24 threads)
+        self._per_call = max(1, -(-self.threads // prefetch))
         free = queue.Queue()
         for _ in range(prefetch + 1 + max(1, extra_buffers)):
             free.put(alloc((cap,) + self.shape))
@@ -386,7 +399,10 @@ class TestingDataset:
             return False
 
         def load(recs, buf, lo, n_glob):
-            return buf, len(recs), self._load_block(recs, buf), lo, n_glob   # a failed record raises at the consumer, in order
+            try:
+                return buf, len(recs), self._load_block(recs, buf), lo, n_glob
+            except Exception as e:                                           # a failed record reaches the consumer in order
+                return buf, 0, e, lo, n_glob
 
         def feeder():
             pool = ThreadPoolExecutor(max_workers=prefetch, thread_name_prefix='byolo-feed')
@@ -419,6 +435,11 @@ class TestingDataset:
                 if isinstance(item, BaseException):
                     raise item
                 buf, n, names, lo, n_glob = item.result()
+                if isinstance(names, Exception):
+                    if errors != 'yield':
+                        raise names
+                    yield Shard(buf[:0], [], lo, n_glob, (lambda b=buf: free.put(b)), names)
+                    continue
                 yield Shard(buf[:n], names, lo, n_glob, (lambda b=buf: free.put(b)))
         finally:
             stop.set()

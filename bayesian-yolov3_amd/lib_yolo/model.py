@@ -256,9 +256,11 @@ class Model:
     # ---- the counterpart of sess.run --------------------------------------------------------------
     def finalize(self):
         self.engine.finalize()
+        self._reg = None                # weights may have been restored / calibrated since the last access
         return self
 
-    def run(self, img, seed=0, dropout_on=True, want_boxes=True, want_nms=True, first_image=0, out=None, mask_bits=None, slot=0):
+    def run(self, img, seed=0, dropout_on=True, want_boxes=True, want_nms=True, first_image=0, out=None, mask_bits=None, slot=0,
+            precision=None):
         """img: float32 CUDA tensor [B,H,W,C] in [0,1).  Returns the dict of Engine.forward and keeps
         it as `self.last`, which the DetLayer accessors read.  `first_image`: position of img[0] in the logical
         (multi-GPU / split) batch; `out`: preallocated rows / kept / count tensors; `mask_bits`: injected dropout
@@ -266,29 +268,44 @@ class Model:
 
         The reference computes in float32 (`lib_yolo/layers.py:550`), which holds any activation a trained checkpoint
         produces.  The default split-f16 arithmetic holds |activation| <= 16376: the library detects anything beyond
-        (BYOLO_ERR_RANGE), and this wrapper then re-runs the batch -- and everything after it -- in the fp32 mode, with
-        a warning, instead of handing out rows the reference would not produce; `self.precision_switches` counts those
-        switches and the returned dict says which arithmetic produced it ('precision').  This is the ONE-process behaviour
-        (detect.py, vis_uncertainty.py, tests); `self.range_fallback = False` turns it into a plain ByoloError.  The
-        multi-GPU driver (byolo/inference.py) runs the engine asynchronously -- the wrapper then never switches by itself --
-        and lets all ranks agree on the switch through the status words its all-gather carries.
+        (BYOLO_ERR_RANGE), and this wrapper then re-runs THAT BATCH in the fp32 mode, with a warning, instead of handing out
+        rows the reference would not produce -- on a second handle that holds the same parameters packed for fp32
+        (Engine.twin: both packs stay resident), so the batches after it run in the default precision again (round 4 switched
+        the model for the rest of the run and re-packed in mid-stream).  `self.precision_switches` counts the switches in BOTH
+        directions (two per such batch) and the returned dict says which arithmetic produced it ('precision').  This is the
+        ONE-process behaviour (detect.py, vis_uncertainty.py, tests); `self.range_fallback = False` turns it into a plain
+        ByoloError.  The multi-GPU driver (byolo/inference.py) runs the engine asynchronously -- the wrapper then never
+        decides by itself -- lets all ranks agree through the status words its all-gather carries and asks for the re-run
+        with `precision='f32'`.
         `slot`: workspace arena of the call (forwards in flight on different HIP streams must not share one)."""
         if not self.engine.finalized:
             self.engine.finalize()
         kw = dict(T=self.T, seed=seed, dropout_on=dropout_on, want_boxes=want_boxes, want_nms=want_nms,
                   first_image=first_image, out=out, mask_bits=mask_bits, slot=slot)
+        if precision is not None and precision != self.engine.precision:
+            eng = self.engine.twin(precision)
+            if getattr(self.engine, '_async', False):
+                eng.set_async(True)
+            self.last = eng.forward(img, **kw)
+            self.last['precision'] = eng.precision
+            self.last['engine'] = eng
+            return self.last
         try:
             self.last = self.engine.forward(img, **kw)
         except ByoloError as e:
             if e.code != ERR_RANGE or self.engine.precision != 'split' or getattr(self.engine, '_async', False) or not self.range_fallback:
                 raise
             import logging
-            logging.warning('%s -- switching this model to the fp32 mode', e)
-            self.engine.set_precision('f32')
-            self.engine.finalize()
-            self.precision_switches += 1
-            self.last = self.engine.forward(img, **kw)
+            logging.warning('%s -- this batch is re-run in the fp32 mode', e)
+            self.engine.clear_status()
+            eng = self.engine.twin('f32')
+            self.precision_switches += 2                  # to fp32 and back
+            self.last = eng.forward(img, **kw)
+            self.last['precision'] = 'f32'
+            self.last['engine'] = eng
+            return self.last
         self.last['precision'] = self.engine.precision
+        self.last['engine'] = self.engine
         return self.last
 
     def matches_blueprint(self, blueprint):
@@ -452,8 +469,10 @@ class DetLayer:
 
     @property
     def raw_output(self):
-        """Raw detection-conv output [S,lh,lw,F] of the last run."""
-        return self._model.engine.layer_output(self._raw_ref.index)
+        """Raw detection-conv output [S,lh,lw,F] of the last run (of the handle that ran it: a batch beyond the split-f16 range
+        ran on the fp32 twin, Model.run)."""
+        eng = (self._model.last or {}).get('engine') or self._model.engine
+        return eng.layer_output(self._raw_ref.index)
 
     def matches_blueprint(self, blueprint):
         try:

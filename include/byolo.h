@@ -140,7 +140,8 @@ BYOLO_API int32_t byolo_set_param(byolo_t* h, const char* name, const float* h_d
 BYOLO_API int32_t byolo_get_param(const byolo_t* h, const char* name, float* h_data, int64_t count);
 /* fold BN (+ 1/keep_prob) into per-channel scale/shift, repack kernels for the MFMA tiles, upload.
  * May be called again after further byolo_set_param calls.  Packs on the host's cores (environment
- * BYOLO_FINALIZE_THREADS: default all, at most 32; the packed bytes do not depend on it). */
+ * BYOLO_FINALIZE_THREADS: default the hardware threads / LOCAL_WORLD_SIZE -- one process per GPU, the ranks of a node finalize
+ * together --, at most 32; the packed bytes do not depend on it). */
 BYOLO_API int32_t byolo_finalize(byolo_t* h);
 
 /* ---- run: one sess.run([nms_op]) (inference_epistemic.py:76, inference_aleatoric.py:75) ------ */

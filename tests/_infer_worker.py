@@ -64,12 +64,14 @@ class FakeModel:
     def finalize(self):
         self.engine.finalize()
 
-    def run(self, x, seed=0, want_boxes=True, first_image=0, out=None, **kw):
+    def run(self, x, seed=0, want_boxes=True, first_image=0, out=None, precision=None, **kw):
         import torch
         eng = self.engine
         eng.forwards += 1
         self.calls.append((int(x.shape[0]), int(first_image), int(seed)))
-        if eng.precision == "split" and eng.raise_in == eng.forwards:
+        if precision is not None:                    # Model.run(precision='f32'): THIS batch on the fp32 twin handle
+            eng.log.append("run:%s:%d" % (precision, seed))
+        if precision is None and eng.precision == "split" and eng.raise_in == eng.forwards:
             eng.flags = 1                            # what the epilogues do on the device; the rows are then garbage
             out["rows"].fill_(float("nan"))
             out["count"].fill_(3)

@@ -135,10 +135,14 @@ def tensors():
     return t
 
 
-def main(block_size=700):
-    os.makedirs(OUT, exist_ok=True)
+def main(block_size=700, restart_interval=16, out=None):
+    """`block_size`, `restart_interval`: table_builder.cc's Options::block_size (TensorFlow: 256 KB) and
+    Options::block_restart_interval (16).  tests/test_checkpoint.py writes the same tensors under OTHER values of both into a
+    temporary directory: a reader fitted to this one fixture's geometry would not read those."""
+    out = out or OUT
+    os.makedirs(out, exist_ok=True)
     t = tensors()
-    prefix = os.path.join(OUT, "model-4242")
+    prefix = os.path.join(out, "model-4242")
     keys = sorted(t, key=lambda s: s.encode())
     items, offset = [(b"", header_proto())], 0
     with open(prefix + ".data-00000-of-00001", "wb") as f:
@@ -153,7 +157,7 @@ def main(block_size=700):
             trailer = b"\x00"                                                              # kNoCompression
             f.write(block + trailer + struct.pack("<I", masked(crc32c(block + trailer))))
             return varint(pos) + varint(len(block))
-        index, bb, pending = BlockBuilder(restart_interval=1), BlockBuilder(), None
+        index, bb, pending = BlockBuilder(restart_interval=1), BlockBuilder(restart_interval), None
         for key, val in items:
             if pending is not None:                                                        # first key of the next block is known now
                 index.add(shortest_separator(pending[0], key), pending[1])
@@ -161,7 +165,7 @@ def main(block_size=700):
             bb.add(key, val)
             if bb.size() >= block_size:
                 pending = (bb.last, emit(bb.finish()))
-                bb = BlockBuilder()
+                bb = BlockBuilder(restart_interval)
         if bb.n:
             pending = (bb.last, emit(bb.finish()))
         index.add(short_successor(pending[0]), pending[1])

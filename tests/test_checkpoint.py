@@ -141,6 +141,38 @@ def test_hand_assembled_bundle_fixture():
     assert len(sub) == 6 * 5 + 2                                     # what a restore into the model asks for
 
 
+@pytest.mark.parametrize("block_size,restart_interval", [(262144, 16), (97, 16), (700, 1), (700, 2), (1500, 64), (4096, 3)])
+def test_bundles_of_other_block_sizes_and_restart_intervals(block_size, restart_interval, tmp_path):
+    """The committed fixture has ONE geometry (block size 700, restart interval 16).  The independent writer
+    (tests/golden/make_bundle_fixture.py) lays the same tensors out under other values of table_builder.cc's two knobs --
+    TensorFlow's own default block size (256 KB: the whole index is one data block, as for a real YOLOv3 checkpoint), blocks of
+    less than one entry's size (every entry its own block: only restart points, shared = 0), restart at every entry / every
+    second entry (no or little prefix compression), an interval longer than a block, an odd one -- and the reader must return
+    the same tensors.  Which published rule each byte follows:
+      entry        table_format.txt "shared_bytes: varint32 | unshared_bytes: varint32 | value_length: varint32 | key_delta | value";
+      block tail   table_format.txt "restarts: uint32[num_restarts] | num_restarts: uint32"; shared_bytes = 0 at a restart point;
+      trailer      format.cc kBlockTrailerSize = 5: "type: uint8 | crc: uint32" with crc32c::Mask(crc of block + type);
+      index block  block handles "offset: varint64 | size: varint64", keys by FindShortestSeparator / FindShortSuccessor;
+      footer       format.h Footer::kEncodedLength = 2 * BlockHandle::kMaxEncodedLength + 8 = 48, magic 0xdb4775248b80fb57;
+      values       tensor_bundle.proto BundleHeaderProto / BundleEntryProto, proto3 wire format (zero fields omitted)."""
+    import importlib.util
+    from conftest import GOLDEN
+    spec = importlib.util.spec_from_file_location("make_bundle_fixture", os.path.join(GOLDEN, "make_bundle_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    mk.main(block_size=block_size, restart_interval=restart_interval, out=str(tmp_path))
+    want = mk.tensors()
+    got = tc.read(str(tmp_path / "model-4242"))
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+    # and the committed fixture is byte-identical to what the writer makes at ITS geometry (the generator is the fixture's definition)
+    if (block_size, restart_interval) == (700, 1):
+        mk.main(block_size=700, restart_interval=16, out=str(tmp_path / "same"))
+        for ext in (".index", ".data-00000-of-00001"):
+            assert open(os.path.join(GOLDEN, "tf_bundle", "model-4242" + ext), "rb").read() == open(str(tmp_path / "same" / ("model-4242" + ext)), "rb").read()
+
+
 def test_find_and_restore(tmp_path):
     from byolo import inference as inf
     from conftest import build_model, golden_params

@@ -173,8 +173,9 @@ def test_inference_epistemic_world2_writes_the_single_process_json(tmp_path):
 @pytest.mark.parametrize("raise_rank,raise_call", [(1, 1), (0, 2), (0, 3)])
 def test_inference_world2_ranks_switch_to_fp32_together(tmp_path, raise_rank, raise_call):
     """BYOLO_ERR_RANGE on ONE rank (the stand-in raises its status words in one forward and returns garbage rows, as the device
-    does): the words travel in the batch's all-gather, so BOTH ranks switch to the fp32 mode at the same batch, re-run what was in
-    flight and write exactly the files of an undisturbed run -- no rank is left in another arithmetic, nothing hangs."""
+    does): the words travel in the batch's all-gather, so BOTH ranks re-run THAT global batch in the fp32 mode (round 5: that batch
+    only, `Model.run(precision='f32')` on the twin handle), re-run what was in flight behind it in the default precision, stay in
+    split-f16 and write exactly the files of an undisturbed run -- no rank is left in another arithmetic, nothing hangs."""
     import json
     _records(tmp_path, 11)
     rc1, o1 = _run_infer(1, tmp_path, str(tmp_path / "one" / "run"))
@@ -186,16 +187,42 @@ def test_inference_world2_ranks_switch_to_fp32_together(tmp_path, raise_rank, ra
     for f in os.listdir(a):
         assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
     c = [json.load(open(tmp_path / ("calls_w2_r%d.json" % r))) for r in range(2)]
+    bad = raise_call                                     # the global batch whose status words came back raised (seed = 3 + batch)
     for r in range(2):
-        assert c[r]["precision"] == "f32" and c[r]["stats"]["precision_switches"] == 1
-        assert c[r]["log"].count("precision:f32") == 1 and "finalize:f32" in c[r]["log"]
-    # both ranks re-ran from the SAME batch: the seeds of the repeated calls agree
-    redo = [[s for (_, _, s) in c[r]["calls"] if [x[2] for x in c[r]["calls"]].count(s) > 1] for r in range(2)]
-    assert redo[0] and min(redo[0]) == 3 + raise_call
-    if raise_call < 3:                                  # (rank 1's block of the third, short batch is empty: nothing to re-run)
-        assert redo[1] and min(redo[1]) == 3 + raise_call
-    else:
-        assert redo[1] == []
+        assert c[r]["precision"] == "split" and c[r]["stats"]["precision"] == "split"
+        assert c[r]["stats"]["precision_switches"] == 2 and c[r]["stats"]["fp32_batches"] == [bad]
+        assert "precision:f32" not in c[r]["log"] and "finalize:f32" not in c[r]["log"]            # nothing is re-packed in mid-stream
+    # both ranks re-ran the SAME batch in fp32 (rank 1's block of the third, short batch is empty: nothing to run there)
+    assert [l for l in c[0]["log"] if l.startswith("run:")] == ["run:f32:%d" % (3 + bad)]
+    assert [l for l in c[1]["log"] if l.startswith("run:")] == (["run:f32:%d" % (3 + bad)] if bad < 3 else [])
+    # ... and the batch in flight behind it once more in the default precision: the seeds of the repeated calls agree
+    redo = [sorted({s for (_, _, s) in c[r]["calls"] if [x[2] for x in c[r]["calls"]].count(s) > 1}) for r in range(2)]
+    assert redo[0] == [3 + b_ for b_ in range(bad, min(bad + 2, 4))]
+    assert redo[1] == [3 + b_ for b_ in range(bad, min(bad + 2, 3))]
+
+
+def test_inference_world2_feed_failure_on_one_rank_stops_both(tmp_path):
+    """every rank reads, CRC-checks and decodes only ITS block of a global batch, so a corrupt record raises on one rank
+    only -- while the other is already queued in that batch's all-gather.  The failing rank takes part in the collective with a
+    'feed failed' status word, the other rank reads it in the gathered buffer and raises too: both processes end within seconds
+    instead of one waiting for the backend's timeout."""
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "bayesian-yolov3_amd"))
+    from lib_yolo import dataset_utils as du
+    _records(tmp_path, 11)
+    p = str(tmp_path / "val-00000-of-00001")
+    raw = bytearray(open(p, "rb").read())
+    recs = list(du._RecordFile(p, True))
+    raw[recs[8][1] + 40] ^= 0xFF                       # record 8 = batch 2 (records 5..9), rank 1's block [8, 10) at world 2
+    open(p, "wb").write(bytes(raw))
+    t0 = time.time()
+    rc, outs = _run_infer(2, tmp_path, str(tmp_path / "out" / "run"), timeout=120)
+    assert time.time() - t0 < 90
+    assert rc[0] != 0 and rc[1] != 0, (rc, outs)
+    assert "CRC" in outs[1], outs[1][-1500:]
+    assert "rank 1 could not read its records of batch 2" in outs[0], outs[0][-1500:]
+    # the batch before the corrupt one was written by both ranks
+    assert sorted(os.listdir(tmp_path / "out" / "run_0")) == ["f%02d.json" % i for i in range(5)]
 
 
 def test_inference_world2_ranks_stop_together_when_the_output_directory_exists(tmp_path):

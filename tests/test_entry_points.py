@@ -249,9 +249,9 @@ def test_normalize_u8_on_the_device_is_the_host_conversion():
 
 @pytest.mark.gpu
 def test_inference_loop_switches_to_fp32_on_a_range_error(tmp_path, monkeypatch):
-    """A checkpoint whose activations leave the split-f16 range (BN gamma 3e4 in darknet53/conv_10): the pipelined driver loop
-    finds BYOLO_ERR_RANGE in the status words that come back with the FIRST batch's rows, switches to the fp32 mode, re-runs the
-    two batches in flight and carries on -- the files are those of a run that was in the fp32 mode from the start."""
+    """A checkpoint whose activations leave the split-f16 range on EVERY frame (BN gamma 3e4 in darknet53/conv_10): the pipelined
+    driver loop finds BYOLO_ERR_RANGE in the status words that come back with each batch's rows and re-runs that batch on the
+    fp32 twin handle -- the files are those of a run that was in the fp32 mode from the start."""
     import inference_epistemic as mod
     imgs, names = _make_records(tmp_path, 5)
     ck = tmp_path / "checkpoints" / "run"
@@ -263,7 +263,8 @@ def test_inference_loop_switches_to_fp32_on_a_range_error(tmp_path, monkeypatch)
                       run_id="run", step="last", seed=10, data={"file_pattern": str(tmp_path / "ecp-day-val-*-of-*")})
     monkeypatch.setenv("BYOLO_PRECISION", "split")
     s1 = mod.inference(dict(cfg, out_path=str(tmp_path / "split" / "run")))
-    assert s1["precision_switches"] == 1 and s1["precision"] == "f32" and s1["images"] == 5
+    # every one of the three batches leaves the range: each is re-run in fp32 (two switches per batch), the run itself stays in split-f16
+    assert s1["precision_switches"] == 6 and s1["fp32_batches"] == [1, 2, 3] and s1["precision"] == "split" and s1["images"] == 5
     monkeypatch.setenv("BYOLO_PRECISION", "f32")
     s2 = mod.inference(dict(cfg, out_path=str(tmp_path / "f32" / "run")))
     assert s2["precision_switches"] == 0 and s2["precision"] == "f32"
@@ -271,6 +272,123 @@ def test_inference_loop_switches_to_fp32_on_a_range_error(tmp_path, monkeypatch)
     assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == sorted(n.replace(".png", ".json") for n in names)
     for f in os.listdir(a):
         assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+
+
+def _one_hot_frame_records(tmp_path, frames, H=64, W=96):
+    from lib_yolo import dataset_utils as du
+    names = ["city_%03d.png" % i for i in range(len(frames))]
+    du.write_tfrecords(str(tmp_path / "ecp-day-val-00000-of-00001"),
+                       [du.make_example({"image/encoded": _png(f), "image/filename": n, "image/height": H, "image/width": W}) for f, n in zip(frames, names)])
+    return names
+
+
+@pytest.mark.gpu
+def test_only_the_batch_beyond_the_range_runs_in_fp32(tmp_path, monkeypatch):
+    """the fp32 fall-back is per batch.  Five frames at batch_size 1; frame 2 is a full-contrast pattern, the
+    others are low-contrast noise, and the BN gamma / beta of det_net_2/conv are scaled so that -- by the ORACLE's own activations,
+    asserted below -- frame 2 alone leaves the split-f16 range (|activation| > 16376) while the others stay below a quarter of it.
+    Expected: batch 3 (frame 2) re-runs in fp32 on every rank, the run stays in split-f16 (`precision`), `precision_switches`
+    counts both directions, `fp32_batches` == [3]; frame 2's file is the file of a run that was in fp32 from the start; the files
+    of the frames AFTER it are byte-identical to those of a run in which frame 2 is replaced by a harmless frame (same seeds, same
+    positions): nothing of the fall-back leaks into the batches behind it -- one JSON per image regardless
+    (inference_epistemic.py:84-92)."""
+    import torch
+    import inference_epistemic as mod
+    from oracle import cpu_ref
+    variant = "bayesian_yolov3_aleatoric"
+    rng = np.random.default_rng(3)
+    H, W = 64, 96
+    frames = [(rng.integers(118, 138, (H, W, 3))).astype(np.uint8) for _ in range(5)]
+    hot = np.zeros((H, W, 3), np.uint8)
+    hot[::2, 1::2] = 255; hot[1::2, ::2] = 255                     # checkerboard: the largest responses a 3x3 stack can see
+    calm = frames[0].copy()
+    p = {k: v.copy() for k, v in golden_params(variant).items()}
+    # gamma and beta of det_net_2/conv (a plain conv-BN-leaky layer: where the hot frame's response peaks) x 200: its output scales
+    # by exactly 200.  The premise is checked on the ORACLE's activations (float32 CPU restatement, every conv / residual output):
+    # the hot frame beyond 4 x the range, every other frame below a quarter of it
+    for v in ("gamma", "beta"):
+        p["det_net_2/conv/batch_normalization/" + v] = p["det_net_2/conv/batch_normalization/" + v] * np.float32(200)
+
+    def amax(frame):
+        x = (frame.astype(np.float32) * np.float32(1 / 255.))[None]
+        with torch.no_grad():
+            f = cpu_ref.forward(cpu_ref.to_torch_params(p), x, variant, T=1, seed=0, taps="all", dropout_off=True)
+        return max(float(t.abs().max()) for i, t in f["layers"].items() if f["topo"][i]["op"] in ("conv", "residual"))
+    a_hot, a_rest = amax(hot), max(amax(f) for f in frames + [calm])
+    print("largest |activation|: hot frame %.3g, the others <= %.3g (split-f16 holds 16376)" % (a_hot, a_rest))
+    assert a_hot > 4 * 16376 and a_rest < 16376 / 4, "the test's premise does not hold"
+    ck = tmp_path / "checkpoints" / "run"
+    ck.mkdir(parents=True)
+    np.savez(str(ck / "model-5.npz"), **p)
+    base = dict(T=3, batch_size=1, checkpoint_path=str(tmp_path / "checkpoints"), run_id="run", step="last", seed=10)
+    runs = {}
+    for tag, fr, prec in (("mixed", frames[:2] + [hot] + frames[3:], "split"), ("calm", frames[:2] + [calm] + frames[3:], "split"),
+                          ("f32", frames[:2] + [hot] + frames[3:], "f32")):
+        d = tmp_path / tag
+        d.mkdir()
+        names = _one_hot_frame_records(d, fr)
+        monkeypatch.setenv("BYOLO_PRECISION", prec)
+        cfg = make_config(variant, H, W, data={"file_pattern": str(d / "ecp-day-val-*-of-*")}, out_path=str(d / "out" / "run"), **base)
+        runs[tag] = (mod.inference(cfg), str(d / "out" / "run_5"), names)
+    s, out, names = runs["mixed"]
+    assert s["images"] == 5 and s["precision"] == "split", s
+    assert s["fp32_batches"] == [3] and s["precision_switches"] == 2, s
+    assert runs["calm"][0]["precision_switches"] == 0 and runs["calm"][0]["fp32_batches"] == []
+    assert runs["f32"][0]["precision"] == "f32" and runs["f32"][0]["precision_switches"] == 0
+    rd = lambda tag, i: open(os.path.join(runs[tag][1], names[i].replace(".png", ".json"))).read()
+    assert rd("mixed", 2) == rd("f32", 2), "the re-run batch is not the fp32 mode's result"
+    for i in (0, 1, 3, 4):
+        assert rd("mixed", i) == rd("calm", i), "frame %d differs from the run without the hot frame" % i
+        assert rd("mixed", i) != rd("f32", i) or i < 0            # (split-f16 and fp32 rows differ in the last bits: the files are not the fp32 run's)
+
+
+def test_the_native_json_writer_is_only_for_the_unedited_stock_function():
+    """the reference invites users to edit `bbox_to_ecp_format` (inference_epistemic.py:131 ff.).  The native formatter
+    stands in for the script's function only while that function is the unedited one-line delegate (byolo.inference._is_stock
+    reads its source); anything else goes through json.dumps of the function's own dicts."""
+    from byolo import inference as binf
+    import inference_epistemic, inference_aleatoric, inference_standard_yolov3
+    for mod, v in ((inference_epistemic, "bayesian_yolov3_aleatoric"), (inference_aleatoric, "yolov3_aleatoric"), (inference_standard_yolov3, "yolov3")):
+        assert binf._is_stock(mod.bbox_to_ecp_format, v)
+        assert not binf._is_stock(mod.bbox_to_ecp_format, "other")
+    ns = {"_inf": binf, "VARIANT": "bayesian_yolov3_aleatoric"}
+    src = ("def bbox_to_ecp_format(bbox, img_size, model, config):\n"
+           "    d = _inf.bbox_to_ecp_format(bbox, img_size, model, config, VARIANT)\n"
+           "    d['extra'] = 1\n"
+           "    return d\n")
+    import linecache
+    linecache.cache["<edited>"] = (len(src), None, src.splitlines(True), "<edited>")
+    exec(compile(src, "<edited>", "exec"), ns)
+    assert not binf._is_stock(ns["bbox_to_ecp_format"], "bayesian_yolov3_aleatoric")
+    assert not binf._is_stock(lambda *a: {}, "yolov3")
+
+
+@pytest.mark.gpu
+def test_an_edited_bbox_to_ecp_format_is_what_gets_written(tmp_path, monkeypatch):
+    """... end to end: the edited function's extra field is in every file, and stats['native_json'] says which writer ran."""
+    import inference_aleatoric as mod
+    imgs, names = _make_records(tmp_path, 2)
+    ck = tmp_path / "checkpoints" / "run"
+    ck.mkdir(parents=True)
+    np.savez(str(ck / "model-9.npz"), **golden_params("yolov3_aleatoric"))
+    cfg = make_config("yolov3_aleatoric", 64, 96, batch_size=2, checkpoint_path=str(tmp_path / "checkpoints"), run_id="run", step="last",
+                      data={"file_pattern": str(tmp_path / "ecp-day-val-*-of-*")})
+    s0 = mod.inference(dict(cfg, out_path=str(tmp_path / "stock" / "run")))
+    assert s0["native_json"]
+    stock = mod.bbox_to_ecp_format
+
+    def edited(bbox, img_size, model, config):
+        d = stock(bbox, img_size, model, config)
+        d["frame_area"] = img_size[0] * img_size[1]
+        return d
+    monkeypatch.setattr(mod, "bbox_to_ecp_format", edited)
+    s1 = mod.inference(dict(cfg, out_path=str(tmp_path / "edited" / "run")))
+    assert not s1["native_json"]
+    for n in names:
+        a = json.load(open(str(tmp_path / "stock" / "run_9" / n.replace(".png", ".json"))))["children"]
+        b = json.load(open(str(tmp_path / "edited" / "run_9" / n.replace(".png", ".json"))))["children"]
+        assert len(a) == len(b) > 0 and all(y["frame_area"] == 64 * 96 for y in b)
+        assert [{k: v for k, v in y.items() if k != "frame_area"} for y in b] == a
 
 
 @pytest.mark.gpu

@@ -260,6 +260,43 @@ def test_darknet_weight_loader(tmp_path):
         yolo2.load_darknet53_weights(str(tmp_path / "short"))
 
 
+@pytest.mark.parametrize("case", ["yolov3/backbone", "yolov3/all", "bayesian_yolov3_aleatoric/all"])
+def test_darknet_weight_loader_equals_the_references_own_loader(case, tmp_path):
+    """SURVEY 8(f) item 2, pinned to REFERENCE OUTPUT: tests/golden/darknet_weights.json holds, per variable,
+    the SHA-256 of what the reference's own importer (lib_yolo/darknet.py:42-122, run unmodified under the shim by
+    oracle/make_golden_weights.py) assigned from a file of structureless seeded float32 words.  The same bytes are regenerated
+    here -- five int32 header words + numpy's default_rng(seed).standard_normal stream, no reading of the format involved --,
+    the product's loader runs, and every variable must hold the same bits.  `backbone`: yolo.load_darknet53_weights (the call the
+    training scripts make, lib_yolo/yolov3.py:220-222); `all`: load_darknet_weights(model.layers, ...), head scopes included; the
+    detection convolutions are skipped by the reference (no 'LeakyRelu' in their layer name, darknet.py:56) and stay untouched."""
+    import hashlib
+    from lib_yolo import darknet
+    g = golden("darknet_weights.json")
+    c = g["cases"][case]
+    variant, which = case.split("/")
+    yolo, m = build_model(variant, 64, 64, T=2)
+    shapes = m.engine.param_shapes()
+    before = {n: m.engine.get_param(n, shapes[n]).copy() for n in c["untouched"]}
+    path = tmp_path / "synthetic.weights"
+    with open(path, "wb") as f:
+        f.write(np.asarray(g["header"], dtype=np.int32).tobytes())
+        rng = np.random.default_rng(g["seed"])
+        left = c["floats"]
+        while left > 0:
+            n = min(left, 1 << 22)
+            f.write(rng.standard_normal(n, dtype=np.float32).tobytes())
+            left -= n
+    assigned = yolo.load_darknet53_weights(str(path)) if which == "backbone" else darknet.load_darknet_weights(m.layers, str(path))
+    assert len(assigned) == c["assign_ops"] and sorted(assigned) == sorted(c["variables"])
+    for name, d in c["variables"].items():
+        got = np.ascontiguousarray(m.engine.get_param(name, shapes[name]), dtype=np.float32)
+        assert list(got.shape) == d["shape"], name
+        assert hashlib.sha256(got.tobytes()).hexdigest() == d["sha256"], "%s: not what the reference's loader assigns (first values %s vs %s)" % (
+            name, got.reshape(-1)[:3], d["first"])
+    for n in c["untouched"]:
+        assert np.array_equal(m.engine.get_param(n, shapes[n]), before[n]), "%s must stay untouched (the reference's loader skips it)" % n
+
+
 def test_winograd_f2x2_3x3_identity():
     """The algebra behind csrc/winograd.hip / wino_fused.hip, with the matrices as written there:
     for one 4x4 input patch d and one 3x3 filter g, A^T [(G g G^T) * (B^T d B)] A equals the 2x2 outputs of the
