@@ -265,7 +265,8 @@ def entry_point_leg(cfg, device, n_frames=512, distinct=32, extras=True):
         sample = json.load(open(os.path.join(out_dir, files[0])))["children"]
         json_bytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in files)
         if not extras:
-            return {"img_s": n_frames / stats["loop_s"], "unit": "img/s", "frames": n_frames, "batch_size": B, "T": T,
+            return {"img_s": n_frames / stats["loop_s"], "steady_img_s": stats.get("steady_img_s"), "steady_images": stats.get("steady_images"),
+                    "unit": "img/s", "frames": n_frames, "batch_size": B, "T": T,
                     "img_size": [H, W], "loop_s": stats["loop_s"], "wall_s": wall, "decode_threads": threads,
                     "host_waited_s": {"feed": stats["wait_feed_s"], "device": stats["wait_device_s"], "writer": stats["wait_writer_s"]},
                     "boxes_per_image": len(sample), "precision": stats["precision"]}
@@ -291,6 +292,8 @@ def entry_point_leg(cfg, device, n_frames=512, distinct=32, extras=True):
             list(pool.map(one, range(n_frames)))
         writer_s = time.perf_counter() - t0
         return {"img_s": n_frames / stats["loop_s"], "unit": "img/s", "frames": n_frames, "batch_size": B, "T": T,
+                # the loop's rate after its fill (the first quarter of the batches: first decode, first H2D, the first forward's plan)
+                "steady_img_s": stats.get("steady_img_s"), "steady_images": stats.get("steady_images"),
                 "entry": "inference_epistemic.inference(config) -- TFRecord shards -> PNG decode -> device -> ECP JSON files",
                 "loop_s": stats["loop_s"], "wall_s": wall, "setup_s": wall - stats["loop_s"], "records_generated_in_s": t_gen,
                 "feed_img_s": n / feed_s, "writer_img_s": n_frames / writer_s, "cores": os.cpu_count(), "decode_threads": threads,
@@ -407,7 +410,7 @@ def main():
                          "tail of step i (decode, sort, NMS) overlaps the convolutions of step i+1.  1 = one stream")
     ap.add_argument("--fp32-steps", type=int, default=5, help="timed steps of the fp32_mode leg (0 = skip it)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the 5-step timings of BASELINE configs 2, 3, 5 and the reference's default frame")
-    ap.add_argument("--entry-frames", type=int, default=512,
+    ap.add_argument("--entry-frames", type=int, default=1536,
                     help="frames of the entry_point leg (inference_epistemic.inference over generated TFRecord shards); 0 = skip it")
     ap.add_argument("--quick-parity", action="store_true", help="skip the minute-long float32 oracle image of configs[4] (1024x1024, T=50)")
     ap.add_argument("--no-dropout", action="store_true",
@@ -431,6 +434,17 @@ def main():
         sys.exit("rank %d: LOCAL_RANK=%d but only %d GPUs are visible" % (rank, local, torch.cuda.device_count()))
     pg = dist.is_initialized()         # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
     torch.cuda.set_device(device)
+    # preflight of the N > 1 path, before anything is built: what the BACKEND says the job is (not the environment), and one tiny
+    # all-reduce over the link the all-gather will use -- a rank on the wrong GPU or a group of the wrong size shows up in the line
+    # (`ranks[].nccl_world`, `ranks[].preflight_sum`) instead of as a hang in the timed region
+    nccl_world, backend, preflight = 1, None, None
+    if pg:
+        nccl_world, backend = dist.get_world_size(), dist.get_backend()
+        one = torch.ones(1, device="cuda:%d" % device) if backend == "nccl" else torch.ones(1)
+        dist.all_reduce(one)
+        preflight = float(one.item())
+        if nccl_world != world or preflight != world:
+            sys.exit("rank %d: the process group reports %d ranks (all-reduce of ones: %g), WORLD_SIZE is %d" % (rank, nccl_world, preflight, world))
 
     cfg = dict(CONFIGS[args.config])
     if args.batch:
@@ -560,7 +574,9 @@ def main():
     g_kept, g_count = last[1], last[2]
     cs = [int((g_kept[b].to(torch.int64).clamp(min=0) * torch.arange(1, g_kept.shape[1] + 1, device=g_kept.device)).sum().item() % 1000003)
           for b in range(g_kept.shape[0])]
-    mine = {"rank": rank, "device": "cuda:%d (%s)" % (device, torch.cuda.get_device_name(device)), "first_image": rank * B, "images": B}
+    mine = {"rank": rank, "device": "cuda:%d (%s)" % (device, torch.cuda.get_device_name(device)), "first_image": rank * B, "images": B,
+            "backend": backend, "nccl_world": nccl_world, "preflight_sum": preflight,
+            "host_threads": {"cpu_count": os.cpu_count(), "local_world": int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)}}
     ranks = [None] * world
     if pg:
         dist.all_gather_object(ranks, mine)
@@ -718,6 +734,8 @@ def main():
             try:
                 line["entry_point"] = entry_point_leg(cfg, device, n_frames=args.entry_frames)
                 line["entry_point"]["vs_value"] = line["entry_point"]["img_s"] / line["value"]
+                if line["entry_point"].get("steady_img_s"):
+                    line["entry_point"]["steady_vs_value"] = line["entry_point"]["steady_img_s"] / line["value"]
             except Exception as e:
                 line["entry_point"] = {"img_s": None, "error": repr(e)}
             # the reference's own default workload through the same entry point: full ECP frame, T = 50, batch_size = 1
@@ -725,9 +743,11 @@ def main():
             if args.config == 4 and not args.no_other_configs:
                 try:
                     c6 = dict(CONFIGS[6], nms=0)
-                    ep6 = entry_point_leg(c6, device, n_frames=48, distinct=8, extras=False)
+                    # 256 frames (round 4: 48 frames = 1.3 s, a fifth of it pipeline fill -- too short to mean anything)
+                    ep6 = entry_point_leg(c6, device, n_frames=256, distinct=8, extras=False)
                     dev6 = (line.get("other_configs") or {}).get("reference default frame (inference_epistemic.py:218-221)", {}).get("img_s")
                     ep6["vs_device_only"] = (ep6["img_s"] / dev6) if dev6 else None
+                    ep6["steady_vs_device_only"] = (ep6["steady_img_s"] / dev6) if dev6 and ep6.get("steady_img_s") else None
                     line["entry_point_reference_default"] = ep6
                 except Exception as e:
                     line["entry_point_reference_default"] = {"img_s": None, "error": repr(e)}

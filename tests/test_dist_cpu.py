@@ -170,6 +170,28 @@ def test_inference_epistemic_world2_writes_the_single_process_json(tmp_path):
     assert one["calls"] == [[5, 0, 4], [5, 0, 5], [1, 0, 6]] and one["stats"]["images"] == 11 and one["stats"]["batches"] == 3
 
 
+def test_inference_epistemic_world8_writes_the_single_process_json(tmp_path):
+    """The shape of the driver's round-end 8-GPU run, on CPU (gloo, eight processes, the stand-in engine): 11 images, global batch
+    5 -- blocks of 1+1+1+1+1+0+0+0, then the same, then 1+0+...+0: ranks 5 - 7 never own an image and still take part in every
+    collective, rank 0 creates the directory, every rank writes only its own files; the job must leave byte-identical JSON to the
+    one-process run."""
+    import json
+    _records(tmp_path, 11)
+    rc1, o1 = _run_infer(1, tmp_path, str(tmp_path / "one" / "run"))
+    assert rc1 == [0], o1
+    rc8, o8 = _run_infer(8, tmp_path, str(tmp_path / "eight" / "run"), timeout=600)
+    assert rc8 == [0] * 8, o8
+    a, b = str(tmp_path / "one" / "run_0"), str(tmp_path / "eight" / "run_0")
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == ["f%02d.json" % i for i in range(11)]
+    for f in os.listdir(a):
+        assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+    c = [json.load(open(tmp_path / ("calls_w8_r%d.json" % r))) for r in range(8)]
+    assert [c[r]["options"] for r in range(8)] == [{"device": r} for r in range(8)]
+    assert [c[r]["stats"]["images"] for r in range(8)] == [3, 2, 2, 2, 2, 0, 0, 0]
+    assert c[0]["calls"] == [[1, 0, 4], [1, 0, 5], [1, 0, 6]] and c[4]["calls"] == [[1, 4, 4], [1, 4, 5]] and c[7]["calls"] == []
+    assert all(c[r]["stats"]["batches"] == 3 for r in range(8))
+
+
 @pytest.mark.parametrize("raise_rank,raise_call", [(1, 1), (0, 2), (0, 3)])
 def test_inference_world2_ranks_switch_to_fp32_together(tmp_path, raise_rank, raise_call):
     """BYOLO_ERR_RANGE on ONE rank (the stand-in raises its status words in one forward and returns garbage rows, as the device
