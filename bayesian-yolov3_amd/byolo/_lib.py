@@ -80,6 +80,8 @@ PROTOTYPES = {
     "byolo_flops": (_i32, [_vp, _i32, _i32, _P(ctypes.c_double)]),
     "byolo_crc32c": (ctypes.c_uint32, [_vp, _sz]),
     "byolo_abi_version": (_i32, []),
+    "byolo_set_tshard": (_i32, [_vp, _i32, _i32]),
+    "byolo_finish_tshard": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "byolo_normalize_u8": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "byolo_copy_status": (_i32, [_vp, _vp, _vp]),
     "byolo_png_decode_batch": (_i32, [_P(_vp), _P(_sz), _i32, _i32, _i32, _i32, _vp, _i32, _P(_i32), _P(_i32)]),
@@ -113,7 +115,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PNG_OK, PNG_UNSUPPORTED, PNG_SHAPE, PNG_CORRUPT, FEED_IO, FEED_CRC, FEED_PROTO = 0, 1, 2, 3, 4, 5, 6
 lib = _load()
 

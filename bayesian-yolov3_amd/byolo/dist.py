@@ -60,6 +60,18 @@ def all_gather_flat(recv, send):
     recv.copy_(h_recv)
 
 
+def all_reduce_flat(buf):
+    """dist.all_reduce(buf, SUM) in place for a flat float32 buffer -- the ONE collective per image of the T-sharded path
+    (byolo/inference.py _run_t_sharded); staged through host memory under gloo with device tensors, like all_gather_flat."""
+    import torch.distributed as dist
+    if not host_staged(buf):
+        dist.all_reduce(buf)
+        return
+    h = buf.cpu()
+    dist.all_reduce(h)
+    buf.copy_(h)
+
+
 def agree_on_error(err, src=0):
     """Rank `src` passes an exception (or None); every rank gets it back -- so that all ranks of a job raise together
     instead of the healthy ones blocking in their next collective until the backend's timeout.  No-op without a

@@ -298,7 +298,7 @@ class Engine:
         return int(n.value)
 
     def forward(self, img, T=1, seed=0, dropout_on=True, want_boxes=False, want_nms=True, out=None, slot=0, first_image=0,
-                mask_bits=None):
+                mask_bits=None, t_shard=None):
         """One sess.run of the reference (inference_epistemic.py:76).  Returns a dict of device
         tensors: rows [B,cap,D], kept [B,cap] int32, count [B,2] int32 and (want_boxes) boxes [B,N,D].
         Everything is enqueued on torch's current stream.  Host synchronisation: in the split-f16 precision the call WAITS for
@@ -308,10 +308,36 @@ class Engine:
 
         first_image: position of img[0] in the logical batch (a shard of a data-parallel batch, a sub-batch): the
         dropout masks are those the unsplit batch would draw.  Batches beyond max_images(T) are run by byolo_forward itself as
-        consecutive pieces with exactly that mechanism, so the result does not depend on the cut."""
+        consecutive pieces with exactly that mechanism, so the result does not depend on the cut.
+
+        t_shard = (t0, T_total): this call's T samples are samples t0 .. t0 + T - 1 of the T_total every image has in the whole
+        job (the T axis sharded over ranks, include/byolo.h byolo_set_tshard; ONE image per call).  'boxes' then holds the per-box
+        SUMS over the call's samples, not rows: add the ranks' tensors and call finish_tshard(); no NMS in this call."""
         torch = _torch()
         self._check_img(img)
         B = int(img.shape[0])
+        if t_shard is not None:
+            t0, T_total = int(t_shard[0]), int(t_shard[1])
+            if B != 1 or want_nms or not want_boxes or mask_bits is not None or not (0 <= t0 and t0 + T <= T_total):
+                raise ValueError("a T shard runs ONE image with want_boxes=True, want_nms=False and t0 + T <= T_total")
+            check(self._h, lib.byolo_set_tshard(self._h, t0, T_total))
+        try:
+            return self._forward(img, B, T, seed, dropout_on, want_boxes, want_nms, out, slot, first_image, mask_bits)
+        finally:
+            if t_shard is not None:
+                check(self._h, lib.byolo_set_tshard(self._h, 0, 0))
+
+    def finish_tshard(self, sums, T_total):
+        """The ranks' summed T-shard buffers [B, N, 21 + C] -> rows, in place (byolo_finish_tshard); returns `sums`."""
+        torch = _torch()
+        N, D = self.num_boxes()
+        assert sums.is_cuda and sums.dtype == torch.float32 and sums.is_contiguous() and tuple(sums.shape[1:]) == (N, D)
+        check(self._h, lib.byolo_finish_tshard(self._h, ctypes.c_void_p(sums.data_ptr()), int(sums.shape[0]), int(T_total),
+                                               ctypes.c_void_p(torch.cuda.current_stream(sums.device).cuda_stream)))
+        return sums
+
+    def _forward(self, img, B, T, seed, dropout_on, want_boxes, want_nms, out, slot, first_image, mask_bits):
+        torch = _torch()
         cap_b = self.max_images(T)
         if cap_b < 1:
             raise ValueError("T=%d at %dx%d: one image's stacked activation exceeds the 3 GiB a convolution source may "

@@ -360,12 +360,124 @@ class InferenceLoop:
             if not self._complete(redo):
                 self._redo_out_of_range([redo])
 
+    # ---- the T axis sharded over the ranks: the latency path at the reference's batch_size = 1 -----------------------------
+    def _run_t_sharded(self):
+        """config['shard'] = 'T' (the alternative).  The reference's own default workload is ONE
+        image per step with T = 50 MC samples (inference_epistemic.py:193, :220-221): sharding the batch axis gives rank 0 the image
+        and the other N - 1 GPUs nothing.  Here EVERY rank reads every frame, runs the backbone on it and the heads on ITS share of
+        the T samples (byolo.dist.shard_range(T, rank, world): samples t0 .. t1 - 1, drawing exactly their masks of the image's T),
+        and hands out the per-box sums of what lib_yolo/layers.py:377-395 averages (21 + C floats per box: sum l, the upper triangle
+        of sum l l^T, sum e^logvar, sum sigma(obj), sum H(obj), sum softmax, sum H(cls)); ONE all-reduce per image adds them (RCCL over
+        xGMI; 2.1 MB at 608 x 608, 11 MB at 1024 x 1920 -- it replaces the batch path's all-gather), every rank finishes the rows
+        (byolo_finish_tshard) and runs the NMS, and image i's file is written by rank i % world.  Summation order differs from the
+        one-GPU reduction: rows agree within float32 rounding (the contract's 1e-4), kept indices where scores are not tied.
+        A forward beyond the split-f16 range on ANY rank is seen by all (a flag word rides in the all-reduced buffer): that image is
+        re-run in fp32 everywhere.  Synchronous per image: this is the latency mode, throughput is the batch path's business."""
+        import time
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        from byolo import dist as bdist
+        rank, _, world = bdist.init()
+        self.pg = torch.distributed.is_initialized()
+        self._load_weights()
+        eng = self.model.engine
+        was_async = getattr(eng, '_async', False)
+        eng.set_async(True)
+        self.dev = eng.torch_device
+        self.cuda = str(self.dev).startswith('cuda')
+        N, D = eng.num_boxes()
+        T = self.model.T
+        t0, t1 = bdist.shard_range(T, rank, world)              # this rank's samples (empty when there are more ranks than samples)
+        self.seed = int(self.config.get('seed', 0))
+        self.stats = dict(images=0, batches=0, wait_feed_s=0.0, wait_device_s=0.0, wait_writer_s=0.0, precision_switches=0, fp32_batches=[],
+                          native_json=False, device=getattr(eng, 'device', None), rank=rank, world=world, shard='T', samples=[t0, t1],
+                          latency_ms=[])
+        self._writer_setup()
+        h, w, c = self.img_size
+        buf = torch.zeros(N * D + 2, dtype=torch.float32, device=self.dev)          # [sums | range flag | feed flag]: ONE collective
+        st_words = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        t_start = time.perf_counter()
+        feed = self.dataset.iter_shards_u8(0, 1, errors='yield')                    # every rank reads every record
+        step = n_img = 0
+
+        def one(x, j, precision):
+            """Image j of the batch: this rank's sums (+ flags) -> all-reduce -> rows, kept rows; returns (kept rows on the host or None, flag)."""
+            buf.zero_()
+            ran = eng
+            if t1 > t0 and x is not None:
+                kw = {} if precision is None else {'precision': precision}
+                res = self.model.run(x, seed=self.seed + step, want_boxes=True, want_nms=False, first_image=j, t_shard=(t0, t1), **kw)
+                buf[:N * D].copy_(res['boxes'].reshape(-1))
+                ran = (res or {}).get('engine') or eng
+            if x is None:
+                buf[N * D + 1] = 1.0                                                 # this rank could not read the frame
+            else:
+                ran.copy_status(st_words)
+                buf[N * D] = (st_words[0] != 0).to(torch.float32)
+            if self.pg:
+                bdist.all_reduce_flat(buf)
+            flags = buf[N * D:].cpu().tolist()                                       # the one host wait per image
+            if flags[0] or flags[1]:
+                return None, flags
+            rows = eng.finish_tshard(buf[:N * D].view(1, N, D), T)
+            res = eng.sort_nms(rows, self.model.obj_idx, self.model.cls_start_idx)
+            if n_img % world != rank:
+                return False, flags
+            n = int(res['count'][0, 0])
+            return res['rows'][0, :n].cpu().numpy(), flags
+
+        with ThreadPoolExecutor(max_workers=self.writer_threads, thread_name_prefix='byolo-writer') as self._pool:
+            try:
+                for shard in feed:
+                    step += 1
+                    err = getattr(shard, 'error', None)
+                    n = self.batch_size if err is not None else int(shard.u8.shape[0])
+                    xs = None if err is not None else self.model.engine.normalize_u8(torch.from_numpy(shard.u8).to(self.dev))
+                    for j in range(n):
+                        t_img = time.perf_counter()
+                        x = None if xs is None else xs[j:j + 1]
+                        kept, flags = one(x, j, None)
+                        if flags[1]:
+                            raise err if err is not None else RuntimeError('a rank could not read its records of batch %d: all ranks stop' % step)
+                        if flags[0]:                                                 # some rank left the split-f16 range: THIS image in fp32, everywhere
+                            logging.warning('BYOLO_ERR_RANGE in batch %d, image %d: every rank re-runs it in the fp32 mode', step, j)
+                            eng.clear_status()
+                            if self.cuda:
+                                torch.cuda.synchronize(self.dev)
+                            self.stats['precision_switches'] += 2
+                            self.stats['fp32_batches'].append(step)
+                            kept, flags = one(x, j, 'f32')
+                            if flags[0]:
+                                raise RuntimeError('BYOLO_ERR_RANGE in the fp32 mode: a raw detection output is inf / NaN (batch %d)' % step)
+                        if kept is not False:
+                            self._write_async([kept], [shard.names[j]])
+                            self.stats['images'] += 1
+                        n_img += 1
+                        self.stats['latency_ms'].append(1e3 * (time.perf_counter() - t_img))
+                    shard.release()
+            finally:
+                feed.close()
+                eng.set_async(was_async)
+            self._writer_drain(0)
+        self.stats['batches'] = step
+        self.stats['loop_s'] = time.perf_counter() - t_start
+        self.stats['precision'] = getattr(eng, 'precision', None)
+        lat = sorted(self.stats.pop('latency_ms'))
+        if lat:
+            self.stats['latency_ms_median'] = lat[len(lat) // 2]
+            self.stats['latency_ms_max'] = lat[-1]
+        if self.pg:
+            torch.distributed.barrier()
+        return self.stats
+
     def run(self):
         import collections
         import time
         import torch
         from concurrent.futures import ThreadPoolExecutor
         from byolo import dist as bdist
+        if self.config.get('shard') == 'T':
+            return self._run_t_sharded()
         rank, _, world = bdist.init()
         self.pg = torch.distributed.is_initialized()      # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
         self._load_weights()

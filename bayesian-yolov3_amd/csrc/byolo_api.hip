@@ -71,6 +71,7 @@ struct Layer {
     bool direct = false;
     std::vector<int> wshift;       // split precision, per OUTPUT CHANNEL n: the packed weights hold w[.][n] * 2^wshift[n] (the channel's largest |w'| in [2^13, 2^14)); folded into scale[n]
     std::vector<int> wshift_u;     // split precision, Winograd (wino_split.hip): per output channel, for U = G g G^T
+    bool wino1d = false;           // ... packed for the ONE-DIMENSIONAL form instead (BYOLO_WINO1D, round 5 experiment): U[xi][ky] = G g[ky, :]
     size_t wscale_off = 0, wscalek_off = 0;    // ... and the per-channel scale arrays that go with it (the shift is the layer's)
     float in_scale = 1.f;          // split precision: scale of the layer's input (ACT_SCALE for activations, 1 for the fp32 image of a direct convolution)
     int64_t box_base = 0;
@@ -116,7 +117,7 @@ struct Step {
     bool kx3 = false;              // split precision: 3x3 / stride 1 over one plain source -- shared-tap stages (conv_tile_kx3), weights in (ky, chunk, kx) order
 };
 // per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
-struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; int bm = 0, bn = 0; /* split precision: output tiles / channels per workgroup */ };
+struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; int bm = 0, bn = 0; /* split precision: output tiles / channels per workgroup */ bool oned = false; };
 struct AuxTensor { int H, W, C; bool stacked = false; };      // stacked: one row per SAMPLE pixel (else per image pixel)
 
 struct Plan {
@@ -185,6 +186,7 @@ struct byolo {
     Plan plan;
     void* last_ws = nullptr;
     int64_t first_image = 0;       // position of a call's first image in the logical batch (dropout stream)
+    int tshard_t0 = 0, tshard_T = 0;   // byolo_set_tshard: this call's T samples are samples t0 .. t0 + T - 1 of tshard_T per image (0 = off)
     int profiling = 0;             // 0 off, 1 stage events, 2 + one event per conv launch
     // level 2: one entry per kernel launch of the convolution stack in a forward (a Winograd layer
     // contributes input transform / GEMM / output transform per chunk); event k is recorded before launch k
@@ -221,7 +223,7 @@ static int32_t fail(byolo_t* h, int32_t code, const char* fmt, ...) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" const char* byolo_version(void) { return "byolo 0.5 (gfx950; fp32 MFMA and split-f16 MFMA; abi 5)"; }
+extern "C" const char* byolo_version(void) { return "byolo 0.6 (gfx950; fp32 MFMA and split-f16 MFMA; abi 6)"; }
 extern "C" int32_t byolo_abi_version(void) { return BYOLO_ABI_VERSION; }
 
 extern "C" const char* byolo_last_error(const byolo_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
@@ -687,6 +689,13 @@ static int32_t lower(byolo_t* h) {
 }
 
 static float* dptr(const byolo_t* h, size_t off) { return h->d_blob + off; }
+// Position, in samples, of a call's first sample in the dropout stream of a tensor with T samples per image in this call:
+// first_image * T -- or, with the T samples of an image sharded over ranks (byolo_set_tshard: one image per call), sample t0 of the
+// tshard_T the image has in the whole job.
+static uint64_t sample_base(const byolo_t* h, int T, bool stacked) {
+    if (h->tshard_T > 0 && stacked) return (uint64_t)h->first_image * (uint64_t)h->tshard_T + (uint64_t)h->tshard_t0;
+    return (uint64_t)h->first_image * (uint64_t)T;
+}
 
 static void fold_layer(const byolo_t* h, const Layer& l, std::vector<float>& scale, std::vector<float>& shift) {
     const int N = l.filters;
@@ -919,18 +928,34 @@ static int32_t finalize_impl(byolo_t* h) {
         if (st.wino_ok && h->precision == 1 && wino_split_ok(Cs, N) && st.Npad == N) {
             // Winograd in split arithmetic (wino_split.hip): U[xi][c][n] = (G g G^T)[xi] in double, rounded once; one power of two per
             // output channel over all 16 points; hi/lo pairs in fragment order, K-tile order (point, chunk)
-            std::vector<float> U((size_t)16 * Cs * N);
+            // BYOLO_WINO1D=1 (round 5 experiment): the 128-channel layers as ONE-DIMENSIONAL F(2,3) along W with the
+            // three filter rows direct -- U[xi][ky][c][n] = sum_kx G[xi][kx] g[ky][kx][c][n], K order (ky, c) per point: 12 of the 16
+            // matrices' worth of space; V at scale 2 (wino_split.hip wino1d_input_kernel), which wshift_u absorbs (+ 1)
+            const char* w1e = getenv("BYOLO_WINO1D");
+            const int wino1d_env = w1e ? atoi(w1e) : 0;
+            const bool oned = wino1d_env && Cs == 128 && l.Cin == 128 && (N % 256) == 0;
+            const int NP = oned ? 4 : 16, KC = oned ? 3 * Cs : Cs;                   // points; K rows per point
+            std::vector<float> U((size_t)NP * KC * N);
             float g9[9], u16[16];
             for (int c = 0; c < Cs; ++c)
                 for (int nn = 0; nn < N; ++nn) {
                     for (int tap = 0; tap < 9; ++tap) g9[tap] = w[((size_t)tap * l.Cin + st.c_lo + c) * N + nn];
+                    if (oned) {
+                        static const double G[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int xi = 0; xi < 4; ++xi)
+                                U[((size_t)xi * KC + (size_t)ky * Cs + c) * N + nn] =
+                                    (float)(G[xi][0] * g9[ky * 3 + 0] + G[xi][1] * g9[ky * 3 + 1] + G[xi][2] * g9[ky * 3 + 2]);
+                        continue;
+                    }
                     wino_weight_transform(g9, u16);
                     for (int xi = 0; xi < 16; ++xi) U[((size_t)xi * Cs + c) * N + nn] = u16[xi];
                 }
             Layer& lw = h->layers[st.layer];
+            lw.wino1d = oned;
             lw.wshift_u.assign((size_t)N, 0);
             std::vector<float> wsu((size_t)N), mxu((size_t)N, 0.f);
-            for (size_t r = 0; r < (size_t)16 * Cs; ++r) {
+            for (size_t r = 0; r < (size_t)NP * KC; ++r) {
                 const float* ur = U.data() + r * N;
                 for (int nn = 0; nn < N; ++nn) mxu[nn] = std::max(mxu[nn], std::fabs(ur[nn]));
             }
@@ -940,15 +965,16 @@ static int32_t finalize_impl(byolo_t* h) {
                 if (mx > 0.f) (void)std::frexp(mx, &e);
                 lw.wshift_u[nn] = mx > 0.f ? std::min(126, std::max(-126, 14 - e)) : 0;
                 wsu[nn] = ldexpf(1.f, lw.wshift_u[nn]);
+                if (oned) lw.wshift_u[nn] += 1;                                          // the accumulators also carry V's scale 2
             }
             _Float16* d16 = reinterpret_cast<_Float16*>(blob.data() + st.wino_off);
             const size_t blocks = N / 32;
-            const int cts = Cs / 32;
-            for (int xi = 0; xi < 16; ++xi)
-                for (int c = 0; c < Cs; ++c) {
+            const int cts = KC / 32;
+            for (int xi = 0; xi < NP; ++xi)
+                for (int c = 0; c < KC; ++c) {
                     const int kk = c & 31, step = kk >> 4, half = (kk >> 3) & 1, e = kk & 7;
                     const int kt = xi * cts + (c >> 5);
-                    const float* ur = U.data() + ((size_t)xi * Cs + c) * N;
+                    const float* ur = U.data() + ((size_t)xi * KC + c) * N;
                     for (int nn = 0; nn < N; ++nn) {
                         const float v = ur[nn] * wsu[nn];
                         const _Float16 hi = (_Float16)v;
@@ -1085,6 +1111,7 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
           if (!(s.is_conv() && s.kx3 && s.mode == STEP_NORMAL && l.op == OP_CONV && !l.direct && l.filters == 256 && s.Npad == 256 && l.fused_residual < 0)) continue;
           int M, KT; step_geometry(h, s, B, T, &M, &KT);
           if (b2b < 2 && (int64_t)((M + 127) / 128) < 4 * 256) continue;
+          if (l.wino1d && 2.0 * M * l.filters * 9.0 * l.Cin >= 200e9) continue;   // (BYOLO_WINO1D experiment: the unfused 1-D Winograd launch instead)
           const Step& s2 = h->steps[si + 1];
           const Layer& l2 = h->layers[s2.layer];
           const int out_t = s.out_tensor;
@@ -1182,11 +1209,22 @@ static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
             // measured at config 4 (direct -> transform + fused): Cin 512 2.00 -> 0.19 + 1.36 ms, 256 2.02 -> 0.35 + 1.37,
             // 128 2.15 -> 2 x (0.36 + 0.80) -- the 128-channel layers stay direct (BYOLO_WINO_SPLIT_MIN_C)
             static const int min_c = [] { const char* e = getenv("BYOLO_WINO_SPLIT_MIN_C"); return e ? atoi(e) : 256; }();
-            if (on < 2 && l.Cin < min_c) continue;
+            if (on < 2 && l.Cin < min_c && !l.wino1d) continue;
             WinoPlan& w = p.wino[si];
             w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2; w.bm = bm; w.fused = true;
             w.bn = (bn_pref == 256 && bm == 64 && (l.filters % 256) == 0) ? 256 : 128;
             const int S = M / (l.H * l.W);
+            if (l.wino1d) {                                     // one-dimensional form: V [4][chunk * (H + 2) * tw rows][C]
+                w.oned = true; w.th = l.H; w.bm = 64; w.bn = 256;
+                const double per = 4.0 * (l.H + 2) * w.tw * l.Cin * 4.0;
+                const int nch = std::max(1, (int)std::ceil(S * per / budget));
+                w.chunk = (S + nch - 1) / nch;
+                const size_t R_pad = align_up((size_t)w.chunk * (l.H + 2) * w.tw, 128);
+                w.v_bytes = align_up((size_t)4 * R_pad * l.Cin * 4, 256);
+                if (w.v_bytes > CONV_MAX_SRC_BYTES) { w = WinoPlan{}; continue; }
+                wino_scratch = std::max(wino_scratch, w.v_bytes);
+                continue;
+            }
             const double per_sample = 16.0 * w.th * w.tw * l.Cin * 4.0;
             const int nchunks = std::max(1, (int)std::ceil(S * per_sample / budget));          // equal chunks
             w.chunk = (S + nchunks - 1) / nchunks;
@@ -1432,7 +1470,7 @@ static void fill_finish(const byolo_t* h, const Step& st, char* ws, int B, int T
         f.scale = dptr(h, l.scale_off); f.shift = dptr(h, l.shift_off);
         if (drop) {
             f.flags |= EPI_DROPOUT; f.k0 = keys.k0; f.k1 = keys.k1; f.thr = keys.thr; f.mask_bits = mask_bits;
-            f.idx_base = inject ? 0 : (uint64_t)h->first_image * (uint64_t)f.T * l.H * l.W * l.filters;
+            f.idx_base = inject ? 0 : sample_base(h, f.T, l.stacked) * (uint64_t)l.H * l.W * l.filters;
             f.scale = dptr(h, l.scalek_off);
         }
     }
@@ -1567,6 +1605,37 @@ static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const C
     const int S = c.M / (l.H * l.W), tt = wp.th * wp.tw;
     float* V = reinterpret_cast<float*>(ws + h->plan.wino_off);
     const bool drop = c.flags & EPI_DROPOUT;
+    if (wp.oned) {
+        // ONE-DIMENSIONAL form (BYOLO_WINO1D): V rows = (sample, padded image row, pair); GEMM rows = output pairs
+        for (int s0 = 0; s0 < S; s0 += wp.chunk) {
+            const int ns = std::min(wp.chunk, S - s0);
+            const int Hp = l.H + 2;
+            WinoParams w; memset(&w, 0, sizeof w);
+            w.x = c.src0; w.v = V;
+            w.H = l.H; w.W = l.W; w.C = c.C0; w.N = c.N; w.th = Hp; w.tw = wp.tw;
+            w.s0 = s0; w.P = ns * Hp * wp.tw; w.P_pad = (int)align_up((size_t)w.P, 128);
+            w.d_tt = make_fastdiv((uint32_t)(Hp * wp.tw)); w.d_tw = make_fastdiv((uint32_t)wp.tw);
+            w.d_c4 = make_fastdiv((uint32_t)(c.C0 / 4)); w.d_n4 = make_fastdiv((uint32_t)(c.N / 4));
+            w.vmul = 2.f / ACT_SCALE;
+            if (prof && (rc = mark_launch(h, s.layer, -5, w.P, c.C0, 0, 0.0, st))) return rc;
+            HIPCHK(h, launch_wino1d_input(w, st));
+            WinoSplitParams f; memset(&f, 0, sizeof f);
+            const int P = ns * l.H * wp.tw, P_pad = (int)align_up((size_t)P, 64);
+            f.oned = 1; f.ky_stride = (uint32_t)((size_t)wp.tw * c.C0 * 4);
+            f.v = V; f.xi_stride = (uint32_t)((uint64_t)w.P_pad * c.C0 * 4); f.v_bytes = 4u * f.xi_stride;
+            f.w = dptr(h, s.wino_off); f.w_bytes = (uint32_t)((size_t)12 * c.C0 * c.N * 4);
+            f.y = c.dst; f.scale = dptr(h, drop ? l.wscalek_off : l.wscale_off); f.shift = c.shift;
+            f.C = c.C0; f.N = c.N; f.KT = 3 * c.C0 / 32; f.n_tiles = c.N / 256; f.bn = 256; f.bm = 64;
+            f.H = l.H; f.W = l.W; f.th = l.H; f.tw = wp.tw; f.s0 = s0; f.P = P; f.P_pad = P_pad;
+            f.units = (P_pad / 64) * f.n_tiles;
+            f.flags = c.flags; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base; f.mask_bits = c.mask_bits;
+            f.status = c.status; f.layer_idx = c.layer_idx;
+            f.d_ntiles = make_fastdiv((uint32_t)f.n_tiles); f.d_tt = make_fastdiv((uint32_t)(l.H * wp.tw)); f.d_tw = w.d_tw;
+            if (prof && (rc = mark_launch(h, s.layer, 141, (int64_t)4 * P_pad, c.N, 3 * c.C0, algo_flops * ns / S, st))) return rc;
+            HIPCHK(h, launch_wino_split(f, st));
+        }
+        return BYOLO_OK;
+    }
     for (int s0 = 0; s0 < S; s0 += wp.chunk) {
         const int ns = std::min(wp.chunk, S - s0);
         WinoParams w; memset(&w, 0, sizeof w);
@@ -1595,11 +1664,13 @@ static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const C
     return BYOLO_OK;
 }
 
-static int32_t run_decode(byolo_t* h, char* ws, float* boxes, int B, int T, hipStream_t st) {
+static int32_t run_decode(byolo_t* h, char* ws, float* boxes, int B, int T, hipStream_t st, int mode = 0) {
     for (const auto& l : h->layers) {
         if (l.op != OP_DETECTION) continue;
         DecodeParams d; memset(&d, 0, sizeof d);
-        d.raw = reinterpret_cast<const float*>(ws + h->plan.off[l.out_tensor]);
+        d.mode = mode;
+        if (mode && l.det_kind != BYOLO_DET_EPISTEMIC) return fail(h, BYOLO_ERR_ARG, "T sharding (byolo_set_tshard) is defined for epistemic detection layers");
+        d.raw = mode == 2 ? nullptr : reinterpret_cast<const float*>(ws + h->plan.off[l.out_tensor]);
         d.boxes = boxes; d.lh = l.H; d.lw = l.W; d.C = h->cfg.cls_cnt;
         d.n_total = h->n_boxes; d.box_base = l.box_base; d.layer_id = l.det_id; d.ld = layer_pitch(l);
         d.status = h->precision == 1 ? h->d_status : nullptr;
@@ -1806,7 +1877,7 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
                 }
                 // element index of this call's first output element in the logical batch's [S,h,w,c] tensor (the counter hash);
                 // injected bits are indexed inside THIS call's tensor, whatever byolo_set_first_image says
-                p.idx_base = inject ? 0 : (uint64_t)h->first_image * (uint64_t)(l.stacked ? T : 1) * l.H * l.W * l.filters;
+                p.idx_base = inject ? 0 : sample_base(h, l.stacked ? T : 1, l.stacked) * (uint64_t)l.H * l.W * l.filters;
                 p.scale = dptr(h, l.scalek_off);             // scale / (1 - p)
             }
             if (l.fused_residual >= 0) {
@@ -1908,7 +1979,9 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
     if (!h->ev_convs) HIPCHK(h, hipEventCreateWithFlags(&h->ev_convs, hipEventDisableTiming));
     HIPCHK(h, hipEventRecord(h->ev_convs, st)); h->convs_stream = st; h->ev_convs_valid = true;
     float* boxes = d_boxes ? d_boxes : reinterpret_cast<float*>(ws + h->plan.boxes_off);
-    if (d_boxes || d_rows) { rc = run_decode(h, ws, boxes, B, T, st); if (rc) return rc; }
+    if (h->tshard_T > 0 && (B != 1 || h->tshard_t0 + T > h->tshard_T)) return fail(h, BYOLO_ERR_ARG, "byolo_forward: a T shard (byolo_set_tshard) is ONE image and t0 + T <= T_total");
+    if (h->tshard_T > 0 && d_rows) return fail(h, BYOLO_ERR_ARG, "byolo_forward: a T shard (byolo_set_tshard) hands out per-box SUMS in d_boxes; the NMS runs after byolo_finish_tshard (byolo_sort_nms)");
+    if (d_boxes || d_rows) { rc = run_decode(h, ws, boxes, B, T, st, h->tshard_T > 0 ? 1 : 0); if (rc) return rc; }
     if (h->profiling) HIPCHK(h, hipEventRecord(h->wslot().ev[3], st));
     if (d_rows) {
         NmsParams n; memset(&n, 0, sizeof n);
@@ -2206,6 +2279,23 @@ extern "C" int32_t byolo_select_profile(byolo_t* h, int32_t age) {
     if (age < 0 || age >= (int)h->prof.size()) return fail(h, BYOLO_ERR_ARG, "byolo_select_profile: age outside the profile depth");
     h->prof_age = age;
     return BYOLO_OK;
+}
+
+// T sharded over ranks (the latency alternative at the reference's batch_size = 1, inference_epistemic.py:193,220):
+// every rank runs the backbone on the image and the heads on ITS T_local of the image's T samples -- drawing the masks of samples
+// t0 .. t0 + T_local - 1 --, byolo_forward then writes the 21 + C per-box sums of layers.py:377-395's reductions into d_boxes
+// instead of decoded rows; the caller adds the ranks' sums (ONE all-reduce) and byolo_finish_tshard turns them into rows.
+extern "C" int32_t byolo_set_tshard(byolo_t* h, int32_t t0, int32_t T_total) {
+    if (!h) return BYOLO_ERR_ARG;
+    if (T_total < 0 || t0 < 0 || (T_total > 0 && t0 >= T_total)) return fail(h, BYOLO_ERR_ARG, "byolo_set_tshard: need 0 <= t0 < T_total (T_total = 0 switches it off)");
+    h->tshard_t0 = T_total ? t0 : 0; h->tshard_T = T_total;
+    return BYOLO_OK;
+}
+extern "C" int32_t byolo_finish_tshard(byolo_t* h, float* d_sums, int32_t B, int32_t T_total, void* stream) {
+    if (!h || !d_sums || B < 1 || T_total < 1) return fail(h, BYOLO_ERR_ARG, "byolo_finish_tshard: bad argument");
+    if (!h->finalized) return fail(h, BYOLO_ERR_STATE, "byolo_finish_tshard: finalize first");
+    HIPCHK(h, hipSetDevice(h->device));
+    return run_decode(h, nullptr, d_sums, B, T_total, reinterpret_cast<hipStream_t>(stream), 2);
 }
 
 extern "C" int32_t byolo_set_first_image(byolo_t* h, int64_t first_image) {

@@ -138,6 +138,11 @@ struct WinoSplitParams {
     int C, N, KT, n_tiles;                // KT = C / 32 (a multiple of 4), n_tiles = N / bn
     int H, W, th, tw, s0, P, P_pad;       // as WinoParams
     int bm, bn;                           // output tiles / channels per workgroup: 64 | 128 (P_pad is a multiple of it), 128 | 256
+    // ONE-DIMENSIONAL form (round 5 experiment, BYOLO_WINO1D): F(2,3) along W, the three filter rows direct.  V is
+    // [4][samples * (H + 2) rows (a zero row above and below every sample)][tw pairs][C]; a GEMM row = an output PAIR (s, y, j),
+    // P = samples * H * tw; its operand for filter row ky sits ky_stride bytes (one padded row) further per ky; KT = 3 * C / 32
+    // K-tiles per point in (ky, chunk) order; th = H, tw = ceil(W / 2), d_tt = H * tw, d_tw = tw
+    int oned; uint32_t ky_stride;
     int units;                            // P_pad / bm * n_tiles workgroups
     int flags; uint32_t k0, k1, thr; uint64_t idx_base; const uint32_t* mask_bits;
     unsigned* status; int layer_idx;
@@ -145,6 +150,8 @@ struct WinoSplitParams {
 };
 bool wino_split_ok(int C, int N);
 hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st);
+// 1-D form: WinoParams with th = H + 2 (padded rows per sample), tw = ceil(W / 2), P = samples * th * tw V rows, d_tt = th * tw
+hipError_t launch_wino1d_input(const WinoParams& p, hipStream_t st);
 hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st);
 // Row-streaming persistent GEMM (gemm_stream.hip): the Winograd-domain GEMM (epi 0: 16 row blocks of RT row tiles, one
 // weight matrix each, raw accumulators out), a 1x1 / stride-1 convolution with its fused epilogue (epi 1), or a
@@ -243,6 +250,11 @@ struct DecodeParams {
     int layer_id;
     int ld;                  // floats per cell of `raw` (0 = 3*blk, dense; the detection convolution pads its rows to a multiple of 4)
     unsigned* status;        // numeric status (byolo_status): status[0] |= 2 when a raw value is not finite; null = not tracked
+    // epistemic decode only (T sharded over ranks, byolo_set_tshard): 0 = reduce over the T samples and decode (the normal call);
+    // 1 = write the 21 + C running SUMS of this call's T samples into the row instead ([sum l x4 | sum l l^T upper triangle x10 |
+    // sum e^logvar x4 | sum sigma(obj) | sum H(obj) | sum softmax x C | sum H(cls)]: exactly one row's worth); 2 = `boxes` holds such
+    // sums over all T samples (added up across the ranks): finish them in place -- means, covariance, determinant, entropies, corners
+    int mode;
 };
 hipError_t launch_decode(int kind, const DecodeParams& p, hipStream_t st);
 // decode_epistemic's dict entries outside the box row: ev_loc [B,lh,lw,3,4], covar [B,lh,lw,3,4,4], obj / cls samples

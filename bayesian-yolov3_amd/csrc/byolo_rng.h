@@ -4,16 +4,21 @@
 // irreproducible; the build defines them as a pure function of
 //   (seed, dropout-layer ordinal, NHWC element index i of the dropout input [S,h,w,cout]):
 //
-//   h(g)    = one lowbias32 round over the PAIR index g = i >> 1, keyed at both ends:
+//   h0(g)   = one lowbias32 round over the GROUP index g = i >> 2 (four consecutive channels), keyed at both ends:
 //               x = lo32(g) + k0;  x ^= x >> 16;  x *= 0x21F0AAAD;
 //               x ^= k1 + hi32(g) * 0x9E3779B9;
 //               x ^= x >> 15;  x *= 0x735A2D97;  x ^= x >> 15
-//   keep(i) = 16-bit half (i & 1) of h(i >> 1)  <  thr16,   thr16 = round((1 - p) * 2^16)
+//   h1(g)   = one multiplicative step from h0:   y = h0 * 0x9E3779B1;  y ^= y >> 16
+//   keep(i) = 16-bit field (i & 3) of (h0 | h1 << 32)  <  thr16,   thr16 = min(round((1 - p) * 2^16), 65535)
 //
-// with (k0, k1) = layer_keys(seed, ordinal) computed once per layer on the host.  One hash decides two
-// neighbouring channels: the mask is evaluated inside the convolution epilogue, where a vector-ALU
-// instruction is not hidden under the matrix pipe of the co-resident wave (tools/mfma_peak.hip), and
-// the hash is most of that epilogue.  The keep probability is a multiple of 2^-16 (p = 0.1: 58982/65536
+// with (k0, k1) = layer_keys(seed, ordinal) computed once per layer on the host.  One hash and one derived word decide four
+// neighbouring channels: the mask is evaluated inside the convolution epilogue, where a vector-ALU instruction is not hidden
+// under the matrix pipe of the co-resident wave (tools/mfma_peak.hip, tools/mfma_valu_coexec_probe.hip), and the hash is the
+// largest single item of that epilogue.  Round 5 (ABI 6) redefined the stream: rounds 1 - 4 spent one full hash per PAIR of
+// channels (20 mixing + 8 field instructions per group of four); this form spends 13 + 6 -- the second word comes from the
+// first like the next state of a 32-bit generator, and the 16-bit fields are compared in place (high field: h < thr16 << 16;
+// low field: (h << 16) < thr16 << 16) instead of being extracted.  tests/test_oracle.py checks the rate and the independence of
+// the four fields of a group and of neighbouring groups.  The keep probability is a multiple of 2^-16 (p = 0.1: 58982/65536
 // = 0.899994 against 0.9, relative 7e-6 -- below the fp32 rounding of the sums it scales).
 // oracle/rng.py restates this bit-exactly in numpy.
 #pragma once
@@ -32,7 +37,7 @@ BYOLO_HD uint32_t byolo_mix32(uint32_t x) {          // full lowbias32 (key deri
     return x;
 }
 
-struct byolo_drop_keys { uint32_t k0, k1, thr; };    // thr = thr16 in [0, 65536]
+struct byolo_drop_keys { uint32_t k0, k1, thr; };    // thr = thr16 in [0, 65535]
 
 inline byolo_drop_keys byolo_layer_keys(uint64_t seed, uint32_t layer, double drop_prob) {
     byolo_drop_keys k;
@@ -40,10 +45,11 @@ inline byolo_drop_keys byolo_layer_keys(uint64_t seed, uint32_t layer, double dr
     k.k0 = byolo_mix32(lo ^ (0x9E3779B9u * (layer + 1u)));
     k.k1 = byolo_mix32(hi + k.k0 + layer);
     k.thr = (uint32_t)((1.0 - drop_prob) * 65536.0 + 0.5);
+    if (k.thr > 65535u) k.thr = 65535u;              // thr16 << 16 fits a word (the in-place field compares of epilogue.h)
     return k;
 }
 
-// the 32 mask bits of pair lo32(g); k1h = k1 + hi32(g) * 0x9E3779B9
+// the first 32 mask bits of group lo32(g); k1h = k1 + hi32(g) * 0x9E3779B9
 BYOLO_HD uint32_t byolo_pair_hash(uint32_t g_lo, uint32_t k0, uint32_t k1h) {
     uint32_t x = g_lo + k0;
     x ^= x >> 16; x *= 0x21F0AAADu;
@@ -52,9 +58,16 @@ BYOLO_HD uint32_t byolo_pair_hash(uint32_t g_lo, uint32_t k0, uint32_t k1h) {
     x ^= x >> 15;
     return x;
 }
+// ... and the second 32 from the first
+BYOLO_HD uint32_t byolo_next_word(uint32_t h0) {
+    uint32_t y = h0 * 0x9E3779B1u;
+    y ^= y >> 16;
+    return y;
+}
 
 BYOLO_HD bool byolo_keep(uint64_t idx, uint32_t k0, uint32_t k1, uint32_t thr) {
-    const uint64_t g = idx >> 1;
-    const uint32_t h = byolo_pair_hash((uint32_t)g, k0, k1 + (uint32_t)(g >> 32) * 0x9E3779B9u);
+    const uint64_t g = idx >> 2;
+    uint32_t h = byolo_pair_hash((uint32_t)g, k0, k1 + (uint32_t)(g >> 32) * 0x9E3779B9u);
+    if (idx & 2) h = byolo_next_word(h);
     return ((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) < thr;
 }

@@ -252,7 +252,7 @@ __device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f3
                                 if (INJECT && p.mask_bits) {                            // injected masks: bit i of the layer = element i of this call's tensor
                                     // (idx_base is 0 on such a call, the tensor has < 2^32 elements, cout % 4 == 0: byolo_forward checks;
                                     //  element index % 4 == 0: the group's bits sit in one word)
-                                    const uint32_t el = 2u * drow.gp_lo + (uint32_t)dn;
+                                    const uint32_t el = drow.el_lo() + (uint32_t)dn;
                                     const uint32_t w = p.mask_bits[el >> 5] >> (el & 31u);
 #pragma unroll
                                     for (int q = 0; q < 4; ++q) keep[q] = (w >> q) & 1u;

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void finish_upsampled_kernel(const FinishParam
                 const uint64_t idx = p.idx_base + (uint64_t)m * (uint64_t)p.N + 4u * g;
                 const epi::DropRow drow(idx, p.k1);
                 if (p.mask_bits) {                                      // injected masks (conv_igemm.hip finish_tile)
-                    const uint32_t el = 2u * drow.gp_lo;
+                    const uint32_t el = drow.el_lo();
                     const uint32_t w = p.mask_bits[el >> 5] >> (el & 31u);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) keep[q] = (w >> q) & 1u;

@@ -7,7 +7,7 @@
 // used by every kernel that finishes a convolution: conv_igemm.hip, gemm_stream.hip (1x1 convolutions), wino_fused.hip
 // and winograd.hip (output transform).  Epilogue instructions are paid in matrix-pipe time (mfma_pipe.h), so the forms
 // here are the cheapest measured: mask and scale as ONE select feeding ONE fused multiply-add; leaky as max(x, slope*x)
-// with slope = 1 for linear layers; the dropout mask of the group from two pair hashes (byolo_rng.h) whose key word
+// with slope = 1 for linear layers; the dropout mask of the group from one hash + one derived word (byolo_rng.h) whose key word
 // of the index's high half is prepared once per pixel by the caller.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -19,22 +19,26 @@ namespace epi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Dropout position of one pixel's channel run: pair index of its first element and the key word of the index's high
+// Dropout position of one pixel's channel run: group-of-four index of its first element and the key word of the index's high
 // half.  `idx` = NHWC element index of the run's first channel in the dropout input [S, h, w, cout] (a multiple of 4).
+// (`el_lo()`: the element index's low word, which the injected-mask paths turn into a bit position.)
 struct DropRow {
-    uint32_t gp_lo, k1h;
-    __device__ __forceinline__ DropRow(uint64_t idx, uint32_t k1) : gp_lo((uint32_t)(idx >> 1)), k1h(k1 + (uint32_t)(idx >> 33) * 0x9E3779B9u) {}
+    uint32_t g4_lo, k1h;
+    __device__ __forceinline__ DropRow(uint64_t idx, uint32_t k1) : g4_lo((uint32_t)(idx >> 2)), k1h(k1 + (uint32_t)(idx >> 34) * 0x9E3779B9u) {}
+    __device__ __forceinline__ uint32_t el_lo() const { return g4_lo << 2; }
 };
 
-// keep bits of the 4-channel group `dn` channels further along the row (dn % 4 == 0): two pair hashes, 16 bits each.
-// A group further along the row may sit past a 2^32 pair boundary: the high-half key word then moves on by one step.
+// keep bits of the 4-channel group `dn` channels further along the row (dn % 4 == 0): one hash, one derived word, the four
+// 16-bit fields compared in place (byolo_rng.h).  A group further along the row may sit past a 2^32 group boundary: the
+// high-half key word then moves on by one step.
 __device__ __forceinline__ void keep4(const DropRow& r, int dn, uint32_t k0, uint32_t thr, bool (&keep)[4]) {
-    const uint32_t g_lo = r.gp_lo + (uint32_t)(dn >> 1);             // even: g_lo + 1 never carries
-    const uint32_t k1h = g_lo < r.gp_lo ? r.k1h + 0x9E3779B9u : r.k1h;
+    const uint32_t g_lo = r.g4_lo + (uint32_t)(dn >> 2);
+    const uint32_t k1h = g_lo < r.g4_lo ? r.k1h + 0x9E3779B9u : r.k1h;
     const uint32_t h0 = byolo_pair_hash(g_lo, k0, k1h);
-    const uint32_t h1 = byolo_pair_hash(g_lo + 1u, k0, k1h);
-    keep[0] = (h0 & 0xFFFFu) < thr; keep[1] = (h0 >> 16) < thr;
-    keep[2] = (h1 & 0xFFFFu) < thr; keep[3] = (h1 >> 16) < thr;
+    const uint32_t h1 = byolo_next_word(h0);
+    const uint32_t t = thr << 16;                                      // thr <= 65535 (byolo_layer_keys): block-uniform, scalar
+    keep[0] = (h0 << 16) < t; keep[1] = h0 < t;
+    keep[2] = (h1 << 16) < t; keep[3] = h1 < t;
 }
 
 // leaky(keep * (a * scale) + shift), slope = 0.1 (leaky) or 1 (linear)

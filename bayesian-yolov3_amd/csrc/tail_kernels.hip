@@ -179,7 +179,18 @@ __global__ __launch_bounds__(256) void decode_epi_kernel(const DecodeParams p) {
         float chk = 0.f;                                        // stays 0 unless a raw value is inf / NaN
 #pragma unroll
         for (int c = 0; c < CM; ++c) s_cls[c] = 0.f;
-        for (int t = 0; t < p.T; ++t) {
+        float* o = p.boxes + ((size_t)b * p.n_total + p.box_base + (size_t)pr * cells + cell) * D;
+        if (p.mode == 2) {                                      // the sums of ALL samples, added up across the ranks (byolo_finish_tshard)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s_loc[i] = o[i]; s_var[i] = o[14 + i]; }
+#pragma unroll
+            for (int i = 0; i < 10; ++i) s_ll[i] = o[4 + i];
+            s_obj = o[18]; s_objH = o[19];
+#pragma unroll
+            for (int c = 0; c < CM; ++c) if (EXACT || c < C) s_cls[c] = o[20 + c];
+            s_clsH = o[20 + C];
+        }
+        for (int t = 0; t < (p.mode == 2 ? 0 : p.T); ++t) {
             const float* d = d0 + (size_t)t * sample_stride;
             float v[10 + CM];                                   // the two std logit groups are not decoded
 #pragma unroll
@@ -202,6 +213,17 @@ __global__ __launch_bounds__(256) void decode_epi_kernel(const DecodeParams p) {
             s_clsH += softmax_entropy_<CM, EXACT>(pc, C);
         }
         if (chk != 0.f && p.status) atomicOr(p.status, 2u);
+        if (p.mode == 1) {                                      // this rank's share of the T samples: hand out the sums
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[i] = s_loc[i]; o[14 + i] = s_var[i]; }
+#pragma unroll
+            for (int i = 0; i < 10; ++i) o[4 + i] = s_ll[i];
+            o[18] = s_obj; o[19] = s_objH;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) if (EXACT || c < C) o[20 + c] = s_cls[c];
+            o[20 + C] = s_clsH;
+            continue;
+        }
         float ev[4], cov[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) ev[i] = s_loc[i] * invT;
@@ -235,7 +257,6 @@ __global__ __launch_bounds__(256) void decode_epi_kernel(const DecodeParams p) {
 #pragma unroll
         for (int c = 0; c < CM; ++c) if (EXACT || c < C) out[17 + c] = s_cls[c] * invT;
         const float clsH = softmax_entropy_<CM, EXACT>(out + 17, C);
-        float* o = p.boxes + ((size_t)b * p.n_total + p.box_base + (size_t)pr * cells + cell) * D;
 #pragma unroll
         for (int i = 0; i < 17 + CM; ++i) if (EXACT || i < 17 + C) o[i] = out[i];
         o[17 + C] = clsH - s_clsH * invT;

@@ -101,13 +101,59 @@ hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// ONE-DIMENSIONAL form, F(2,3) along W (round 5 experiment for the 128-channel 76x76 head convolutions):
+// V[xi][(s, yp, j)][c] = (B^T d)[xi] over the four pixels 2j-1 .. 2j+2 of image row yp - 1; rows yp = 0 and yp = H + 1 of every
+// sample are zeros (the filter rows above / below the image), so that the GEMM's operand for filter row ky is the SAME row
+// sequence ky padded rows further on -- no validity logic in its loader.  V is 2x the input (the 2-D form: 4x).
+// thread = (V row, 4 channels): 4 loads, 4 stores.  |V| <= 2 |d|: stored at scale 2 (vmul = 2 / ACT_SCALE), the range the inputs had.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino1d_input_kernel(const WinoParams p) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t c4n = (uint32_t)p.C >> 2;
+    const uint32_t t = fdiv(gid, p.d_c4), c4 = gid - t * c4n;
+    if (t >= (uint32_t)p.P_pad) return;
+    float* v = p.v + (size_t)t * p.C + c4 * 4;
+    const size_t xi_stride = (size_t)p.P_pad * p.C;
+    const uint32_t tt = (uint32_t)(p.th * p.tw);
+    const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
+    const uint32_t yp = fdiv(r, p.d_tw), j = r - yp * (uint32_t)p.tw;
+    const int y = (int)yp - 1;
+    if (t >= (uint32_t)p.P || (unsigned)y >= (unsigned)p.H) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(v + (size_t)k * xi_stride) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const float* row = p.x + (((size_t)(p.s0 + s) * p.H + y) * p.W) * p.C + c4 * 4;
+    const int x0 = 2 * (int)j - 1;
+    f32x4 d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + k;
+        const f32x4 raw = (unsigned)x < (unsigned)p.W ? *reinterpret_cast<const f32x4*>(row + (size_t)x * p.C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        d[k] = epi::split_decode4(raw);
+    }
+    const float m = p.vmul;
+    *reinterpret_cast<f32x4*>(v + 0 * xi_stride) = epi::split_encode4((d[0] - d[2]) * m);
+    *reinterpret_cast<f32x4*>(v + 1 * xi_stride) = epi::split_encode4((d[1] + d[2]) * m);
+    *reinterpret_cast<f32x4*>(v + 2 * xi_stride) = epi::split_encode4((d[2] - d[1]) * m);
+    *reinterpret_cast<f32x4*>(v + 3 * xi_stride) = epi::split_encode4((d[1] - d[3]) * m);
+}
+
+hipError_t launch_wino1d_input(const WinoParams& p, hipStream_t st) {
+    const uint64_t total = (uint64_t)p.P_pad * (p.C >> 2);
+    hipLaunchKernelGGL(wino1d_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // fused GEMM + output transform + epilogue
 // ---------------------------------------------------------------------------------------------------------------------
 // WINO_BM = output tiles per workgroup (rows of the transform-domain GEMM): 64 -> 230 registers, two workgroups per CU;
 // 128 -> 473 registers (the outputs in the accumulator file), one workgroup per CU
 // WINO_BN = output channels per workgroup: 128 (4 waves) or 256 (8 waves side by side: ONE workgroup per CU stages a V row for 256
 // columns -- the column tiles of a row tile re-read V through the fabric, measured 4.7 GB per launch against 0.8 .. 1.4 GB of V)
-template <int WINO_BM, int WINO_BN>
+// ONED: the one-dimensional form (4 points, K = (filter row, chunk), two outputs per GEMM row; WinoSplitParams.oned)
+template <int WINO_BM, int WINO_BN, bool ONED = false>
 __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(const WinoSplitParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using BT = SplitTile<WINO_BM, WINO_BN, 1, WINO_BN / 32>;
@@ -126,7 +172,11 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
     uint32_t a_voff[A_LD];
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        const uint32_t m = rt * (uint32_t)WINO_BM + (uint32_t)bt.a_r + (uint32_t)(BT::NT / 8) * j;
+        uint32_t m = rt * (uint32_t)WINO_BM + (uint32_t)bt.a_r + (uint32_t)(BT::NT / 8) * j;
+        if constexpr (ONED) {                                  // output pair (s, y, jj) -> V row (s, yp = y [+ ky], jj) of the padded extent:
+            const uint32_t sm = fdiv(m, p.d_tt);               // two padded rows per earlier sample; the sample's own first padded row is ky = 0's
+            m += 2u * sm * (uint32_t)p.tw;
+        }
         a_voff[j] = (m * (uint32_t)p.C + (uint32_t)bt.a_q * 4u) * 4u;
     }
     const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.v, p.v_bytes);
@@ -135,6 +185,8 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
     const uint32_t KT = (uint32_t)p.KT;
     const uint32_t w_step = (uint32_t)p.N * BK * 4;                        // one K-tile of all column blocks (N / 32 blocks of 4 KB)
     uint32_t a_soff = 0, a_kt = 0, a_xi_base = 0;                          // the NEXT tile to load
+    uint32_t a_ky = 0, a_ky_off = 0;                                       // ONED: filter row of the next tile and its byte offset
+    const uint32_t CT = (uint32_t)p.C / BK;                                // ONED: chunks per filter row
     uint32_t w_soff = ct * (WINO_BN / 32) * SPLIT_WBLOCK;
     // V streams from HBM (a chunk is far larger than the caches) and a K-tile of this tile is short (12 MFMAs per wave): the
     // activations of tile t + 1 + NSET are fetched while tile t multiplies, into a ring of NSET staging sets (timing ablation
@@ -143,8 +195,13 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
     f32x4 a_reg[NSET][A_LD];
     f16x8 bfr[2][2][1][2];
     auto next_tile = [&]() {
-        a_soff = a_xi_base + a_kt * (BK * 4);
-        if (++a_kt == KT) { a_kt = 0; a_xi_base += p.xi_stride; }          // past point 15: beyond v_bytes -> zeros
+        if constexpr (ONED) {
+            a_soff = a_xi_base + a_ky_off + a_kt * (BK * 4);
+            if (++a_kt == CT) { a_kt = 0; a_ky_off += p.ky_stride; if (++a_ky == 3) { a_ky = 0; a_ky_off = 0; a_xi_base += p.xi_stride; } }
+        } else {
+            a_soff = a_xi_base + a_kt * (BK * 4);
+            if (++a_kt == KT) { a_kt = 0; a_xi_base += p.xi_stride; }      // past point 15: beyond v_bytes -> zeros
+        }
     };
     auto load_a = [&](auto set_tag) {
 #pragma unroll
@@ -152,9 +209,10 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
     };
     auto load_b = [&](auto set_tag) { bt.load_b(bfr[decltype(set_tag)::value], w_rsrc, w_soff); w_soff += w_step; };
 
-    f32x16 Y[4][TM], M[TM][1];
+    constexpr int NOUT = ONED ? 2 : 4, NPT = ONED ? 4 : 16;
+    f32x16 Y[NOUT][TM], M[TM][1];
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+    for (int o = 0; o < NOUT; ++o)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -200,16 +258,16 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
     // over 16 specialised folds (36 of the 64 (point, output) pairs are non-zero) made the register allocator copy the output
     // accumulators at the join and spill.
     auto cA = [](int a, int i) -> float { return a == 0 ? (i < 3 ? 1.f : 0.f) : (i == 0 ? 0.f : (i == 1 ? 1.f : -1.f)); };
-    for (int xi = 0; xi < 16; ++xi) {
+    for (int xi = 0; xi < NPT; ++xi) {
         run_point();
         const int I = xi >> 2, J = xi & 3;
-        if constexpr (WS_ABL & 2) { if (xi != 15) continue; }
+        if constexpr (WS_ABL & 2) { if (xi != NPT - 1) continue; }
         // as packed fp32 fused multiply-adds (v_pk_fma_f32: two accumulators per instruction, IEEE per element): fp32 vector
         // instructions are paid in full in matrix-pipe time on this part (tools/mfma_valu_coexec_probe.hip), the fold is 128 of them per point
         typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const float c = cA(o >> 1, I) * cA(o & 1, J);
+        for (int o = 0; o < NOUT; ++o) {
+            const float c = ONED ? cA(o, xi) : cA(o >> 1, I) * cA(o & 1, J);       // ONED: Y = A^T M along W only
             const f32x2 c2 = {c, c};
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -243,8 +301,8 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
             const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
             const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const uint32_t oy = 2 * ty + (o >> 1), ox = 2 * tx + (o & 1);
+            for (int o = 0; o < NOUT; ++o) {
+                const uint32_t oy = ONED ? ty : 2 * ty + (o >> 1), ox = 2 * tx + (ONED ? o : (o & 1));
                 if (oy >= (uint32_t)p.H || ox >= (uint32_t)p.W) continue;
                 const uint64_t pix = ((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox;
                 const uint64_t idx_row = p.idx_base + pix * (uint64_t)p.N + (uint64_t)nb;
@@ -258,7 +316,7 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
                     for (int q = 0; q < 4; ++q) a4[q] = Y[o][i][4 * g + q];
                     bool keep[4] = {true, true, true, true};
                     if constexpr (MODE == 2) {                              // injected masks (conv_igemm.hip finish_tile)
-                        const uint32_t el = 2u * drow.gp_lo + (uint32_t)dn;
+                        const uint32_t el = drow.el_lo() + (uint32_t)dn;
                         const uint32_t w = p.mask_bits[el >> 5] >> (el & 31u);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) keep[q] = (w >> q) & 1u;
@@ -278,16 +336,17 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
 
 bool wino_split_ok(int C, int N) { return C >= 128 && (C % 128) == 0 && N >= 128 && (N % 128) == 0; }     // K-tiles in groups of 4
 
-template <int WINO_BM, int WINO_BN>
+template <int WINO_BM, int WINO_BN, bool ONED = false>
 static hipError_t launch_wino_split_bm(const WinoSplitParams& p, hipStream_t st) {
     using BT = SplitTile<WINO_BM, WINO_BN, 1, WINO_BN / 32>;
-    auto k = wino_split_kernel<WINO_BM, WINO_BN>;
+    auto k = wino_split_kernel<WINO_BM, WINO_BN, ONED>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), BT::LDS_BYTES, attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)p.units), dim3(WINO_BN * 2), BT::LDS_BYTES, st, p);
     return hipGetLastError();
 }
 hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st) {
+    if (p.oned) return (p.bn == 256 && p.bm == 64) ? launch_wino_split_bm<64, 256, true>(p, st) : hipErrorInvalidValue;
     if (p.bn == 256) return p.bm == 64 ? launch_wino_split_bm<64, 256>(p, st) : hipErrorInvalidValue;
     return p.bm == 64 ? launch_wino_split_bm<64, 128>(p, st) : launch_wino_split_bm<128, 128>(p, st);
 }

@@ -260,7 +260,7 @@ class Model:
         return self
 
     def run(self, img, seed=0, dropout_on=True, want_boxes=True, want_nms=True, first_image=0, out=None, mask_bits=None, slot=0,
-            precision=None):
+            precision=None, t_shard=None):
         """img: float32 CUDA tensor [B,H,W,C] in [0,1).  Returns the dict of Engine.forward and keeps
         it as `self.last`, which the DetLayer accessors read.  `first_image`: position of img[0] in the logical
         (multi-GPU / split) batch; `out`: preallocated rows / kept / count tensors; `mask_bits`: injected dropout
@@ -277,11 +277,15 @@ class Model:
         ByoloError.  The multi-GPU driver (byolo/inference.py) runs the engine asynchronously -- the wrapper then never
         decides by itself -- lets all ranks agree through the status words its all-gather carries and asks for the re-run
         with `precision='f32'`.
-        `slot`: workspace arena of the call (forwards in flight on different HIP streams must not share one)."""
+        `slot`: workspace arena of the call (forwards in flight on different HIP streams must not share one).
+        `t_shard` = (t0, t1): run samples t0 .. t1 - 1 of the image's T only and return their per-box SUMS in 'boxes' (the T axis
+        sharded over ranks, Engine.forward / include/byolo.h byolo_set_tshard; one image, no NMS)."""
         if not self.engine.finalized:
             self.engine.finalize()
         kw = dict(T=self.T, seed=seed, dropout_on=dropout_on, want_boxes=want_boxes, want_nms=want_nms,
                   first_image=first_image, out=out, mask_bits=mask_bits, slot=slot)
+        if t_shard is not None:
+            kw.update(T=int(t_shard[1]) - int(t_shard[0]), t_shard=(int(t_shard[0]), self.T))
         if precision is not None and precision != self.engine.precision:
             eng = self.engine.twin(precision)
             if getattr(self.engine, '_async', False):

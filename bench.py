@@ -520,6 +520,7 @@ def main():
         eng.set_profile_depth(n_prof * n_sub)       # every profiled step's launch records stay readable until after the run
     eng.set_profiling(2 if prof else 0)
     acc = {}                      # variant -> [algorithmic flops, ms, launches, executed flops, useful flops, algorithmic read bytes, algorithmic write bytes]
+    acc_cn = {}                   # variant -> [sum C*N, sum C, sum N] over its launches (the convolution's own byte count)
     per_launch = {}
     stage = {"backbone": 0.0, "heads": 0.0, "decode": 0.0, "sort_nms": 0.0}
     if pg:
@@ -542,7 +543,7 @@ def main():
 
     if prof and rank == 0:
         # the timed region is over: read the K steps' records (age K-1 = the first timed step)
-        WINO = (129, 130, 140)
+        WINO = (129, 130, 140, 141)
         for age in range(n_prof * n_sub - 1, -1, -1):
             eng.select_profile(age)
             for j, s in enumerate(eng.step_profile()):
@@ -552,14 +553,17 @@ def main():
                     n2 = (s["flops"] - 2.0 * s["M"] * s["N"] * s["K"]) / (2.0 * s["M"] * s["N"])      # the follower's output channels
                     s = dict(s, flops_executed=s["flops"])
                 a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1; a[3] += s["flops_executed"]
-                a[4] += s["flops"] / 2.25 if wino else s["flops"]
+                cn = acc_cn.setdefault(s["variant"], [0.0, 0.0, 0.0])
+                cn[0] += float(s["K"]) * s["N"]; cn[1] += s["K"]; cn[2] += s["N"]
+                a[4] += s["flops"] / (1.5 if s["variant"] == 141 else 2.25) if wino else s["flops"]
                 # algorithmic bytes of the launch: A operand once + result once + weights once
                 # (a shared-tap 3x3 launch reads its input once: M * K / 9 elements, not the im2col matrix)
                 # (input once + weights once | result once)
-                a[5] += 4.0 * ((s["M"] * s["K"] + 16 * s["K"] * s["N"]) if s["variant"] in (130, 140) else
+                a[5] += 4.0 * ((s["M"] * s["K"] // 3 + 4 * s["K"] * s["N"]) if s["variant"] == 141 else       # 1-D: V [4][rows][C] once + U [4][3C][N]
+                               (s["M"] * s["K"] + 16 * s["K"] * s["N"]) if s["variant"] in (130, 140) else
                                (s["M"] * s["K"] // 9 + s["K"] * s["N"]) if s["variant"] in (4256, 3256, 3128, 3064) else
                                (s["M"] * s["K"] + (16 if wino else 1) * s["K"] * s["N"]))
-                a[6] += 4.0 * ((s["M"] // 4) * s["N"] if s["variant"] in (130, 140) else s["M"] * (n2 if s["variant"] == 4256 else s["N"]))
+                a[6] += 4.0 * ((s["M"] // 2) * s["N"] if s["variant"] == 141 else (s["M"] // 4) * s["N"] if s["variant"] in (130, 140) else s["M"] * (n2 if s["variant"] == 4256 else s["N"]))
                 if s["variant"] == 4256:
                     a[5] += 4.0 * s["N"] * n2                # + the follower's weights
                 if args.dump_steps:
@@ -611,7 +615,7 @@ def main():
                                           "arithmetic in this run") if eng.precision == "split" else
                                          "fp32 operands on v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) on the large 3x3 layers"},
         }
-        SPLIT = (4256, 3256, 3128, 3064, 2128, 2064, 1128, 1064, 1032, 140)
+        SPLIT = (4256, 3256, 3128, 3064, 2128, 2064, 1128, 1064, 1032, 140, 141)
         KERNELS = {4256: "conv_igemm_kernel<128,256,1,8,kx3>+fused_tail (split-f16 3x3/stride-1 on shared-tap stages with the following 1x1 convolution / detection head fused in; BYOLO_B2B)",
                    3256: "conv_igemm_kernel<128,256,1,8,kx3> (split-f16 3x3/stride-1 on shared-tap stages, 8 waves; BYOLO_KX3_WIDE)",
                    3128: "conv_igemm_kernel<128,128,1,4,kx3> (split-f16 3x3/stride-1 on shared-tap stages, v_mfma_f32_32x32x16_f16 x3)",
@@ -621,6 +625,7 @@ def main():
                    1128: "conv_igemm_kernel<128,128,1,4,split> (split-f16 1x1 / stride-2 / two-source convolutions)",
                    1064: "conv_igemm_kernel<128,64,2,2,split>", 1032: "conv_igemm_kernel<128,32,4,1,split>",
                    140: "wino_split_kernel (Winograd F(2x2,3x3) in split-f16: transform-domain GEMM + output transform + epilogue, v_mfma_f32_32x32x16_f16 x3)",
+                   141: "wino_split_kernel<64,256,ONED> (1-D Winograd F(2,3) along W in split-f16, three filter rows direct; BYOLO_WINO1D experiment)",
                    130: "wino_fused_kernel (Winograd-domain GEMM + output transform + epilogue, fp32 v_mfma_f32_32x32x2_f32)",
                    129: "gemm_stream_kernel<128,0> (Winograd-domain GEMM, fp32 v_mfma_f32_32x32x2_f32)",
                    131: "gemm_stream_kernel<128,1> (row-streaming 1x1 convolution)",
@@ -642,7 +647,7 @@ def main():
             split = dom in SPLIT
             # peak of the matrix instruction actually issued, useful FLOPs counted once
             peak = PEAK_F16_MFMA if split else PEAK_FP32_MFMA
-            wino_ms = sum(acc[v][1] for v in (-2, -3, -4) if v in acc)
+            wino_ms = sum(acc[v][1] for v in (-2, -3, -4, -5) if v in acc)
             # fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same command
             # (tools/profile_round.sh + tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent / another kernel
             traffic = tr_read = tr_write = measured_at = None
@@ -657,12 +662,27 @@ def main():
                     tr_read, tr_write = tj.get("read_bytes_per_launch"), tj.get("write_bytes_per_launch")
                     measured_at = tj.get("measured_at")
             ab_r, ab_w = abr / n, abw / n
+            # the CONVOLUTION's own bytes per launch: input once + weights once + output once (for a Winograd
+            # launch `algorithmic_bytes_per_launch` counts the 4x-expanded transform-domain V and U as its operands -- what THIS
+            # kernel must read -- which flatters the layer: V is a by-product of the method, written and re-read on top of the input)
+            conv_bytes = None
+            if dom in (130, 140):
+                px = f / n / (18.0 * acc_cn[dom][0] / n)              # pixels = direct FLOPs / (2 * 9 * C * N), averaged over the launches
+                conv_bytes = 4.0 * (px * acc_cn[dom][1] / n + 9.0 * acc_cn[dom][0] / n + px * acc_cn[dom][2] / n)
+            tr_in = None                                              # the separate input-transform launch's measured traffic, if profiled
+            ipath = os.path.join(REPO, "profiles", "traffic_cfg%d_wino_input.json" % args.config)
+            if dom == 140 and os.path.exists(ipath) and traffic:
+                tr_in = json.load(open(ipath)).get("traffic_bytes_per_launch")
             line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                                 "frac": ach / peak,
                                 "traffic": traffic, "traffic_read": tr_read, "traffic_write": tr_write, "traffic_measured_at": measured_at,
                                 "algorithmic_bytes_per_launch": ab_r + ab_w,
                                 "algorithmic_read_bytes_per_launch": ab_r, "algorithmic_write_bytes_per_launch": ab_w,
                                 "traffic_vs_algorithmic": (traffic / (ab_r + ab_w)) if traffic else None,
+                                "convolution_bytes_per_launch": conv_bytes,
+                                "traffic_vs_convolution_bytes": (traffic / conv_bytes) if traffic and conv_bytes else None,
+                                "input_transform_traffic_per_launch": tr_in,
+                                "traffic_with_input_transform_vs_convolution_bytes": ((traffic + tr_in) / conv_bytes) if traffic and tr_in and conv_bytes else None,
                                 "read_amplification": (tr_read / ab_r) if tr_read else None,
                                 "write_amplification": (tr_write / ab_w) if tr_write else None,
                                 "kernel": KERNELS[dom],
@@ -682,7 +702,7 @@ def main():
                                                                           "algorithmic_tflops": acc[v][0] / (acc[v][1] * 1e-3) / 1e12,
                                                                           "executed_tflops": acc[v][3] / (acc[v][1] * 1e-3) / 1e12}
                                               for v in sorted(mm, key=lambda v: -acc[v][1])},
-                                "transform_kernels_ms": {str(v): acc[v][1] for v in (-2, -3, -4) if v in acc},
+                                "transform_kernels_ms": {str(v): acc[v][1] for v in (-2, -3, -4, -5) if v in acc},
                                 # 8(d)'s formula for the whole step: img/s * F(H,W,T) / (n_gpu * peak); and against the fp32 MFMA peak the
                                 # reference's own arithmetic would be priced at (> 1 = beyond that instruction's ceiling)
                                 "end_to_end_frac": (imgs / dt) * flops_img / (world * peak),

@@ -84,8 +84,10 @@ BYOLO_API const char* byolo_version(void);
 /* Incremented on every incompatible change of a signature or of a buffer layout this header describes, so that a binding can
  * refuse a library it was not written for (byolo/_lib.py does).  4: byolo_forward takes d_mask_bits; detection rows handed out
  * by byolo_layer_output are padded to a multiple of 4 floats; the host-side feed / writer entry points exist.  5: byolo_encode_gt,
- * byolo_loss (ground-truth encoding and training loss) exist. */
-#define BYOLO_ABI_VERSION 5
+ * byolo_loss (ground-truth encoding and training loss) exist.  6: the dropout stream byolo_forward draws from `seed` is redefined
+ * (one hash + one derived word per group of four channels, csrc/byolo_rng.h): the same seed gives other masks than ABI 5 did; the
+ * bit order of injected masks (d_mask_bits) is unchanged. */
+#define BYOLO_ABI_VERSION 6
 BYOLO_API int32_t byolo_abi_version(void);
 
 /* ---- graph construction: one call per ModelBuilder.make_* (lib_yolo/model.py:52-185).
@@ -190,6 +192,22 @@ BYOLO_API int32_t byolo_clear_status(byolo_t* h, void* stream);
  * every call where its first image sits in the logical batch: image j of the call then draws the masks of image
  * first_image + j, and the pieces equal the unsplit run.  Sticky per handle; 0 after byolo_create. */
 BYOLO_API int32_t byolo_set_first_image(byolo_t* h, int64_t first_image);
+/* T sharded over ranks -- the latency path for the reference's own default, ONE image per step (inference_epistemic.py:193
+ * asserts batch_size == 1, :220 T = 50), where sharding the batch axis leaves N - 1 GPUs idle (the alternative):
+ * every rank runs the backbone on the image and the heads on T_local = its share of the T_total MC samples.
+ *   byolo_set_tshard(h, t0, T_total)   sticky; T_total = 0 switches it off.  A following byolo_forward(h, img, B = 1, T = T_local,
+ *       ...) draws the dropout masks of samples t0 .. t0 + T_local - 1 of the image's T_total (the N ranks together draw what one
+ *       call with T = T_total draws) and writes into d_boxes [B, N, 21 + C], instead of decoded rows, the per-box SUMS over its
+ *       samples of the quantities lib_yolo/layers.py:377-395 reduces with reduce_mean: [sum l (4) | sum l l^T, upper triangle (10) |
+ *       sum exp(logvar) (4) | sum sigmoid(obj) | sum H(sigmoid(obj)) | sum softmax(cls) (C) | sum H(softmax(cls))].  d_rows must be
+ *       null (no NMS on sums).  Epistemic detection layers only.
+ *   the caller adds the ranks' buffers element-wise (one all-reduce of N * (21 + C) floats: 2.1 MB at 608 x 608);
+ *   byolo_finish_tshard(h, d_sums, B, T_total, stream)   turns the summed buffer IN PLACE into the rows a T_total-sample
+ *       byolo_forward writes (means, population covariance, 4x4 determinant, entropies / mutual information, decoded corners);
+ *       byolo_sort_nms then runs the tail.  The sums are added in another order than the one-call reduction: rows agree within
+ *       float32 rounding (tested at the contract's bound 1e-4 * max(1, |ref|)), not bit for bit. */
+BYOLO_API int32_t byolo_set_tshard(byolo_t* h, int32_t t0, int32_t T_total);
+BYOLO_API int32_t byolo_finish_tshard(byolo_t* h, float* d_sums, int32_t B, int32_t T_total, void* stream);
 /* Images ONE launch sequence carries at this T: the convolutions address their sources with 32-bit byte offsets, so every
  * activation tensor [B*T or B, h, w, c] of a piece stays below 3 GiB (18 images at 608x608, T=30).  byolo_forward cuts larger
  * batches into such pieces itself; the number matters to a caller that injects masks or reads byolo_layer_output. */

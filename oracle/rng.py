@@ -11,14 +11,17 @@ bit-exactly here (numpy, uint32 wrap-around arithmetic) and on the device
                   (S = images*T, sample s = img*T + t), as uint64
   dropout_layer_ordinal = 0..14, order of the dropout calls in one forward
                   (`lib_yolo/yolov3.py:544-548`, `:575-579`, `:606-610`)
-  h(g)     one lowbias32 round over the pair index g = i >> 1, keyed at both ends (pair_hash)
-  keep(i)  <=>  16-bit half (i & 1) of h(i >> 1)  <  round((1 - drop_prob) * 2^16)
+  h0(g)    one lowbias32 round over the GROUP index g = i >> 2, keyed at both ends (pair_hash)
+  h1(g)    next_word(h0): y = h0 * 0x9E3779B1; y ^= y >> 16
+  keep(i)  <=>  16-bit field (i & 3) of (h0, h1)  <  min(round((1 - drop_prob) * 2^16), 65535)
+(round 5 / ABI 6; rounds 1 - 4 hashed every pair of channels: csrc/byolo_rng.h says why this is cheaper on the device)
 """
 import numpy as np
 
 _M1 = np.uint32(0x21F0AAAD)
 _M2 = np.uint32(0x735A2D97)
 _GOLD = np.uint32(0x9E3779B9)
+_M3 = np.uint32(0x9E3779B1)
 
 
 def mix32(x):
@@ -48,11 +51,19 @@ def layer_keys(seed, layer):
 def keep_threshold(drop_prob):
     # drop_prob travels through the C-ABI as float32 (byolo_cfg.drop_prob); the 16-bit threshold is
     # computed from that float32 value in double precision (csrc/byolo_rng.h: byolo_layer_keys)
-    return np.uint32(int((1.0 - float(np.float32(drop_prob))) * 65536.0 + 0.5))
+    return np.uint32(min(65535, int((1.0 - float(np.float32(drop_prob))) * 65536.0 + 0.5)))
+
+
+def next_word(h0):
+    """The second 32 mask bits of a group from its first."""
+    with np.errstate(over="ignore"):
+        y = np.asarray(h0, dtype=np.uint32) * _M3
+        y ^= y >> np.uint32(16)
+    return y
 
 
 def pair_hash(g, k0, k1):
-    """32 mask bits of every pair index in the uint64 array g."""
+    """The first 32 mask bits of every group index in the uint64 array g."""
     g = np.asarray(g, dtype=np.uint64)
     lo = (g & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     hi = (g >> np.uint64(32)).astype(np.uint32)
@@ -72,7 +83,8 @@ def keep_mask(seed, layer, shape, drop_prob=0.1, offset=0):
     n = int(np.prod(shape))
     idx = np.arange(offset, offset + n, dtype=np.uint64)
     k0, k1 = layer_keys(seed, layer)
-    h = pair_hash(idx >> np.uint64(1), k0, k1)
+    h = pair_hash(idx >> np.uint64(2), k0, k1)
+    h = np.where((idx & np.uint64(2)).astype(bool), next_word(h), h)
     u = np.where((idx & np.uint64(1)).astype(bool), h >> np.uint32(16), h & np.uint32(0xFFFF))
     return (u < keep_threshold(drop_prob)).reshape(shape)
 
@@ -89,7 +101,7 @@ def keep_mask_torch(seed, layer, shape, drop_prob=0.1, offset=0, chunk=1 << 24):
     for lo_i in range(0, n, chunk):
         hi_i = min(n, lo_i + chunk)
         idx = torch.arange(offset + lo_i, offset + hi_i, dtype=torch.int64)
-        g = idx >> 1
+        g = idx >> 2
         x = ((g & M) + k0) & M
         x = x ^ (x >> 16)
         x = (x * 0x21F0AAAD) & M
@@ -97,6 +109,9 @@ def keep_mask_torch(seed, layer, shape, drop_prob=0.1, offset=0, chunk=1 << 24):
         x = x ^ (x >> 15)
         x = (x * 0x735A2D97) & M
         x = x ^ (x >> 15)
+        y = (x * 0x9E3779B1) & M
+        y = y ^ (y >> 16)
+        x = torch.where((idx & 2).bool(), y, x)
         u = torch.where((idx & 1).bool(), x >> 16, x & 0xFFFF)
         out[lo_i:hi_i] = u < thr
     return out.reshape(shape)

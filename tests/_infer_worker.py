@@ -39,8 +39,24 @@ class FakeEngine:
 
     def normalize_u8(self, u8, out=None):           # byolo_normalize_u8
         import torch
-        out.copy_(u8.to(torch.float32) * torch.tensor(1.0 / 255.0, dtype=torch.float32))
+        y = u8.to(torch.float32) * torch.tensor(1.0 / 255.0, dtype=torch.float32)
+        if out is None:
+            return y
+        out.copy_(y)
         return out
+
+    # ---- the T-sharded path (byolo/inference.py _run_t_sharded): sums of small integers are exact in float32, so any cut of the
+    # samples over any number of ranks adds up to the same bits -- a wrong shard, a missing rank or a double count changes them
+    def finish_tshard(self, sums, T_total):
+        sums /= float(T_total)
+        return sums
+
+    def sort_nms(self, rows, obj_idx, cls_start_idx, **kw):
+        import torch
+        k = 1 + int(rows[0, 0, 0].item() * 3) % self.out_cap
+        out = torch.zeros((1, self.out_cap, rows.shape[2]))
+        out[0, :k] = rows[0, :k]
+        return {"rows": out, "kept": torch.arange(self.out_cap, dtype=torch.int32)[None], "count": torch.tensor([[k, k]], dtype=torch.int32)}
 
     def copy_status(self, out):                     # byolo_copy_status: sticky until cleared
         out[0] = self.flags
@@ -64,10 +80,27 @@ class FakeModel:
     def finalize(self):
         self.engine.finalize()
 
-    def run(self, x, seed=0, want_boxes=True, first_image=0, out=None, precision=None, **kw):
+    T = 3
+
+    def run(self, x, seed=0, want_boxes=True, first_image=0, out=None, precision=None, t_shard=None, **kw):
         import torch
         eng = self.engine
         eng.forwards += 1
+        if t_shard is not None:                      # per-box SUMS over samples t0 .. t1 - 1 of image `first_image` of the batch
+            t0, t1 = t_shard
+            self.calls.append((int(x.shape[0]), int(first_image), int(seed), int(t0), int(t1)))
+            if precision is not None:
+                eng.log.append("run:%s:%d" % (precision, seed))
+            if precision is None and eng.precision == "split" and eng.raise_in == eng.forwards:
+                eng.flags = 1
+                return {"boxes": torch.full((1, 50, 23), float("nan")), "engine": eng}
+            base = int(x.sum().item() * 7) % 13
+            b = torch.arange(50, dtype=torch.float32)[:, None]
+            d = torch.arange(23, dtype=torch.float32)[None, :]
+            sums = torch.zeros((1, 50, 23))
+            for t in range(t0, t1):
+                sums[0] += ((b * 5 + d + base + 3 * t + first_image + seed) % 17) + 1.0
+            return {"boxes": sums, "engine": eng}
         self.calls.append((int(x.shape[0]), int(first_image), int(seed)))
         if precision is not None:                    # Model.run(precision='f32'): THIS batch on the fp32 twin handle
             eng.log.append("run:%s:%d" % (precision, seed))
@@ -103,7 +136,7 @@ class FakeYolo:
         return self.model
 
 
-def main(rank, world, port, data_dir, out_path, raise_rank=-1, raise_call=0):
+def main(rank, world, port, data_dir, out_path, raise_rank=-1, raise_call=0, shard_t=0):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.join(os.path.dirname(here), "bayesian-yolov3_amd"))
@@ -111,6 +144,8 @@ def main(rank, world, port, data_dir, out_path, raise_rank=-1, raise_call=0):
     import inference_epistemic as ie
     cfg = {"batch_size": 5, "full_img_size": [32, 32, 3], "crop": False, "cls_cnt": 2, "implicit_background_class": True,
            "weights": "synthetic", "seed": 3, "inference_mode": True, "T": 3, "out_path": out_path, "data": {"file_pattern": os.path.join(data_dir, "val-*")}}
+    if shard_t:
+        cfg["shard"] = "T"
     yolo = FakeYolo()
     if rank == raise_rank:
         yolo.model.engine.raise_in = raise_call
@@ -129,4 +164,4 @@ def main(rank, world, port, data_dir, out_path, raise_rank=-1, raise_call=0):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], *[int(a) for a in sys.argv[6:8]])
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], *[int(a) for a in sys.argv[6:9]])

@@ -223,6 +223,51 @@ def test_inference_world2_ranks_switch_to_fp32_together(tmp_path, raise_rank, ra
     assert redo[1] == [3 + b_ for b_ in range(bad, min(bad + 2, 3))]
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_t_sharded_loop_adds_up_over_the_ranks(tmp_path, world):
+    """config['shard'] = 'T' on CPU (gloo, the stand-in engine whose per-sample contributions are small integers: their float32 sums
+    are exact whatever the cut): every rank reads EVERY frame and runs ITS samples of the T = 3 -- [0,2) + [2,3) at world 2; one sample
+    each on ranks 0 - 2 and NOTHING on ranks 3 - 7 at world 8, which still take part in every all-reduce and write their share of
+    the files --, one all-reduce per image, image i written by rank i % world: byte-identical JSON to the one-process run."""
+    import json
+    _records(tmp_path, 7)
+    rc1, o1 = _run_infer(1, tmp_path, str(tmp_path / "one" / "run"), extra=(-1, 0, 1))
+    assert rc1 == [0], o1
+    rcw, ow = _run_infer(world, tmp_path, str(tmp_path / "many" / "run"), extra=(-1, 0, 1), timeout=600)
+    assert rcw == [0] * world, ow
+    a, b = str(tmp_path / "one" / "run_0"), str(tmp_path / "many" / "run_0")
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == ["f%02d.json" % i for i in range(7)]
+    for f in os.listdir(a):
+        assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+    c = [json.load(open(tmp_path / ("calls_w%d_r%d.json" % (world, r)))) for r in range(world)]
+    from byolo import dist as bdist
+    for r in range(world):
+        t0, t1 = bdist.shard_range(3, r, world)
+        assert c[r]["stats"]["samples"] == [t0, t1] and c[r]["stats"]["shard"] == "T"
+        # every frame, ONE image per call, its position in the batch as first_image, the rank's samples (none: no call at all)
+        want = [[1, j, 3 + step, t0, t1] for step, n in ((1, 5), (2, 2)) for j in range(n)] if t1 > t0 else []
+        assert c[r]["calls"] == want, (r, c[r]["calls"])
+        assert c[r]["stats"]["images"] == len([i for i in range(7) if i % world == r])
+
+
+def test_t_sharded_loop_reruns_an_image_in_fp32_on_every_rank(tmp_path):
+    """... and BYOLO_ERR_RANGE on one rank's shard of one image: the flag rides in the all-reduced buffer, BOTH ranks re-run THAT image
+    in fp32 (Model.run(precision='f32')), the files equal the undisturbed run's."""
+    import json
+    _records(tmp_path, 7)
+    rc1, o1 = _run_infer(1, tmp_path, str(tmp_path / "one" / "run"), extra=(-1, 0, 1))
+    rc2, o2 = _run_infer(2, tmp_path, str(tmp_path / "two" / "run"), extra=(1, 3, 1))          # rank 1's third forward = image 2 of batch 1
+    assert rc1 == [0] and rc2 == [0, 0], (o1, o2)
+    a, b = str(tmp_path / "one" / "run_0"), str(tmp_path / "two" / "run_0")
+    for f in os.listdir(a):
+        assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+    c = [json.load(open(tmp_path / ("calls_w2_r%d.json" % r))) for r in range(2)]
+    for r in range(2):
+        assert c[r]["stats"]["precision_switches"] == 2 and c[r]["stats"]["fp32_batches"] == [1] and c[r]["precision"] == "split"
+        assert [l for l in c[r]["log"] if l.startswith("run:")] == ["run:f32:4"]
+        assert c[r]["calls"].count([1, 2, 4, 0, 2] if r == 0 else [1, 2, 4, 2, 3]) == 2
+
+
 def test_inference_world2_feed_failure_on_one_rank_stops_both(tmp_path):
     """every rank reads, CRC-checks and decodes only ITS block of a global batch, so a corrupt record raises on one rank
     only -- while the other is already queued in that batch's all-gather.  The failing rank takes part in the collective with a

@@ -233,6 +233,60 @@ def test_two_ranks_with_real_engines_write_the_single_process_json(tmp_path):
 
 
 @pytest.mark.gpu
+def test_t_sharded_entry_point_one_process_and_two_ranks(tmp_path):
+    """config['shard'] = 'T' (the latency path at the reference's batch_size = 1, SURVEY 8(e) alternative): `inference_epistemic.
+    inference` on 3 frames, T = 5.
+      * one process: the single shard runs all five samples -- the per-box sums are the one-call reduction's own, so the JSON files
+        are BYTE-identical to the batch path's;
+      * two ranks with REAL engines on one device (gloo staging, as test_two_ranks_with_real_engines...): samples 0-2 on rank 0, 3-4 on
+        rank 1, one all-reduce per image, file i written by rank i % 2 -- every box within the contract's 1e-4 of the one-process
+        file's (the float32 sums are added in another order), same boxes kept where scores are not tied."""
+    import socket
+    import subprocess
+    import sys
+    import inference_epistemic as mod
+    imgs, names = _make_records(tmp_path, 3)
+    ck = tmp_path / "checkpoints" / "run"
+    ck.mkdir(parents=True)
+    np.savez(str(ck / "model-77.npz"), **golden_params("bayesian_yolov3_aleatoric"))
+    pattern = str(tmp_path / "ecp-day-val-*-of-*")
+    cfg = make_config("bayesian_yolov3_aleatoric", 64, 96, T=5, batch_size=1, checkpoint_path=str(tmp_path / "checkpoints"),
+                      run_id="run", step="last", seed=10, data={"file_pattern": pattern})
+    s0 = mod.inference(dict(cfg, out_path=str(tmp_path / "batch" / "run")))
+    s1 = mod.inference(dict(cfg, out_path=str(tmp_path / "tshard1" / "run"), shard="T"))
+    assert s0["images"] == s1["images"] == 3 and s1["shard"] == "T" and s1["samples"] == [0, 5] and s1["latency_ms_median"] > 0
+    a, b = str(tmp_path / "batch" / "run_77"), str(tmp_path / "tshard1" / "run_77")
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) == sorted(n.replace(".png", ".json") for n in names)
+    for f in os.listdir(a):
+        assert open(os.path.join(a, f)).read() == open(os.path.join(b, f)).read(), f
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BYOLO_DIST_BACKEND="gloo", BYOLO_DIST_SHARE_DEVICE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(here, "_inference_worker.py"), pattern, str(tmp_path / "checkpoints"),
+           str(tmp_path / "tshard2" / "run"), "1", str(tmp_path / "stats"), "T", "5"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    c = str(tmp_path / "tshard2" / "run_77")
+    assert sorted(os.listdir(c)) == sorted(os.listdir(a))
+    st = [json.load(open(str(tmp_path / ("stats_rank%d.json" % r)))) for r in range(2)]
+    assert [x["samples"] for x in st] == [[0, 3], [3, 5]] and [x["images"] for x in st] == [2, 1]
+    num = ("y0", "x0", "y1", "x1", "score", "x_var_epi", "y_var_epi", "w_var_epi", "h_var_epi", "x_var_ale", "y_var_ale", "w_var_ale", "h_var_ale",
+           "obj_mutual_info", "obj_entropy", "ped_score", "rider_score", "cls_mutual_info", "cls_entropy")
+    for f in os.listdir(a):
+        one = json.load(open(os.path.join(a, f)))["children"]
+        two = json.load(open(os.path.join(c, f)))["children"]
+        assert len(one) == len(two) > 0
+        oc = np.array([[d["y0"], d["x0"], d["y1"], d["x1"]] for d in two])
+        for d in one:                              # (the kept ORDER may flip between near-tied scores: match by corners)
+            g = two[int(np.argmin(np.abs(oc - np.array([d["y0"], d["x0"], d["y1"], d["x1"]])).sum(1)))]
+            for k in num:
+                scale = 96.0 if k in ("y0", "x0", "y1", "x1") else 1.0
+                assert abs(g[k] - d[k]) <= 1e-4 * scale * max(1.0, abs(d[k]) / scale), (f, k, g[k], d[k])
+            assert g["layer_id"] == d["layer_id"] and g["prior_id"] == d["prior_id"]
+
+
+@pytest.mark.gpu
 def test_normalize_u8_on_the_device_is_the_host_conversion():
     """byolo_normalize_u8 == decode_img's `astype(float32) * float32(1 / 255)` bit for bit, every byte value, lengths that are
     not a multiple of 4 included (`lib_yolo/dataset_utils.py:6-11`, tf.image.convert_image_dtype)."""

@@ -367,6 +367,48 @@ def test_decode_stage_vs_the_references_own_numpy_decode(size):
         assert np.all(a[..., 11 + C + 1] == 1) and np.all(a[..., 11 + C + 2] == p), "layer / prior ids"
 
 
+@pytest.mark.parametrize("cuts", [((0, 1), (1, 2), (3, 3)), ((0, 3), (3, 3)), ((0, 6),)])
+def test_t_shards_add_up_to_the_whole_forward(cuts):
+    """SURVEY 8(e), the latency alternative: the T = 6 MC samples of ONE image cut into shards -- as the ranks
+    of a job would run them, here one after the other on one engine -- each handing out its per-box SUMS (byolo_set_tshard), the
+    sums added, byolo_finish_tshard.  The shards draw the masks of THEIR samples of the image's six, so the result is the
+    one-call forward up to the order of the float32 additions: rows within the literal bound of the one-call rows AND of the
+    float64 oracle, ids exact, and the tail on the finished rows bit-exact against the oracle NMS.  A single shard (0, 6) runs the
+    same additions in the same order: bit-identical rows."""
+    torch = _torch()
+    from oracle import cpu_ref
+    from conftest import assert_rows_close
+    v = "bayesian_yolov3_aleatoric"
+    T = 6
+    params = golden_params(v)
+    yolo, m = build_model(v, 64, 96, T=T, params=params)
+    m.finalize()
+    eng = m.engine
+    imgs = golden_images(1)
+    x = torch.from_numpy(imgs).cuda()
+    whole = eng.forward(x, T=T, seed=42, want_boxes=True, want_nms=False)["boxes"].clone()
+    sums = None
+    for t0, tl in cuts:
+        part = eng.forward(x, T=tl, seed=42, want_boxes=True, want_nms=False, t_shard=(t0, T))["boxes"]
+        sums = part.clone() if sums is None else sums + part
+    rows = eng.finish_tshard(sums.contiguous(), T)
+    torch.cuda.synchronize()
+    got, ref = rows.cpu().numpy(), whole.cpu().numpy()
+    if len(cuts) == 1:
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "one shard of all samples must be the one-call forward bit for bit"
+    assert_rows_close(got, ref, v, "T shards %s vs the one-call forward" % (cuts,))
+    with torch.no_grad():
+        ref64, _ = cpu_ref.detect_boxes(cpu_ref.to_torch_params(params, torch.float64), imgs, v, T=T, seed=42, dtype=torch.float64)
+    assert_rows_close(got, ref64.numpy(), v, "T shards %s vs the float64 oracle" % (cuts,))
+    res = eng.sort_nms(rows, m.obj_idx, m.cls_start_idx)
+    _check_nms_against_oracle(got, res, v)
+    # the handle is back in the normal mode afterwards
+    again = eng.forward(x, T=T, seed=42, want_boxes=True, want_nms=False)["boxes"]
+    assert torch.equal(again, whole)
+    with pytest.raises(ValueError):
+        eng.forward(torch.cat([x, x]), T=3, seed=42, want_boxes=True, want_nms=False, t_shard=(0, T))
+
+
 def test_dropout_quirk_and_determinism():
     """standard_test_dropout=True disables dropout (layers.py:567-568): equals dropout_on=False and
     all T samples are then identical -> epistemic variances ~ 0.  Same seed twice -> identical bits."""
@@ -548,6 +590,38 @@ def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, bn, m
         assert_close(dl.raw_output.cpu().numpy(), g["raw_%d" % k], "%s raw det output %d (winograd, split)" % (variant, k))
     assert_close(wino["boxes"].cpu().numpy(), gb, "%s pre-NMS rows (winograd, split)" % variant)
     assert_close(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy(), "%s winograd vs direct (split)" % variant)
+    assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
+
+
+@pytest.mark.parametrize("variant", [VARIANTS[2], VARIANTS[1]])
+def test_one_dimensional_winograd_in_split_arithmetic(variant, monkeypatch, precision):
+    """Round 5 experiment (BYOLO_WINO1D=1): the 128-channel 3x3 / stride-1 convolutions -- the three 76x76 head
+    convolutions of the benchmark and the eight backbone ones beside them -- as ONE-DIMENSIONAL Winograd F(2,3) along W with the
+    three filter rows direct (wino_split.hip wino1d_input_kernel + wino_split_kernel<64,256,ONED>): 12 products per output pair
+    instead of 18, V twice the input instead of four times.  Forced onto every such layer (BYOLO_WINO_SPLIT=2) beside the 2-D form
+    on the others: the launch list shows variant 141, rows and raw detection outputs hold the fixtures of the reference's graph at
+    the literal bound, and differ from the direct path's (it really ran)."""
+    if precision != "split":
+        pytest.skip("Winograd in split arithmetic belongs to the default precision")
+    B = 1 if variant.startswith("bayes") else 2
+    monkeypatch.setenv("BYOLO_WINO_SPLIT", "0")
+    _, direct, _, _ = _run(variant, B, keep_all=False)
+    monkeypatch.setenv("BYOLO_WINO_SPLIT", "2")
+    monkeypatch.setenv("BYOLO_WINO1D", "1")
+    m, wino, params, imgs = _run(variant, B)
+    m.engine.set_profiling(2)
+    torch = _torch()
+    m.run(torch.from_numpy(imgs).cuda(), seed=42)
+    torch.cuda.synchronize()
+    v = [s["variant"] for s in m.engine.step_profile()]
+    m.engine.set_profiling(0)
+    assert v.count(141) >= 9 and v.count(-5) == v.count(141), "one-dimensional Winograd launches: %s" % v
+    g = golden("fwd_%s.npz" % variant)
+    gb = g["bbox"] if g["bbox"].ndim == 3 else g["bbox"][None]
+    for k, dl in enumerate(m.det_layers):
+        assert_close(dl.raw_output.cpu().numpy(), g["raw_%d" % k], "%s raw det output %d (1-D winograd, split)" % (variant, k))
+    assert_close(wino["boxes"].cpu().numpy(), gb, "%s pre-NMS rows (1-D winograd, split)" % variant)
+    assert_close(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy(), "%s 1-D winograd vs direct (split)" % variant)
     assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
 
 

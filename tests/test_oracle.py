@@ -160,7 +160,7 @@ def test_nms_two_class():
 def test_rng_definition():
     """The dropout stream: known answers + torch fast path == numpy definition + offset semantics."""
     assert int(rng.keep_threshold(0.1)) == 58982            # round((1 - float32(0.1)) * 2^16)
-    assert int(rng.keep_threshold(0.0)) == 65536 and int(rng.keep_threshold(1.0)) == 0
+    assert int(rng.keep_threshold(0.0)) == 65535 and int(rng.keep_threshold(1.0)) == 0       # thr16 << 16 fits a word
     k0, k1 = rng.layer_keys(42, 0)
     assert (int(k0), int(k1)) == (int(rng.mix32(np.uint32(42 ^ 0x9E3779B9))), int(rng.mix32(np.uint32((0 + int(k0) + 0) & 0xFFFFFFFF))))
     m = rng.keep_mask(42, 3, (4, 5, 6, 32))
@@ -170,28 +170,43 @@ def test_rng_definition():
     # the definition, element by element, in Python integers (csrc/byolo_rng.h: byolo_keep)
     def keep_scalar(i, k0, k1, thr):
         M = 0xFFFFFFFF
-        g = i >> 1
+        g = i >> 2
         x = ((g & M) + k0) & M
         x ^= x >> 16; x = (x * 0x21F0AAAD) & M
         x ^= (k1 + (g >> 32) * 0x9E3779B9) & M
         x ^= x >> 15; x = (x * 0x735A2D97) & M
         x ^= x >> 15
+        if i & 2:
+            x = (x * 0x9E3779B1) & M
+            x ^= x >> 16
         return ((x >> 16) if (i & 1) else (x & 0xFFFF)) < thr
     k0, k1 = (int(v) for v in rng.layer_keys(42, 3))
-    for off in (0, 1, (1 << 33) - 7):
+    for off in (0, 1, (1 << 34) - 7):
         got = rng.keep_mask(42, 3, (16,), offset=off)
         assert got.tolist() == [keep_scalar(off + i, k0, k1, 58982) for i in range(16)]
-    # long-run rate and independence of the two halves of a pair / of neighbouring pairs
-    big_m = rng.keep_mask(5, 1, (1 << 20,))
-    assert abs(big_m.mean() - 58982 / 65536) < 1.5e-3
-    for lag in (1, 2, 3):
+    # long-run rate and independence of the four fields of a group (two of them come from a word DERIVED from the other two's) and
+    # of neighbouring groups
+    big_m = rng.keep_mask(5, 1, (1 << 22,))
+    pk = 58982 / 65536
+    assert abs(big_m.mean() - pk) < 1e-3
+    for lag in (1, 2, 3, 4, 5, 8):
         both = (big_m[:-lag] & big_m[lag:]).mean()
-        assert abs(both - (58982 / 65536) ** 2) < 2e-3, (lag, both)
+        assert abs(both - pk ** 2) < 1.5e-3, (lag, both)
+    grp = big_m.reshape(-1, 4)
+    assert np.abs(grp.mean(0) - pk).max() < 1.5e-3, grp.mean(0)                        # every field at the rate
+    pat = (grp * np.array([1, 2, 4, 8])).sum(1)
+    freq = np.bincount(pat, minlength=16) / len(pat)
+    for v in range(16):                                                                # every 4-bit pattern at its product probability
+        want = np.prod([pk if (v >> q) & 1 else 1 - pk for q in range(4)])
+        assert abs(freq[v] - want) < 4 * np.sqrt(want * (1 - want) / len(pat)) + 1e-4, (v, freq[v], want)
+    # ... across layers and seeds: the same elements under other keys agree like independent draws
+    other = rng.keep_mask(5, 2, (1 << 22,))
+    assert abs((big_m & other).mean() - pk ** 2) < 1.5e-3 and abs((big_m & rng.keep_mask(6, 1, (1 << 22,))).mean() - pk ** 2) < 1.5e-3
     # sample offset: image i of a batch == a batch-1 run with offset i*T*h*w*c
     full = rng.keep_mask(7, 2, (6, 3, 3, 8))
     part = rng.keep_mask(7, 2, (3, 3, 3, 8), offset=3 * 3 * 3 * 8)
     assert np.array_equal(full[3:], part)
-    big = (1 << 33) - 100                                    # the pair index crosses the 32-bit boundary
+    big = (1 << 34) - 100                                    # the group index crosses the 32-bit boundary
     assert np.array_equal(rng.keep_mask(1, 1, (300,), offset=big), rng.keep_mask_torch(1, 1, (300,), offset=big).numpy())
     assert int(rng.mix32(np.uint32(0))) == 0 and int(rng.mix32(np.uint32(1))) == 0x6ABB8EB3 or True
 
