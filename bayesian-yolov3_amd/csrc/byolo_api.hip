@@ -1617,7 +1617,7 @@ static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const C
             w.d_tt = make_fastdiv((uint32_t)(Hp * wp.tw)); w.d_tw = make_fastdiv((uint32_t)wp.tw);
             w.d_c4 = make_fastdiv((uint32_t)(c.C0 / 4)); w.d_n4 = make_fastdiv((uint32_t)(c.N / 4));
             w.vmul = 2.f / ACT_SCALE;
-            if (prof && (rc = mark_launch(h, s.layer, -5, w.P, c.C0, 0, 0.0, st))) return rc;
+            if (prof && (rc = mark_launch(h, s.layer, -6, w.P, c.C0, 0, 0.0, st))) return rc;
             HIPCHK(h, launch_wino1d_input(w, st));
             WinoSplitParams f; memset(&f, 0, sizeof f);
             const int P = ns * l.H * wp.tw, P_pad = (int)align_up((size_t)P, 64);

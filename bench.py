@@ -647,7 +647,7 @@ def main():
             split = dom in SPLIT
             # peak of the matrix instruction actually issued, useful FLOPs counted once
             peak = PEAK_F16_MFMA if split else PEAK_FP32_MFMA
-            wino_ms = sum(acc[v][1] for v in (-2, -3, -4, -5) if v in acc)
+            wino_ms = sum(acc[v][1] for v in (-2, -3, -4, -6) if v in acc)
             # fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same command
             # (tools/profile_round.sh + tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent / another kernel
             traffic = tr_read = tr_write = measured_at = None
@@ -702,7 +702,7 @@ def main():
                                                                           "algorithmic_tflops": acc[v][0] / (acc[v][1] * 1e-3) / 1e12,
                                                                           "executed_tflops": acc[v][3] / (acc[v][1] * 1e-3) / 1e12}
                                               for v in sorted(mm, key=lambda v: -acc[v][1])},
-                                "transform_kernels_ms": {str(v): acc[v][1] for v in (-2, -3, -4, -5) if v in acc},
+                                "transform_kernels_ms": {str(v): acc[v][1] for v in (-2, -3, -4, -6) if v in acc},
                                 # 8(d)'s formula for the whole step: img/s * F(H,W,T) / (n_gpu * peak); and against the fp32 MFMA peak the
                                 # reference's own arithmetic would be priced at (> 1 = beyond that instruction's ceiling)
                                 "end_to_end_frac": (imgs / dt) * flops_img / (world * peak),
