@@ -80,6 +80,9 @@ PROTOTYPES = {
     "byolo_flops": (_i32, [_vp, _i32, _i32, _P(ctypes.c_double)]),
     "byolo_crc32c": (ctypes.c_uint32, [_vp, _sz]),
     "byolo_abi_version": (_i32, []),
+    "byolo_plan_num": (_i32, [_vp, _i32, _i32, _i32, _P(_i32), _P(_i32), _P(_i64)]),
+    "byolo_plan_step": (_i32, [_vp, _i32, _P(_i32), _P(_i32), _P(_i32), _P(_i32)]),
+    "byolo_plan_tensor": (_i32, [_vp, _i32, _P(_i64), _P(_i64), _P(_i32)]),
     "byolo_set_tshard": (_i32, [_vp, _i32, _i32]),
     "byolo_finish_tshard": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "byolo_normalize_u8": (_i32, [_vp, _vp, _i64, _vp, _vp]),

@@ -11,9 +11,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "..", "byolo", "libbyolo.so")
-SRCS = ["byolo_api.hip", "conv_igemm.hip", "conv_kernels.hip", "winograd.hip", "gemm_stream.hip", "wino_fused.hip", "wino_split.hip", "tail_kernels.hip",
+SRCS = ["byolo_api.hip", "byolo_pack.hip", "byolo_plan.hip", "conv_igemm.hip", "conv_kernels.hip", "winograd.hip", "gemm_stream.hip", "wino_fused.hip", "wino_split.hip", "tail_kernels.hip",
         "train_kernels.hip", "host_io.cpp"]
-HDRS = ["byolo_kernels.h", "byolo_rng.h", "mfma_pipe.h", "epilogue.h", os.path.join("..", "..", "include", "byolo.h")]
+HDRS = ["byolo_kernels.h", "byolo_internal.h", "byolo_rng.h", "mfma_pipe.h", "epilogue.h", os.path.join("..", "..", "include", "byolo.h")]
 DEPS = SRCS + HDRS
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result"]
 LIBS = ["-lz"]          # host_io.cpp: the PNG decoder inflates with zlib

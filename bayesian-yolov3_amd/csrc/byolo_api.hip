@@ -12,215 +12,16 @@
 //   detection conv (+bias) -> split -> decode             conv_igemm (bias epilogue) + one decode launch
 //                                                          writing rows at their concat_bbox offset
 //   concat_bbox -> non_max_suppression -> gather          sort_keys + nms launches
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/byolo.h"
-#include "byolo_kernels.h"
-#include "byolo_rng.h"
-
-using namespace byk;
-
-namespace {
-
-enum Op { OP_CONV, OP_RESIDUAL, OP_ROUTE, OP_UPSAMPLE, OP_STACK, OP_DETECTION };
-
-struct Param {
-    std::string name;
-    std::vector<int64_t> shape;
-    std::vector<float> data;
-    int64_t count() const { int64_t c = 1; for (auto s : shape) c *= s; return c; }
-};
-
-struct Layer {
-    Op op;
-    std::string scope;
-    int filters = 0, ksize = 0, stride = 1, norm = 0;
-    int prev = -1;                 // implicit input (previous layer; -1 = image)
-    int ref[2] = {-1, -1};         // explicit absolute refs (shortcut / routes / stack src)
-    int nref = 0;
-    int det_kind = 0, det_id = 0;
-    float priors[6] = {0, 0, 0, 0, 0, 0};
-    // inferred output
-    int C = 0, H = 0, W = 0;
-    bool stacked = false;
-    // params
-    int p_kernel = -1, p_bias = -1, p_gamma = -1, p_beta = -1, p_mean = -1, p_var = -1;
-    int drop_ordinal = -1;
-    int Cin = 0;
-    // lowering
-    bool materialized = false;     // owns an activation tensor
-    int out_tensor = -1;           // layer index whose tensor receives this conv's output
-    int fused_residual = -1;       // residual layer fused into this conv's epilogue
-    bool standalone = false;       // residual layer computed by its own element-wise step (STEP_ADD)
-    int add_a = -1;                // ... its left operand (tensor id)
-    // packed weights (offsets in floats into the device blob)
-    size_t w_off = 0, scale_off = 0, shift_off = 0;
-    size_t scalek_off = 0;             // dropout layers: scale / (1 - p), what the epilogue multiplies with when the masks are on
-    int tile = 0, Npad = 0;
-    bool direct = false;
-    std::vector<int> wshift;       // split precision, per OUTPUT CHANNEL n: the packed weights hold w[.][n] * 2^wshift[n] (the channel's largest |w'| in [2^13, 2^14)); folded into scale[n]
-    std::vector<int> wshift_u;     // split precision, Winograd (wino_split.hip): per output channel, for U = G g G^T
-    bool wino1d = false;           // ... packed for the ONE-DIMENSIONAL form instead (BYOLO_WINO1D, round 5 experiment): U[xi][ky] = G g[ky, :]
-    size_t wscale_off = 0, wscalek_off = 0;    // ... and the per-channel scale arrays that go with it (the shift is the layer's)
-    float in_scale = 1.f;          // split precision: scale of the layer's input (ACT_SCALE for activations, 1 for the fp32 image of a direct convolution)
-    int64_t box_base = 0;
-};
-
-struct Src { int layer; int C; int sh; bool tile; };
-struct View { Src s[2]; int n = 0; };
-
-// One conv launch.  Normally one per conv/detection layer; the T-invariant de-duplication
-//  lowers some layers of a stacked (MC-sample) graph differently:
-//   STEP_REP      every input is a T-fold tile of an unstacked tensor and the layer has dropout: the
-//                 conv runs once per image, the epilogue is replayed for the T samples (masks differ);
-//   STEP_PARTIAL  the tiled (T-invariant) half of a channel concat, convolved once per image into an
-//                 auxiliary raw-accumulator tensor ...
-//   STEP_MAIN     ... which the conv over the stacked half picks up as an addend before scale / mask.
-// Two more step kinds keep the builder general (the reference's models never need them):
-//   STEP_GATHER   a route / upsample / stack VIEW that a loader cannot express on the fly (the inner view of a nested
-//                 concat or double upsample, a view used as a residual shortcut) is copied into a tensor of its own;
-//   STEP_ADD      a residual add that cannot ride in a convolution's epilogue (its left operand is not a convolution,
-//                 or that convolution's output has other readers) runs as an element-wise kernel.
-// And one that the reference's Bayesian model does need (round 4): the stacked half of its two concat convolutions is an
-// UPSAMPLED tensor, and a 1x1 convolution commutes with nearest-neighbour upsampling -- its GEMM belongs at the source's
-// resolution, a quarter of the rows:
-//   STEP_PARTIAL with `low`  the stacked half, convolved per SAMPLE at the source's resolution into an auxiliary raw-accumulator
-//                 tensor [S, H/2, W/2, N] (it also owns the layer's scale / shift arrays);
-//   STEP_FINISH   output pixel (s, y, x) = epilogue(low[s, y/2, x/2] + partial[image, y, x]): an element-wise kernel
-//                 (conv_kernels.hip finish_upsampled_kernel).  The same two numbers added in the same order as STEP_MAIN's
-//                 accumulator + addend, the same epilogue arithmetic: the same bits.  BYOLO_LOWMAIN=0 keeps STEP_MAIN.
-enum StepMode { STEP_NORMAL = 0, STEP_REP = 1, STEP_PARTIAL = 2, STEP_MAIN = 3, STEP_GATHER = 4, STEP_ADD = 5, STEP_FINISH = 6 };
-struct Step {
-    int layer; View in;
-    int mode = STEP_NORMAL;
-    bool is_conv() const { return mode <= STEP_MAIN; }
-    int c_lo = 0, c_hi = 0;        // input-channel range of the layer's Cin this launch convolves
-    int out_tensor = -1;           // tensor id written (layer index, or n_layers + aux index)
-    int addend_tensor = -1;        // STEP_MAIN / STEP_FINISH: the PARTIAL result
-    bool low = false;              // STEP_PARTIAL: the stacked half at the source's resolution (per sample, output H/2 x W/2)
-    int low_tensor = -1;           // STEP_FINISH: that launch's result
-    size_t w_off = 0; int Npad = 0, tile = 0;   // packed weights of this launch
-    bool wino_ok = false;          // 3x3 / stride 1 over one plain source: Winograd F(2x2,3x3) is possible
-    size_t wino_off = 0;           // the 16 transformed weight matrices U[xi], each packed [Cin/32][Npad][32]
-    bool p1 = false;               // split precision: 1x1 / stride 1 over one plain source -- the uniform loop of conv_tile_p1 (BYOLO_P1=0: the general loop)
-    bool kx3 = false;              // split precision: 3x3 / stride 1 over one plain source -- shared-tap stages (conv_tile_kx3), weights in (ky, chunk, kx) order
-};
-// per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
-struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; int bm = 0, bn = 0; /* split precision: output tiles / channels per workgroup */ bool oned = false; };
-struct AuxTensor { int H, W, C; bool stacked = false; };      // stacked: one row per SAMPLE pixel (else per image pixel)
-
-struct Plan {
-    int B = -1, T = -1;
-    std::vector<int64_t> off;      // per layer tensor offset in bytes (-1: none)
-    size_t arena = 0, boxes_off = 0, nms_off = 0, stats_off = 0, total = 0;
-    size_t img_split_off = 0;      // split precision: the image as hi/lo pairs, for a matrix-pipe convolution that reads it (img_c % 32 == 0)
-    size_t slab_off = 0, slab_bytes = 0, cnt_off = 0, cnt_bytes = 0;   // split-K slabs (shared by all steps), per-step ticket counters
-    std::vector<ConvSplit> split;  // per step
-    std::vector<int> tile;         // per step: tile configuration of the launch
-    std::vector<WinoPlan> wino;    // per step
-    std::vector<int> stream1x1;    // per step: tile width of the row-streaming 1x1 launch (gemm_stream.hip), 0 = conv_igemm
-    std::vector<char> fuse;        // per step: the NEXT step (a 1x1 convolution / detection head reading only this output) runs inside this launch
-    size_t wino_off = 0;           // scratch for V and M of one chunk (shared by all steps)
-};
-static constexpr int CNT_PER_STEP = 1024;      // >= resident workgroups of any tile configuration
-// split precision: every activation tensor holds ACT_SCALE * value, so that the lo half of a value >= 2^-4 is a normal
-// fp16 (smaller values keep an absolute error of 2^-25 / ACT_SCALE = 7.5e-9 -- the fp32 rounding of a value of 0.125);
-// an activation beyond 65504 / ACT_SCALE = 16376 overflows to infinity.  A power of two: folded into scale / shift
-// exactly.  (Measured at 608x608, T=4 against the float64 oracle: scale 1, 4, 16 are indistinguishable -- DESIGN.md 5.)
-static constexpr float ACT_SCALE = 4.f;
-
-}  // namespace
-
-struct byolo {
-    byolo_cfg cfg;
-    int device = 0;
-    std::string err;
-    std::vector<Layer> layers;
-    std::vector<Param> params;
-    std::map<std::string, int> pindex;
-    int n_dropout = 0, n_det = 0;
-    int backbone_end = -1;
-    bool finalized = false;        // weights folded, packed and uploaded
-    bool lowered = false;          // graph frozen and lowered to steps (host only)
-    std::vector<char> need_mat;    // per layer: this view is copied into a tensor of its own (STEP_GATHER)
-    mutable int want_mat = -1;     // lowering: the view whose materialisation would resolve the last failure
-    std::vector<Step> steps;
-    std::vector<AuxTensor> aux;    // auxiliary tensors (ids n_layers + k): partial sums of split convs
-    bool dedup = true;             // T-invariant de-duplication (BYOLO_NO_DEDUP=1 disables, for A/B)
-    // Arithmetic of the convolution stack (byolo_set_precision; BYOLO_PRECISION=f32|split):
-    //   0  fp32 operands on v_mfma_f32_32x32x2_f32 (+ Winograd F(2x2,3x3) where it pays)
-    //   1  split-f16 operands ("hi + lo", ~23 significant bits, fp32 accumulation) on v_mfma_f32_32x32x16_f16:
-    //      activations live in memory as [4 hi | 4 lo] groups holding ACT_SCALE * value, weights as 2^wshift * w
-    bool img_split = false;        // split precision: some matrix-pipe convolution reads the image -> a hi/lo copy is made per forward
-    int precision = 1;             // default: split-f16 (BYOLO_PRECISION=f32 selects the fp32 matrix instruction)
-    int prec_requested = 1;        // what byolo_set_precision / BYOLO_PRECISION asked for
-    std::string prec_note;         // why byolo_finalize fell back to BYOLO_PREC_F32 (empty: it did not)
-    // Numeric status (byolo_status): two device words {flags, first layer} every split-f16 epilogue / decode launch of this
-    // handle may raise (sticky until byolo_clear_status), and their pinned host mirror
-    unsigned* d_status = nullptr; unsigned* h_status = nullptr;
-    bool async_status = false;     // byolo_set_async: byolo_forward does not wait for the status words
-    bool plan_inject = false;      // the current plan was made for injected dropout masks (fp32 mode: conv_igemm launches only)
-    int plan_epoch = 0;            // bumped whenever the plan is invalidated (precision, finalize)
-    int wsm_B = -1, wsm_T = -1, wsm_epoch = -1; size_t wsm_total = 0;     // byolo_workspace_bytes: size of the masked-call plan of (B, T)
-    // Forwards of ONE handle alternating over several streams (a caller pipelining whole steps: bench.py --pipeline): the
-    // convolution stacks run one after the other -- two of them sharing the chip gain nothing and blur every per-launch timing
-    // -- while a step's latency-bound tail (decode, sort, NMS) overlaps the next step's convolutions.  ev_convs is recorded
-    // behind the last convolution launch of a forward; a forward on ANOTHER stream waits for it before its first launch.
-    hipEvent_t ev_convs = nullptr; hipStream_t convs_stream = nullptr; bool ev_convs_valid = false;
-    std::vector<int> last_use;     // per tensor id: index of the last step reading it
-    float* d_blob = nullptr;       // packed weights + scale/shift
-    size_t blob_floats = 0;
-    float* d_ones = nullptr; float* d_zeros = nullptr; int maxC = 0;
-    int64_t n_boxes = 0; int row_len = 0, obj_idx = 0, cls_start = 0;
-    Plan plan;
-    void* last_ws = nullptr;
-    int64_t first_image = 0;       // position of a call's first image in the logical batch (dropout stream)
-    int tshard_t0 = 0, tshard_T = 0;   // byolo_set_tshard: this call's T samples are samples t0 .. t0 + T - 1 of tshard_T per image (0 = off)
-    int profiling = 0;             // 0 off, 1 stage events, 2 + one event per conv launch
-    // level 2: one entry per kernel launch of the convolution stack in a forward (a Winograd layer
-    // contributes input transform / GEMM / output transform per chunk); event k is recorded before launch k
-    // ev_begin / ev_end: indices into the slot's event pool (the end of a launch is the begin of the next one)
-    struct Launch { int layer, variant; int64_t m, n, k; double algo_flops; int ksplit, split_tiles; int ev_begin, ev_end; };
-    // The records of the last `depth` profiled forwards (byolo_set_profile_depth; 1 by default): a caller that times a
-    // run of back-to-back forwards reads all of them AFTER the run instead of synchronising with every step.
-    struct ProfSlot {
-        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        bool ev_valid = false;
-        std::vector<Launch> launches;
-        std::vector<hipEvent_t> step_ev;   // pool; n_ev in use
-        int n_ev = 0, last_main = -1;      // events used by this forward; the last launch marked (its end = the next one's begin)
-        bool step_valid = false;
-    };
-    std::vector<ProfSlot> prof = std::vector<ProfSlot>(1);
-    int prof_w = 0;                    // slot of the most recent profiled forward
-    int prof_age = 0;                  // which forward the read calls refer to: 0 = the last, 1 = the one before, ...
-    ProfSlot& wslot() { return prof[prof_w]; }
-    ProfSlot& rslot() { const int d = (int)prof.size(); return prof[((prof_w - prof_age) % d + d) % d]; }
-};
+#include "byolo_internal.h"
 
 static thread_local std::string g_err;
 
-static int32_t fail(byolo_t* h, int32_t code, const char* fmt, ...) {
+int32_t byolo_fail(byolo_t* h, int32_t code, const char* fmt, ...) {
     char buf[1024];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     if (h) h->err = buf; else g_err = buf;
     return code;
 }
-#define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
-    return fail(h, BYOLO_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
-
-static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
 extern "C" const char* byolo_version(void) { return "byolo 0.6 (gfx950; fp32 MFMA and split-f16 MFMA; abi 6)"; }
@@ -307,16 +108,6 @@ static int32_t begin_add(byolo_t* h, const char* what) {
     if (!h) return fail(nullptr, BYOLO_ERR_ARG, "%s: null handle", what);
     if (h->lowered) return fail(h, BYOLO_ERR_STATE, "%s: graph is frozen after byolo_finalize", what);
     return BYOLO_OK;
-}
-
-// No C++ exception leaves the C-ABI: a host allocation that fails (a graph of absurd sizes) is BYOLO_ERR_NOMEM, like a workspace
-// that is too small -- the caller is a ctypes / cgo / JNI binding that cannot unwind.
-template <class F>
-static int32_t guarded(byolo_t* h, const char* what, F&& f) {
-    try { return f(); }
-    catch (const std::bad_alloc&) { return fail(h, BYOLO_ERR_NOMEM, "%s: out of host memory", what); }
-    catch (const std::exception& e) { return fail(h, BYOLO_ERR_ARG, "%s: %s", what, e.what()); }
-    catch (...) { return fail(h, BYOLO_ERR_ARG, "%s: an exception that is not a std::exception", what); }      // nothing crosses the C-ABI (include/byolo.h)
 }
 
 // Bounds of a convolution this library will hold on the host (the reference's largest: 1024 channels, 4.7 M weights): beyond them a
@@ -668,13 +459,14 @@ static int32_t lower_once(byolo_t* h) {
     }
     h->maxC = 1;
     for (const auto& l : h->layers) h->maxC = std::max(h->maxC, l.C);
+    decide_loops(h);
     h->lowered = true;
     return BYOLO_OK;
 }
 
 // Lower the graph; where a view cannot be expressed inside a loader, give that view a tensor of its own and try again
 // (at most once per layer).
-static int32_t lower(byolo_t* h) {
+int32_t byolo_lower(byolo_t* h) {
     const int n = (int)h->layers.size();
     if (!n) return fail(h, BYOLO_ERR_STATE, "byolo_finalize: empty graph");
     if (!h->n_det) return fail(h, BYOLO_ERR_STATE, "byolo_finalize: no detection layer (model.py:190: assert len(det_layers) > 0)");
@@ -688,7 +480,9 @@ static int32_t lower(byolo_t* h) {
     }
 }
 
-static float* dptr(const byolo_t* h, size_t off) { return h->d_blob + off; }
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
 // Position, in samples, of a call's first sample in the dropout stream of a tensor with T samples per image in this call:
 // first_image * T -- or, with the T samples of an image sharded over ranks (byolo_set_tshard: one image per call), sample t0 of the
 // tshard_T the image has in the whole job.
@@ -697,711 +491,6 @@ static uint64_t sample_base(const byolo_t* h, int T, bool stacked) {
     return (uint64_t)h->first_image * (uint64_t)T;
 }
 
-static void fold_layer(const byolo_t* h, const Layer& l, std::vector<float>& scale, std::vector<float>& shift) {
-    const int N = l.filters;
-    scale.resize(N); shift.resize(N);
-    if (l.op == OP_DETECTION) {
-        const float* b = h->params[l.p_bias].data.data();
-        for (int c = 0; c < N; ++c) { scale[c] = 1.f; shift[c] = b[c]; }
-        return;
-    }
-    const float* g = h->params[l.p_gamma].data.data();
-    const float* be = h->params[l.p_beta].data.data();
-    const float* m = h->params[l.p_mean].data.data();
-    const float* v = h->params[l.p_var].data.data();
-    for (int c = 0; c < N; ++c) {                              // layers.py:510-518, eps 1e-5
-        const float inv = g[c] * (1.0f / sqrtf(v[c] + 1e-5f));
-        scale[c] = inv; shift[c] = be[c] - m[c] * inv;
-    }
-}
-
-// split precision: the accumulators hold ACT_SCALE * 2^wshift * conv (the stem: conv -- fp32 image, fp32 weights) and the
-// output tensor holds ACT_SCALE * value (a detection head: the value itself, fp32) -- powers of two, folded exactly
-static float acc_scale_of(const Layer& l, int c) {                                    // the direct kernels keep fp32 weights
-    return l.in_scale * ((l.direct || l.wshift.empty()) ? 1.f : ldexpf(1.f, l.wshift[c]));
-}
-static void fold_split(const Layer& l, std::vector<float>& scale, std::vector<float>& shift) {
-    const float out_scale = l.op == OP_DETECTION ? 1.f : ACT_SCALE;
-    for (size_t c = 0; c < scale.size(); ++c) scale[c] *= out_scale / acc_scale_of(l, (int)c);
-    for (float& v : shift) v *= out_scale;
-}
-
-// inverted dropout's 1 / (1 - p) (layers.py:520-527 via tf.layers.dropout) is folded into the per-channel scale
-static void scale_keep(const byolo_t* h, std::vector<float>& scale) {
-    const float inv_keep = 1.0f / (1.0f - h->cfg.drop_prob);
-    for (float& v : scale) v *= inv_keep;
-}
-
-// split precision, Winograd launches of layer l: V holds B^T d B of the VALUES (the transform multiplies the stored 4 * value by
-// 1/4), U holds 2^wshift_u * (G g G^T): the accumulators are 2^wshift_u * conv, the output tensor holds ACT_SCALE * value
-static void wino_scales(const byolo_t* h, const Layer& l, std::vector<float>& sc, std::vector<float>& sk) {
-    std::vector<float> sf;
-    fold_layer(h, l, sc, sf);
-    for (size_t c = 0; c < sc.size(); ++c) sc[c] *= ACT_SCALE / ldexpf(1.f, l.wshift_u[c]);
-    sk = sc;
-    scale_keep(h, sk);
-}
-
-// byolo_finalize packs ~62 M weights (hi/lo fragments, Winograd U in double): independent per launch, so on the host's cores.
-// BYOLO_FINALIZE_THREADS: worker threads (default: the cores / LOCAL_WORLD_SIZE, at most 32; 1 = in the calling thread).  The packed bytes do not
-// depend on it (every element is computed by the same expression; tasks write disjoint ranges).
-template <class F>
-static bool parallel_tasks(int n, F&& f) {
-    const char* e = getenv("BYOLO_FINALIZE_THREADS");
-    // one process per GPU: the N ranks of a node finalize at the same time -- each takes its share of the hardware threads
-    // (LOCAL_WORLD_SIZE is what torchrun exports; 8 ranks x 32 packing threads on one host was round 4's default)
-    const char* lw = getenv("LOCAL_WORLD_SIZE");
-    const int ranks = std::max(1, lw ? atoi(lw) : 1);
-    const int want = e ? atoi(e) : std::max(1, (int)std::thread::hardware_concurrency() / ranks);
-    const int nt = std::min(n, std::max(1, std::min(want, 32)));
-    std::atomic<int> next{0};
-    std::atomic<bool> ok{true};
-    auto work = [&] {
-        try { for (int i; (i = next.fetch_add(1)) < n;) f(i); }
-        catch (...) { ok = false; }
-    };
-    std::vector<std::thread> th;
-    try { for (int t = 1; t < nt; ++t) th.emplace_back(work); } catch (...) {}      // (no more threads to be had: fewer workers)
-    work();
-    for (auto& t : th) t.join();
-    return ok;
-}
-
-static int32_t finalize_impl(byolo_t* h) {
-    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "byolo_finalize: null handle");
-    if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
-    // Every parameter must be a number.  The reference would carry an inf / NaN from a checkpoint (tf.train.Saver.restore,
-    // inference_epistemic.py:58) silently into its float32 outputs; here it would also poison the per-channel weight scales.
-    for (const auto& l : h->layers) {
-        if (l.op != OP_CONV && l.op != OP_DETECTION) continue;
-        for (int pi : {l.p_kernel, l.p_bias, l.p_gamma, l.p_beta, l.p_mean, l.p_var}) {
-            if (pi < 0) continue;
-            for (float v : h->params[pi].data)
-                if (!std::isfinite(v)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: variable '%s' holds a non-finite value", h->params[pi].name.c_str());
-        }
-        if (l.p_var >= 0)
-            for (float v : h->params[l.p_var].data)
-                if (!(v + 1e-5f > 0.f)) return fail(h, BYOLO_ERR_ARG, "byolo_finalize: variable '%s' holds a variance <= -eps (rsqrt of a negative number)", h->params[l.p_var].name.c_str());
-    }
-    // Split storage keeps activations in groups of 4 channels.  A graph it cannot express (no reference model has one) runs in
-    // the fp32 mode instead of being refused: byolo_get_precision / byolo_precision_note tell.
-    if (h->precision == 0 && !h->prec_note.empty() && h->prec_requested == 1) h->precision = 1;      // the request stands; decide again
-    h->prec_note.clear();
-    if (h->precision == 1)
-        for (const auto& l : h->layers)
-            if (l.op == OP_CONV && (l.filters % 4)) {
-                char buf[256];
-                snprintf(buf, sizeof buf, "fp32 mode: split-f16 storage needs output channels in groups of 4, layer '%s' has %d", l.scope.c_str(), l.filters);
-                h->prec_note = buf; h->precision = 0; h->plan.B = -1; h->plan.T = -1; ++h->plan_epoch;
-                static const bool quiet = [] { const char* e = getenv("BYOLO_QUIET"); return e && atoi(e); }();
-                if (!quiet) fprintf(stderr, "byolo: %s\n", buf);
-                break;
-            }
-    HIPCHK(h, hipSetDevice(h->device));
-    if (!h->d_status) {
-        HIPCHK(h, hipMalloc((void**)&h->d_status, 2 * sizeof(unsigned)));
-        HIPCHK(h, hipHostMalloc((void**)&h->h_status, 2 * sizeof(unsigned), hipHostMallocDefault));
-        const unsigned init[2] = {0u, 0xFFFFFFFFu};
-        HIPCHK(h, hipMemcpy(h->d_status, init, sizeof init, hipMemcpyHostToDevice));
-        h->h_status[0] = 0u; h->h_status[1] = 0xFFFFFFFFu;
-    }
-    // layout of the device blob
-    size_t off = 0; const int maxC = h->maxC;
-    for (auto& st : h->steps) {
-        if (!st.is_conv()) continue;
-        Layer& l = h->layers[st.layer];
-        const int Cs = st.c_hi - st.c_lo, K = l.ksize * l.ksize * Cs, N = l.filters;
-        st.w_off = off; off += align_up((size_t)K * st.Npad, 64);      // tile / Npad / wino_ok: set by lower()
-        l.tile = st.tile; l.Npad = st.Npad;
-        if (st.wino_ok) { st.wino_off = off; off += align_up((size_t)16 * Cs * st.Npad, 64); }
-        if (st.mode == STEP_PARTIAL && !st.low) continue;       // raw accumulators: no scale / shift (the `low` launch owns the layer's, for its STEP_FINISH)
-        l.scale_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);   // readable (zeros) up to Npad
-        l.shift_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
-        if (l.drop_ordinal >= 0) { l.scalek_off = off; off += align_up((size_t)std::max(N, st.Npad), 64); }
-        if (st.wino_ok) {                                       // split precision: the scales that go with U's own power-of-two shifts
-            l.wscale_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
-            l.wscalek_off = off; off += align_up((size_t)std::max(N, st.Npad), 64);
-        }
-    }
-    std::vector<float> blob(off, 0.f);
-    std::vector<float> sc, sf;
-    h->img_split = false;
-    if (h->precision == 1) {
-        const char* ple = getenv("BYOLO_WSHIFT_PER_LAYER");
-        const bool per_layer = ple && atoi(ple);
-        const bool ok = parallel_tasks((int)h->layers.size(), [&](int li) {
-            Layer& l = h->layers[li];
-            if (l.op != OP_CONV && l.op != OP_DETECTION) return;
-            // a direct convolution reads the image as it is (fp32); a matrix-pipe convolution reads a hi/lo copy of it
-            l.in_scale = (l.direct && l.prev < 0) ? 1.f : ACT_SCALE;
-            // One power of two PER OUTPUT CHANNEL (folded into scale[n], exactly): the column's largest |w'| lands in
-            // [2^13, 2^14), so a filter whose weights are 2^-10 of its neighbours' -- a checkpoint whose BN gammas absorbed the
-            // scale, e.g. -- keeps its 22 bits.  (One shift per layer gave such a column 12.)  Clamped: 2^shift stays finite.
-            const Param& k = h->params[l.p_kernel];
-            const int N = l.filters;
-            const size_t rows = k.data.size() / (size_t)N;          // HWIO == [K][N]
-            std::vector<float> mx((size_t)N, 0.f);
-            for (size_t r = 0; r < rows; ++r) {
-                const float* kr = k.data.data() + r * N;
-                for (int n = 0; n < N; ++n) mx[n] = std::max(mx[n], std::fabs(kr[n]));
-            }
-            l.wshift.assign((size_t)N, 0);
-            l.wshift_u.clear();
-            for (int n = 0; n < N; ++n) {
-                int e = 0;
-                if (mx[n] > 0.f) (void)std::frexp(mx[n], &e);      // mx = m * 2^e, m in [0.5, 1)
-                l.wshift[n] = mx[n] > 0.f ? std::min(126, std::max(-126, 14 - e)) : 0;      // 2^shift and 2^-shift are normal floats
-            }
-            // BYOLO_WSHIFT_PER_LAYER=1 (A/B in tests/test_robustness.py): one shift per layer, from the layer's largest weight
-            if (per_layer) {
-                int lo = 127;
-                for (int n = 0; n < N; ++n) if (mx[n] > 0.f) lo = std::min(lo, l.wshift[n]);
-                l.wshift.assign((size_t)N, lo == 127 ? 0 : lo);
-            }
-        });
-        if (!ok) return fail(h, BYOLO_ERR_NOMEM, "byolo_finalize: out of host memory");
-        for (const auto& l : h->layers)
-            if ((l.op == OP_CONV || l.op == OP_DETECTION) && !l.direct && l.prev < 0) h->img_split = true;
-    }
-    // Tasks: (step, 0) packs the launch's weights, (step, 1) its Winograd-domain weights; the largest first.  Every task writes its
-    // own range of the blob and its own step / layer fields (a Winograd launch is the only step of its layer).
-    struct PackTask { int step, kind; double cost; };
-    std::vector<PackTask> tasks;
-    for (size_t si = 0; si < h->steps.size(); ++si) {
-        const Step& st = h->steps[si];
-        if (!st.is_conv()) continue;
-        const Layer& l = h->layers[st.layer];
-        const double k = (double)l.ksize * l.ksize * (st.c_hi - st.c_lo) * l.filters;
-        tasks.push_back({(int)si, 0, k});
-        if (st.wino_ok) tasks.push_back({(int)si, 1, 2.0 * 16 / 9 * k});
-    }
-    std::stable_sort(tasks.begin(), tasks.end(), [](const PackTask& a, const PackTask& b) { return a.cost > b.cost; });
-    const bool packed = parallel_tasks((int)tasks.size(), [&](int ti) {
-        Step& st = h->steps[tasks[ti].step];
-        const Layer& l = h->layers[st.layer];
-        const int Cs = st.c_hi - st.c_lo, taps = l.ksize * l.ksize, N = l.filters;
-        const float* w = h->params[l.p_kernel].data.data();     // HWIO == [K][N], k = (ky*ks + kx)*Cin + c
-        if (tasks[ti].kind == 0) {
-            st.kx3 = false; st.p1 = false;
-            float* dst = blob.data() + st.w_off;
-            if (l.direct) memcpy(dst, w, sizeof(float) * (size_t)taps * l.Cin * N);
-            else if (h->precision == 1) {
-                static const bool kx3_on = [] { const char* e = getenv("BYOLO_KX3"); return !e || atoi(e) != 0; }();
-                st.kx3 = kx3_on && l.ksize == 3 && l.stride == 1 && st.in.n == 1 && st.in.s[0].sh == 0 && st.in.s[0].layer >= 0 && st.Npad >= 64 &&
-                         (st.mode == STEP_NORMAL || st.mode == STEP_REP);
-                const char* p1e = getenv("BYOLO_P1");
-                const bool p1_on = !p1e || atoi(p1e) != 0;
-                st.p1 = p1_on && l.ksize == 1 && l.stride == 1 && st.in.n == 1 && st.in.s[0].layer >= 0 && st.Npad >= 64;
-                const int cts = Cs / 32;
-                // split-f16 weights (mfma_pipe.h): w' = w * 2^wshift with the layer's largest |w'| in [2^13, 2^14), each
-                // element as hi = RNE_f16(w'), lo = RNE_f16(w' - hi), in FRAGMENT ORDER: [K-tile][32-column block][step s]
-                // [plane: hi, lo][lane = 32 * half + column][8 fp16: k = 32 kt + 16 s + 8 half + 0..7] -- the operand
-                // registers of v_mfma_f32_32x32x16_f16 as one coalesced 1 KB load per (step, plane).
-                // K-tile order: (tap, chunk); shared-tap launches: (ky, chunk, kx)
-                _Float16* d16 = reinterpret_cast<_Float16*>(dst);
-                std::vector<float> ws((size_t)N);
-                for (int nn = 0; nn < N; ++nn) ws[nn] = ldexpf(1.f, l.wshift[nn]);
-                const size_t blocks = st.Npad / 32;
-                for (int tap = 0; tap < taps; ++tap)
-                    for (int c = 0; c < Cs; ++c) {
-                        const int kk = c & 31, step = kk >> 4, half = (kk >> 3) & 1, e = kk & 7;
-                        const int kt = st.kx3 ? ((tap / 3) * cts + (c >> 5)) * 3 + tap % 3 : tap * cts + (c >> 5);
-                        const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
-                        for (int nn = 0; nn < N; ++nn) {
-                            const float v = wr[nn] * ws[nn];
-                            const _Float16 hi = (_Float16)v;
-                            _Float16* d = d16 + (((size_t)kt * blocks + (nn >> 5)) * 4 + step * 2) * 512 + (half * 32 + (nn & 31)) * 8 + e;
-                            d[0] = hi; d[512] = (_Float16)(v - (float)hi);
-                        }
-                    }
-            } else {
-                for (int tap = 0; tap < taps; ++tap)
-                    for (int c = 0; c < Cs; ++c) {                  // this launch's channel slice of every tap
-                        const int k = tap * Cs + c, kt = k >> 5, kk = k & 31;
-                        const float* wr = w + ((size_t)tap * l.Cin + st.c_lo + c) * N;
-                        float* d = dst + ((size_t)kt * st.Npad) * 32 + kk;
-                        for (int nn = 0; nn < N; ++nn) d[(size_t)nn * 32] = wr[nn];
-                    }
-            }
-            return;
-        }
-        if (st.wino_ok && h->precision == 1 && wino_split_ok(Cs, N) && st.Npad == N) {
-            // Winograd in split arithmetic (wino_split.hip): U[xi][c][n] = (G g G^T)[xi] in double, rounded once; one power of two per
-            // output channel over all 16 points; hi/lo pairs in fragment order, K-tile order (point, chunk)
-            // BYOLO_WINO1D=1 (round 5 experiment): the 128-channel layers as ONE-DIMENSIONAL F(2,3) along W with the
-            // three filter rows direct -- U[xi][ky][c][n] = sum_kx G[xi][kx] g[ky][kx][c][n], K order (ky, c) per point: 12 of the 16
-            // matrices' worth of space; V at scale 2 (wino_split.hip wino1d_input_kernel), which wshift_u absorbs (+ 1)
-            const char* w1e = getenv("BYOLO_WINO1D");
-            const int wino1d_env = w1e ? atoi(w1e) : 0;
-            const bool oned = wino1d_env && Cs == 128 && l.Cin == 128 && (N % 256) == 0;
-            const int NP = oned ? 4 : 16, KC = oned ? 3 * Cs : Cs;                   // points; K rows per point
-            std::vector<float> U((size_t)NP * KC * N);
-            float g9[9], u16[16];
-            for (int c = 0; c < Cs; ++c)
-                for (int nn = 0; nn < N; ++nn) {
-                    for (int tap = 0; tap < 9; ++tap) g9[tap] = w[((size_t)tap * l.Cin + st.c_lo + c) * N + nn];
-                    if (oned) {
-                        static const double G[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
-                        for (int ky = 0; ky < 3; ++ky)
-                            for (int xi = 0; xi < 4; ++xi)
-                                U[((size_t)xi * KC + (size_t)ky * Cs + c) * N + nn] =
-                                    (float)(G[xi][0] * g9[ky * 3 + 0] + G[xi][1] * g9[ky * 3 + 1] + G[xi][2] * g9[ky * 3 + 2]);
-                        continue;
-                    }
-                    wino_weight_transform(g9, u16);
-                    for (int xi = 0; xi < 16; ++xi) U[((size_t)xi * Cs + c) * N + nn] = u16[xi];
-                }
-            Layer& lw = h->layers[st.layer];
-            lw.wino1d = oned;
-            lw.wshift_u.assign((size_t)N, 0);
-            std::vector<float> wsu((size_t)N), mxu((size_t)N, 0.f);
-            for (size_t r = 0; r < (size_t)NP * KC; ++r) {
-                const float* ur = U.data() + r * N;
-                for (int nn = 0; nn < N; ++nn) mxu[nn] = std::max(mxu[nn], std::fabs(ur[nn]));
-            }
-            for (int nn = 0; nn < N; ++nn) {
-                const float mx = mxu[nn];
-                int e = 0;
-                if (mx > 0.f) (void)std::frexp(mx, &e);
-                lw.wshift_u[nn] = mx > 0.f ? std::min(126, std::max(-126, 14 - e)) : 0;
-                wsu[nn] = ldexpf(1.f, lw.wshift_u[nn]);
-                if (oned) lw.wshift_u[nn] += 1;                                          // the accumulators also carry V's scale 2
-            }
-            _Float16* d16 = reinterpret_cast<_Float16*>(blob.data() + st.wino_off);
-            const size_t blocks = N / 32;
-            const int cts = KC / 32;
-            for (int xi = 0; xi < NP; ++xi)
-                for (int c = 0; c < KC; ++c) {
-                    const int kk = c & 31, step = kk >> 4, half = (kk >> 3) & 1, e = kk & 7;
-                    const int kt = xi * cts + (c >> 5);
-                    const float* ur = U.data() + ((size_t)xi * KC + c) * N;
-                    for (int nn = 0; nn < N; ++nn) {
-                        const float v = ur[nn] * wsu[nn];
-                        const _Float16 hi = (_Float16)v;
-                        _Float16* d = d16 + (((size_t)kt * blocks + (nn >> 5)) * 4 + step * 2) * 512 + (half * 32 + (nn & 31)) * 8 + e;
-                        d[0] = hi; d[512] = (_Float16)(v - (float)hi);
-                    }
-                }
-        }
-        if (st.wino_ok && h->precision == 0) {                  // U[xi][c][n] = (G g G^T)[xi], each xi packed like a 1x1 conv
-            float* u = blob.data() + st.wino_off;
-            const size_t xi_stride = (size_t)(Cs / 32) * st.Npad * 32;
-            float g9[9], u16[16];
-            for (int c = 0; c < Cs; ++c)
-                for (int nn = 0; nn < N; ++nn) {
-                    for (int tap = 0; tap < 9; ++tap) g9[tap] = w[((size_t)tap * l.Cin + c) * N + nn];
-                    wino_weight_transform(g9, u16);
-                    float* d = u + ((size_t)(c >> 5) * st.Npad + nn) * 32 + (c & 31);
-                    for (int xi = 0; xi < 16; ++xi) d[(size_t)xi * xi_stride] = u16[xi];
-                }
-        }
-    });
-    if (!packed) return fail(h, BYOLO_ERR_NOMEM, "byolo_finalize: out of host memory");
-    for (auto& st : h->steps) {
-        if (!st.is_conv()) continue;
-        const Layer& l = h->layers[st.layer];
-        const int N = l.filters;
-        if (st.mode == STEP_PARTIAL && !st.low) continue;
-        fold_layer(h, l, sc, sf);
-        if (h->precision == 1) fold_split(l, sc, sf);
-        memcpy(blob.data() + l.scale_off, sc.data(), sizeof(float) * N);
-        memcpy(blob.data() + l.shift_off, sf.data(), sizeof(float) * N);
-        if (l.drop_ordinal >= 0) {
-            scale_keep(h, sc);
-            memcpy(blob.data() + l.scalek_off, sc.data(), sizeof(float) * N);
-        }
-        if (h->precision == 1 && st.wino_ok && !l.wshift_u.empty()) {
-            std::vector<float> wsc, wsk;
-            wino_scales(h, l, wsc, wsk);
-            memcpy(blob.data() + l.wscale_off, wsc.data(), sizeof(float) * N);
-            memcpy(blob.data() + l.wscalek_off, wsk.data(), sizeof(float) * N);
-        }
-    }
-    if (h->d_blob && h->blob_floats != off) { HIPCHK(h, hipFree(h->d_blob)); h->d_blob = nullptr; }
-    if (!h->d_blob) HIPCHK(h, hipMalloc((void**)&h->d_blob, sizeof(float) * off));
-    h->blob_floats = off;
-    HIPCHK(h, hipMemcpy(h->d_blob, blob.data(), sizeof(float) * off, hipMemcpyHostToDevice));
-    if (!h->d_ones) {
-        std::vector<float> ones((size_t)maxC, 1.f);
-        HIPCHK(h, hipMalloc((void**)&h->d_ones, sizeof(float) * maxC));
-        HIPCHK(h, hipMalloc((void**)&h->d_zeros, sizeof(float) * maxC));
-        HIPCHK(h, hipMemcpy(h->d_ones, ones.data(), sizeof(float) * maxC, hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemset(h->d_zeros, 0, sizeof(float) * maxC));
-    }
-    h->finalized = true;
-    h->plan.B = -1; h->plan.T = -1; ++h->plan_epoch;            // kernel choices depend on what was packed: plan again
-    return BYOLO_OK;
-}
-extern "C" int32_t byolo_finalize(byolo_t* h) {
-    return guarded(h, "byolo_finalize", [&] { return finalize_impl(h); });
-}
-
-// ------------------------------------------------------------------------------------------------
-// workspace planning (liveness-based first-fit; 288 GB HBM is not a reason to thrash the caches)
-// ------------------------------------------------------------------------------------------------
-// Floats per pixel of a layer's tensor.  A matrix-pipe detection head pads its 3 * (5 + C) or 3 * 2 * (5 + C) channels (21, 42, ..)
-// to a multiple of 4: the epilogue then stores 16-byte vectors like every other convolution (the two padding channels come out
-// as zeros: zero weight columns, zero bias); decode reads with that pitch, byolo_copy_layer_output hands out the dense tensor.
-static int layer_pitch(const Layer& l) { return (l.op == OP_DETECTION && !l.direct) ? (l.C + 3) / 4 * 4 : l.C; }
-
-static int64_t tensor_bytes(const byolo_t* h, int id, int B, int T) {
-    const int n = (int)h->layers.size();
-    if (id >= n) {                                                // auxiliary: one row per IMAGE pixel (stacked: per sample pixel)
-        const AuxTensor& a = h->aux[id - n];
-        return (int64_t)align_up((size_t)((int64_t)B * (a.stacked ? T : 1) * a.H * a.W * a.C) * sizeof(float), 256);
-    }
-    const Layer& l = h->layers[id];
-    const int64_t S = l.stacked ? (int64_t)B * T : B;
-    return (int64_t)align_up((size_t)(S * l.H * l.W * layer_pitch(l)) * sizeof(float), 256);
-}
-
-// rows (M) and K-tiles of one launch -- the same arithmetic as fill_conv
-static void step_geometry(const byolo_t* h, const Step& st, int B, int T, int* M, int* KT) {
-    const Layer& l = h->layers[st.layer];
-    const bool per_image = st.mode == STEP_REP || (st.mode == STEP_PARTIAL && !st.low);
-    const int64_t S = (l.stacked && !per_image) ? (int64_t)B * T : B;
-    *M = (int)(S * (l.H >> (st.low ? 1 : 0)) * (l.W >> (st.low ? 1 : 0)));
-    *KT = l.ksize * l.ksize * ((st.c_hi - st.c_lo) / 32);
-}
-
-static void make_plan(byolo_t* h, int B, int T, bool inject = false) {
-    Plan& p = h->plan;
-    if (p.B == B && p.T == T && h->plan_inject == inject) return;
-    h->plan_inject = inject;
-    const int n = (int)h->layers.size() + (int)h->aux.size();     // tensor ids: layers, then auxiliaries
-    p.B = B; p.T = T; p.off.assign(n, -1);
-    struct Blk { int64_t off, size; };
-    std::vector<Blk> free_list;
-    int64_t end = 0;
-    auto alloc = [&](int64_t sz) -> int64_t {
-        for (size_t i = 0; i < free_list.size(); ++i) {
-            if (free_list[i].size >= sz) {
-                const int64_t o = free_list[i].off;
-                free_list[i].off += sz; free_list[i].size -= sz;
-                if (!free_list[i].size) free_list.erase(free_list.begin() + i);
-                return o;
-            }
-        }
-        if (!free_list.empty() && free_list.back().off + free_list.back().size == end) {   // grow the tail block
-            const int64_t o = free_list.back().off; end = o + sz; free_list.pop_back(); return o;
-        }
-        const int64_t o = end; end += sz; return o;
-    };
-    auto release = [&](int64_t off, int64_t sz) {
-        Blk b{off, sz};
-        auto it = std::lower_bound(free_list.begin(), free_list.end(), b, [](const Blk& x, const Blk& y) { return x.off < y.off; });
-        it = free_list.insert(it, b);
-        if (it + 1 != free_list.end() && it->off + it->size == (it + 1)->off) { it->size += (it + 1)->size; free_list.erase(it + 1); }
-        if (it != free_list.begin() && (it - 1)->off + (it - 1)->size == it->off) { (it - 1)->size += it->size; free_list.erase(it); }
-    };
-    // Back-to-back fusion (conv_igemm.hip fused_tail): a shared-tap 3x3 convolution with exactly 256 output channels (the 8-wave
-    // 128 x 256 tile), followed by a 1x1 convolution / detection head of <= 128 output channels that is the ONLY reader of its
-    // output: the follower runs inside the 3x3 launch from LDS, the 3x3 layer's output tensor is never written.  Decided here,
-    // before the arena is laid out: the fused launch reads the 3x3 layer's INPUT while it writes the FOLLOWER's output, so those
-    // two must not share memory (unfused, the follower's output may take the place of the 3x3 layer's dead input).
-    // Measured at config 4 (round 4, three A/B runs on one box each, gpurun_out/r4f-r4h): the three pairs of the 76x76 head
-    // 2.11 + 0.56 -> 2.60, 2.11 + 0.56 -> 2.59, 2.09 + 0.38 -> 2.32 ms; 342.6 -> 348.3, 344.5 -> 349.9, 347.1 -> 350.4 img/s.
-    // BYOLO_B2B: 0 never, 1 launches of >= 4 rounds of 256 workgroups (default), 2 every eligible pair (tests)
-    p.fuse.assign(h->steps.size(), 0);
-    { const char* be = getenv("BYOLO_B2B");
-      const int b2b = be ? atoi(be) : 1;
-      for (size_t si = 0; b2b && h->precision == 1 && !inject && !h->cfg.keep_all_outputs && si + 1 < h->steps.size(); ++si) {
-          const Step& s = h->steps[si];
-          const Layer& l = h->layers[s.layer];
-          if (!(s.is_conv() && s.kx3 && s.mode == STEP_NORMAL && l.op == OP_CONV && !l.direct && l.filters == 256 && s.Npad == 256 && l.fused_residual < 0)) continue;
-          int M, KT; step_geometry(h, s, B, T, &M, &KT);
-          if (b2b < 2 && (int64_t)((M + 127) / 128) < 4 * 256) continue;
-          if (l.wino1d && 2.0 * M * l.filters * 9.0 * l.Cin >= 200e9) continue;   // (BYOLO_WINO1D experiment: the unfused 1-D Winograd launch instead)
-          const Step& s2 = h->steps[si + 1];
-          const Layer& l2 = h->layers[s2.layer];
-          const int out_t = s.out_tensor;
-          if (s2.is_conv() && s2.mode == STEP_NORMAL && s2.p1 && !l2.direct && l2.ksize == 1 && l2.stride == 1 && s2.in.n == 1 &&
-              s2.in.s[0].layer == out_t && !s2.in.s[0].tile && s2.in.s[0].sh == 0 && s2.in.s[0].C == 256 && s2.c_lo == 0 && s2.c_hi == 256 &&
-              l2.fused_residual < 0 && s2.Npad <= 128 && (layer_pitch(l2) % 4) == 0 && l2.H == l.H && l2.W == l.W && l2.stacked == l.stacked &&
-              h->last_use[out_t] == (int)si + 1)
-              p.fuse[si] = 1;
-      }
-    }
-    for (int si = 0; si < (int)h->steps.size(); ++si) {
-        const Layer& l = h->layers[h->steps[si].layer];
-        const int t = h->steps[si].out_tensor;
-        if (!(si > 0 && p.fuse[si - 1])) p.off[t] = alloc(tensor_bytes(h, t, B, T));      // (a fused follower's output exists since the step before)
-        if (p.fuse[si]) { const int t2 = h->steps[si + 1].out_tensor; p.off[t2] = alloc(tensor_bytes(h, t2, B, T)); }
-        if (h->cfg.keep_all_outputs) continue;
-        for (int k = 0; k < n; ++k)
-            if (p.off[k] >= 0 && h->last_use[k] == si) release(p.off[k], tensor_bytes(h, k, B, T));
-        if (h->last_use[t] < 0 && l.op != OP_DETECTION) release(p.off[t], tensor_bytes(h, t, B, T));   // dead output
-    }
-    // detection raw outputs must survive until their decode (same step) -> they are released one step
-    // late by construction (last_use == -1 handled below): keep them simple: never reuse det outputs.
-    p.arena = align_up((size_t)end, 256);
-    p.boxes_off = p.arena;
-    size_t o = p.boxes_off + align_up((size_t)B * h->n_boxes * h->row_len * sizeof(float), 256);
-    p.nms_off = o; o += align_up(nms_workspace_bytes(B, h->n_boxes), 256);
-    p.stats_off = o; o += align_up((size_t)1024 * 2 * h->maxC * sizeof(double) + 2 * h->maxC * sizeof(float), 256);
-    p.img_split_off = o; if (h->img_split) o += align_up((size_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c * sizeof(float), 256);
-    // launch geometry per step: tile configuration and the split-K of the last partial round (shape-only)
-    p.split.assign(h->steps.size(), ConvSplit{0, 0, 0, 1});
-    p.tile.assign(h->steps.size(), 0);
-    size_t slab = 0;
-    for (size_t si = 0; si < h->steps.size(); ++si) {
-        const Step& s = h->steps[si];
-        const Layer& l = h->layers[s.layer];
-        if (!s.is_conv() || l.direct) continue;
-        int M, KT; step_geometry(h, s, B, T, &M, &KT);
-        // Grid fill: a 128x128 tiling of a small-M layer (deep backbone layers at small batch) leaves CUs
-        // idle; the 128x64 tile doubles the block count (the packed weight layout [K/32][Npad][32] does not
-        // depend on BN when N % 128 == 0).
-        int tile = s.tile;
-        if (tile == TILE_128x128 && (l.filters % 128) == 0 && (int64_t)((M + 127) / 128) * (l.filters / 128) < 512) tile = TILE_128x64;
-        // split precision: only the shared-tap 3x3 kernel has a 128-wide tile (the plain kernel would need scratch memory there);
-        // the 1x1 / stride-2 / concat convolutions run on the 64-wide tile, which also keeps twice the workgroups in flight per
-        // byte streamed for the HBM-latency-bound 76x76 head layers (measured at config 4: 0.83 -> 0.56, 0.77 -> 0.67 ms)
-        if (h->precision == 1) tile = conv_split_tile(tile, s.kx3 || s.p1);
-        else if (inject && tile == TILE_128x128) tile = TILE_128x64;      // the fp32 128-wide build has no mask-injection path (conv_igemm.hip)
-        // shared-tap 3x3 with cout % 256 == 0 and enough rows to fill the chip: ONE 8-wave workgroup owns all 256 output channels of
-        // its 128 pixels, so an activation row is fetched and staged once per 256 columns instead of once per 128.  Measured at
-        // config 4 (round 4, gpurun_out/r4b_*): the three 76x76 head convolutions 2.13 -> 2.22 ms each (-4 %): with ONE workgroup per
-        // CU the epilogues of all eight waves coincide and nothing multiplies meanwhile, where two independent 4-wave workgroups
-        // overlap one's epilogue with the other's K loop -- so it is NOT the default.
-        // BYOLO_KX3_WIDE: 0 never (default), 1 launches of >= 4 rounds of 256 workgroups, 2 every eligible launch (tests)
-        const char* kwe = getenv("BYOLO_KX3_WIDE");           // (read per plan, like BYOLO_WINO_SPLIT: tests and fuzzers flip it inside one process)
-        const int kx3_wide = kwe ? atoi(kwe) : 0;
-        if (h->precision == 1 && s.kx3 && (s.Npad % 256) == 0 && kx3_wide && (l.filters % 128) == 0 &&
-            (kx3_wide >= 2 ? (tile == TILE_128x128 || tile == TILE_128x64)       // (forced: also where the grid-fill rule above went narrow)
-                           : (tile == TILE_128x128 && (int64_t)((M + 127) / 128) * (s.Npad / 256) >= 4 * 256)))
-            tile = TILE_128x256;
-        if (p.fuse[si]) tile = TILE_128x256;                  // (decided before the arena was laid out, above)
-        p.tile[si] = tile;
-        // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
-        const bool sp = h->precision == 1, kx3 = sp && s.kx3;
-        p.split[si] = conv_plan_split(M, s.Npad, kx3 ? KT / 3 : KT, tile, sp ? (kx3 ? 1.2 : 0.4) : 1.0);
-        if (s.low) p.split[si] = ConvSplit{((M + 127) / 128) * (s.Npad / conv_tile_bn(tile)), 0, 0, 1};      // whole tiles: the accumulation order of a STEP_MAIN tile
-        if (tile == TILE_128x256) p.split[si] = ConvSplit{((M + 127) / 128) * (s.Npad / 256), 0, 0, 1};      // whole tiles only: its workgroups walk the tile list (conv_igemm.hip WALK); a follower needs a finished tile
-        slab = std::max(slab, conv_split_slab_bytes(p.split[si], tile));
-    }
-    // Winograd F(2x2,3x3) for the large 3x3 / stride-1 convolutions (winograd.hip): samples per chunk such that
-    // the transformed input V (4x the input) and the GEMM result M (4x the output) of a chunk fit the scratch.
-    // BYOLO_WINOGRAD=0 keeps every convolution direct.
-    p.wino.assign(h->steps.size(), WinoPlan{});
-    size_t wino_scratch = 0;
-    // Split precision: Winograd F(2x2,3x3) in split arithmetic (wino_split.hip) for the LARGE 3x3 / stride-1 convolutions -- the
-    // nine 3x3 convolutions of the heads at T >= ~10 samples.  The transform streams 5x the input through HBM, so small layers keep
-    // the shared-tap direct kernel.  BYOLO_WINO_SPLIT: 0 never, 1 layers of >= BYOLO_WINO_SPLIT_MIN_GFLOP (default 200), 2 every
-    // eligible layer (tests); BYOLO_WINO_SPLIT_BM / _BN: 64 | 128 output tiles, 256 | 128 channels per workgroup; BYOLO_WINO_SPLIT_CHUNK_MB: V bytes of a chunk.
-    if (h->precision == 1) {
-        const char* e = getenv("BYOLO_WINO_SPLIT");
-        const int on = e ? atoi(e) : 1;
-        const char* mf = getenv("BYOLO_WINO_SPLIT_MIN_GFLOP");
-        const char* cb = getenv("BYOLO_WINO_SPLIT_CHUNK_MB");
-        const char* be = getenv("BYOLO_WINO_SPLIT_BM");
-        const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 200.0) * 1e9, budget = (cb ? atof(cb) : 1500.0) * 1e6;
-        const int bm = be && atoi(be) == 128 ? 128 : 64;
-        const char* bne = getenv("BYOLO_WINO_SPLIT_BN");
-        const int bn_pref = bne ? atoi(bne) : 256;             // measured at config 4: 1.29 -> 1.19 ms per fused launch
-        for (size_t si = 0; on && si < h->steps.size(); ++si) {
-            const Step& s = h->steps[si];
-            const Layer& l = h->layers[s.layer];
-            if (!s.wino_ok || !s.kx3 || s.mode != STEP_NORMAL || l.wshift_u.empty() || l.fused_residual >= 0 || p.fuse[si]) continue;
-            int M, KT; step_geometry(h, s, B, T, &M, &KT);
-            if (2.0 * M * l.filters * 9.0 * l.Cin < min_flops) continue;
-            // per transform point the K loop is only Cin / 32 tiles long, and the fold + the 5x input stream are paid per point:
-            // measured at config 4 (direct -> transform + fused): Cin 512 2.00 -> 0.19 + 1.36 ms, 256 2.02 -> 0.35 + 1.37,
-            // 128 2.15 -> 2 x (0.36 + 0.80) -- the 128-channel layers stay direct (BYOLO_WINO_SPLIT_MIN_C)
-            static const int min_c = [] { const char* e = getenv("BYOLO_WINO_SPLIT_MIN_C"); return e ? atoi(e) : 256; }();
-            if (on < 2 && l.Cin < min_c && !l.wino1d) continue;
-            WinoPlan& w = p.wino[si];
-            w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2; w.bm = bm; w.fused = true;
-            w.bn = (bn_pref == 256 && bm == 64 && (l.filters % 256) == 0) ? 256 : 128;
-            const int S = M / (l.H * l.W);
-            if (l.wino1d) {                                     // one-dimensional form: V [4][chunk * (H + 2) * tw rows][C]
-                w.oned = true; w.th = l.H; w.bm = 64; w.bn = 256;
-                const double per = 4.0 * (l.H + 2) * w.tw * l.Cin * 4.0;
-                const int nch = std::max(1, (int)std::ceil(S * per / budget));
-                w.chunk = (S + nch - 1) / nch;
-                const size_t R_pad = align_up((size_t)w.chunk * (l.H + 2) * w.tw, 128);
-                w.v_bytes = align_up((size_t)4 * R_pad * l.Cin * 4, 256);
-                if (w.v_bytes > CONV_MAX_SRC_BYTES) { w = WinoPlan{}; continue; }
-                wino_scratch = std::max(wino_scratch, w.v_bytes);
-                continue;
-            }
-            const double per_sample = 16.0 * w.th * w.tw * l.Cin * 4.0;
-            const int nchunks = std::max(1, (int)std::ceil(S * per_sample / budget));          // equal chunks
-            w.chunk = (S + nchunks - 1) / nchunks;
-            // BYOLO_WINO_SPLIT_ROUNDS=k (experiment): chunks whose fused launch is k whole rounds of resident workgroups, so that a
-            // chunk's V (<= ~140 MB per round) is still in the Infinity Cache when the GEMM reads it
-            static const int rounds = [] { const char* e = getenv("BYOLO_WINO_SPLIT_ROUNDS"); return e ? atoi(e) : 0; }();
-            if (rounds > 0) {
-                const int slots = (w.bn == 256 ? 256 : 512), n_tiles = l.filters / w.bn;
-                const int64_t row_tiles = (int64_t)rounds * slots / n_tiles;                // of w.bm rows each
-                const int tt = w.th * w.tw;
-                int c = (int)((row_tiles * w.bm) / tt);                                     // whole samples that fit
-                while (c > 1 && (int64_t)align_up((size_t)c * tt, 128) / w.bm * n_tiles > (int64_t)rounds * slots) --c;
-                w.chunk = std::max(1, std::min(S, c));
-            }
-            const size_t P_pad = align_up((size_t)w.chunk * w.th * w.tw, 128);
-            w.v_bytes = align_up((size_t)16 * P_pad * l.Cin * 4, 256);
-            if (w.v_bytes > CONV_MAX_SRC_BYTES) { w = WinoPlan{}; continue; }                 // 32-bit buffer offsets
-            w.m_bytes = 0;
-            wino_scratch = std::max(wino_scratch, w.v_bytes);
-        }
-    }
-    { const char* e = getenv("BYOLO_WINOGRAD");
-      const int on = (h->precision == 1 || inject) ? 0 : (e ? atoi(e) : 1);   // split precision: direct convolutions only (memory-bound transforms do not pay there); injected masks: conv_igemm's epilogue reads them
-      const char* mf = getenv("BYOLO_WINO_MIN_GFLOP");                     // tuning knob: smallest layer (direct GFLOP) to transform
-      // (measured at config 4: 100 -> 144.97, 20 -> 147.35, 5 -> 147.32 img/s; at config 2 (416x416, 8 images) the 52x52
-      //  layers are 12.8 GFLOP: 20 -> 1375, 10 -> 1506, 5 -> 1504 img/s.  Default 10.)
-      const char* bm = getenv("BYOLO_WINO_CHUNK_MB");                      // tuning knob: V + M bytes of one chunk
-      // (chunk budget measured at config 4: 2600 MB 177.6, 600 MB 179.4, 300 MB 150.6 img/s -- below ~500 MB the fused
-      //  kernel's slots run out of row tiles; 800 MB keeps the scratch small without costing rounds)
-      const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 10.0) * 1e9, budget = (bm ? atof(bm) : 800.0) * 1e6;   // on == 2: every eligible layer (tests)
-      for (size_t si = 0; on && si < h->steps.size(); ++si) {
-        const Step& s = h->steps[si];
-        const Layer& l = h->layers[s.layer];
-        if (!s.wino_ok) continue;
-        int M, KT; step_geometry(h, s, B, T, &M, &KT);
-        if (2.0 * M * l.filters * 9.0 * l.Cin < min_flops) continue;
-        // The transforms stream 4x the input + 4x the output through HBM (measured 5.2 TB/s); per output pixel the GEMM
-        // saves 5/9 of 2*9*Cin*cout FLOPs.  That pays when Cin*cout/(Cin+cout) is large: measured at config 4
-        // 512x1024 channels (19x19) -33 %, 256x512 (38x38) -24 %, 128x256 (76x76) +6 % -> direct below ~128.
-        static const double min_ratio = [] { const char* e = getenv("BYOLO_WINO_MIN_RATIO"); return e ? atof(e) : 80.0; }();
-        if (on < 2 && (double)l.Cin * l.filters / (l.Cin + l.filters) < min_ratio) continue;
-        WinoPlan& w = p.wino[si];
-        w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2;
-        const int S = M / (l.H * l.W);
-        const double per_sample = 16.0 * w.th * w.tw * (l.Cin + l.filters) * 4.0;
-        const int nchunks = (int)std::ceil(S * per_sample / budget);                 // equal chunks
-        w.chunk = (S + nchunks - 1) / nchunks;
-        // Fused kernel (wino_fused.hip; no M): its work unit is a row tile of 128 output tiles through all 16 transform
-        // points, dealt out statically to 512 / (cout/64) slots -- pick the chunk size (samples) whose row-tile count
-        // wastes the fewest slot rounds, and use the fused kernel only when every slot gets >= 3 row tiles.
-        const char* fe = getenv("BYOLO_WINO_FUSED");
-        const int fused_mode = fe ? atoi(fe) : 1;                              // 0 never, 2 always (tests); read per plan
-        if (fused_mode && wino_fused_ok(l.Cin, l.filters)) {
-            const int slots = 512 / (l.filters / 64), tt = w.th * w.tw;
-            const int max_c = (int)std::max(1.0, std::min((double)S, std::floor(budget / (16.0 * tt * l.Cin * 4.0))));
-            auto rt = [&](int c) { return (c * tt + 127) / 128; };
-            auto rounds = [&](int c) { return (rt(c) + slots - 1) / slots; };
-            int best_c = 0; double best_cost = 1e30;
-            for (int c = std::max(1, max_c / 6); c <= max_c; ++c) {
-                const int full = S / c, last = S % c;
-                // cost in slot rounds (+ a little per chunk for the launches and the pipeline fill)
-                const double cost = full * (rounds(c) + 0.15) + (last ? rounds(last) + 0.15 : 0.0);
-                if (cost < best_cost - 1e-9 || (std::fabs(cost - best_cost) < 1e-9 && c > best_c)) { best_cost = cost; best_c = c; }
-            }
-            if (best_c > 0 && (fused_mode >= 2 || rt(best_c) / slots >= 3)) { w.fused = true; w.chunk = best_c; }
-        }
-        const size_t P_pad = align_up((size_t)w.chunk * w.th * w.tw, 128);
-        w.v_bytes = align_up((size_t)16 * P_pad * l.Cin * 4, 256);
-        w.m_bytes = w.fused ? 0 : align_up((size_t)16 * P_pad * l.filters * 4, 256);
-        wino_scratch = std::max(wino_scratch, w.v_bytes + w.m_bytes);
-        const int rows = (int)(16 * P_pad);
-        p.split[si] = conv_plan_split(rows, s.Npad, l.Cin / 32, s.tile);
-        p.tile[si] = s.tile;
-        slab = std::max(slab, conv_split_slab_bytes(p.split[si], s.tile));
-      }
-    }
-    // Row-streaming launch for the 1x1 / stride-1 convolutions over one plain source (gemm_stream.hip): the 1x1
-    // convolutions of the heads, the concat convolutions' stacked half (STEP_MAIN) and the detection heads.
-    // BYOLO_STREAM1X1=0 keeps them on conv_igemm (A/B), =2 takes it for every shape the kernel can express (tests).
-    p.stream1x1.assign(h->steps.size(), 0);
-    { const char* e = getenv("BYOLO_STREAM1X1");
-      const bool on = h->precision == 0 && !inject && (!e || atoi(e) != 0), force = e && atoi(e) >= 2;
-      for (size_t si = 0; on && si < h->steps.size(); ++si) {
-        const Step& s = h->steps[si];
-        const Layer& l = h->layers[s.layer];
-        if (!s.is_conv() || l.direct || l.ksize != 1 || l.stride != 1) continue;
-        if (s.mode != STEP_NORMAL && s.mode != STEP_MAIN) continue;
-        if (s.in.n != 1 || s.in.s[0].sh || s.in.s[0].tile || s.in.s[0].layer < 0 || l.fused_residual >= 0) continue;
-        if (l.op == OP_CONV && (l.filters % 4)) continue;
-        int M, KT; step_geometry(h, s, B, T, &M, &KT);
-        const int bn = conv1x1_stream_tile(M, s.c_hi - s.c_lo, l.filters, force);
-        if (bn && (l.filters <= 64 ? s.Npad == 64 : s.Npad == l.filters)) p.stream1x1[si] = bn;
-      }
-    }
-    p.wino_off = o; o += align_up(wino_scratch, 256);
-    p.slab_off = o; p.slab_bytes = slab; o += align_up(slab, 256);
-    p.cnt_bytes = h->steps.size() * CNT_PER_STEP * sizeof(unsigned);
-    p.cnt_off = o; o += align_up(p.cnt_bytes, 256);
-    p.total = o;
-}
-
-extern "C" int32_t byolo_num_layers(const byolo_t* h) { return h ? (int32_t)h->layers.size() : BYOLO_ERR_ARG; }
-
-extern "C" int32_t byolo_num_boxes(const byolo_t* h, int64_t* n, int32_t* d) {
-    if (!h) return BYOLO_ERR_ARG;
-    if (n) *n = h->n_boxes;
-    if (d) *d = h->row_len;
-    return BYOLO_OK;
-}
-
-// images one launch sequence may carry at this T (byolo_max_images): 32-bit source offsets and pixel counts
-static int64_t piece_cap(const byolo_t* h, int32_t T) {
-    uint64_t per_image = (uint64_t)h->cfg.img_h * h->cfg.img_w * h->cfg.img_c * 4;      // bytes per image of the largest tensor
-    int64_t rows = 0;                                                                  // pixels per image of the largest layer
-    for (const auto& l : h->layers) {
-        const uint64_t s = l.stacked ? (uint64_t)T : 1;
-        if (l.materialized) per_image = std::max(per_image, s * l.H * l.W * l.C * 4);
-        rows = std::max<int64_t>(rows, (int64_t)s * l.H * l.W);
-    }
-    const uint64_t by_bytes = CONV_MAX_SRC_BYTES / per_image, by_rows = (((uint64_t)1 << 31) - 1) / (uint64_t)rows;
-    return (int64_t)std::min<uint64_t>(std::min(by_bytes, by_rows), 1 << 20);
-}
-
-static int32_t check_run(byolo_t* h, int32_t B, int32_t T, const char* what, bool need_device = true) {
-    if (!h) return fail(nullptr, BYOLO_ERR_ARG, "%s: null handle", what);
-    if (need_device && !h->finalized) return fail(h, BYOLO_ERR_STATE, "%s: call byolo_finalize first", what);
-    if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
-    if (B < 1 || T < 1) return fail(h, BYOLO_ERR_ARG, "%s: B and T must be >= 1", what);
-    for (const auto& l : h->layers) {
-        const int64_t S = l.stacked ? (int64_t)B * T : B;
-        if (S * l.H * l.W >= (int64_t)1 << 31) return fail(h, BYOLO_ERR_ARG, "%s: B*T*h*w exceeds 2^31 pixels", what);
-        // the convolution addresses its sources with 32-bit byte offsets (buffer loads)
-        if (l.materialized && (uint64_t)S * l.H * l.W * l.C * 4 > CONV_MAX_SRC_BYTES)
-            return fail(h, BYOLO_ERR_ARG, "%s: a [%lld,%d,%d,%d] activation exceeds the 3 GiB a convolution source may span; "
-                        "split the call into smaller image batches", what, (long long)S, l.H, l.W, l.C);
-    }
-    if ((uint64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c * 4 > CONV_MAX_SRC_BYTES)
-        return fail(h, BYOLO_ERR_ARG, "%s: the image batch exceeds 3 GiB; split the call", what);
-    return BYOLO_OK;
-}
-
-static int32_t workspace_bytes_impl(byolo_t* h, int32_t B, int32_t T, size_t* out) {
-    if (h && B >= 1 && T >= 1) {                       // a batch beyond byolo_max_images runs in pieces (byolo_forward): the largest piece's arena
-        if (!h->lowered) { int32_t rc = lower(h); if (rc) return rc; }
-        const int64_t cap = piece_cap(h, T);
-        if (cap >= 1 && B > cap) {
-            if (!out) return fail(h, BYOLO_ERR_ARG, "byolo_workspace_bytes: null out");
-            size_t a = 0, b = 0;
-            int32_t rc = byolo_workspace_bytes(h, (int32_t)cap, T, &a); if (rc) return rc;
-            if (B % cap) { rc = byolo_workspace_bytes(h, (int32_t)(B % cap), T, &b); if (rc) return rc; }
-            *out = std::max(a, b);
-            return BYOLO_OK;
-        }
-    }
-    int32_t rc = check_run(h, B, T, "byolo_workspace_bytes", false); if (rc) return rc;
-    if (!out) return fail(h, BYOLO_ERR_ARG, "byolo_workspace_bytes: null out");
-    // the plan of a call with injected dropout masks (byolo_forward's d_mask_bits) differs in the fp32 mode (64-wide tiles, other
-    // split-K slabs, no Winograd): the size returned covers BOTH, so a workspace sized here never fails either kind of call
-    // (the plan in effect stays the unmasked one, made ONCE per (B, T): a caller asks for the size before every forward)
-    make_plan(h, B, T, false);
-    if (h->wsm_B != B || h->wsm_T != T || h->wsm_epoch != h->plan_epoch) {
-        const Plan keep = h->plan;
-        h->plan.B = -1;
-        make_plan(h, B, T, true);
-        h->wsm_total = h->plan.total; h->wsm_B = B; h->wsm_T = T; h->wsm_epoch = h->plan_epoch;
-        h->plan = keep; h->plan_inject = false;
-    }
-    *out = std::max(h->plan.total, h->wsm_total);
-    return BYOLO_OK;
-}
-extern "C" int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t* out) {
-    return guarded(h, "byolo_workspace_bytes", [&] { return workspace_bytes_impl(h, B, T, out); });
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward
-// ------------------------------------------------------------------------------------------------
 static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char* ws, int B, int T, ConvParams& p) {
     const Layer& l = h->layers[st.layer];
     memset(&p, 0, sizeof p);
@@ -2410,3 +1499,4 @@ extern "C" uint32_t byolo_crc32c(const void* data, size_t n) {
     while (n--) crc = (crc >> 8) ^ tab[0][(crc ^ *p++) & 0xFF];
     return crc ^ 0xFFFFFFFFu;
 }
+

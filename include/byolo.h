@@ -150,6 +150,16 @@ BYOLO_API int32_t byolo_finalize(byolo_t* h);
 BYOLO_API int32_t byolo_num_layers(const byolo_t* h);
 BYOLO_API int32_t byolo_num_boxes(const byolo_t* h, int64_t* n_boxes, int32_t* row_len);   /* N, D of concat_bbox */
 BYOLO_API int32_t byolo_workspace_bytes(byolo_t* h, int32_t B, int32_t T, size_t* out);
+/* Introspection of the workspace plan of a (B, T) call, host only (no device, no byolo_finalize needed) -- what tests/test_planner.py
+ * checks on the CPU: no tensor is written while another tensor that shares its memory is still to be read.
+ *   byolo_plan_num     makes the plan (inject != 0: the plan of a call with d_mask_bits); steps, tensors, arena size;
+ *   byolo_plan_step    the tensor step `step` writes; fuses_next = 1 when step + 1 runs INSIDE this step's launch (its output is
+ *                      written during this step, this step's own output tensor never exists); the tensors the step's launch reads;
+ *   byolo_plan_tensor  offset in the workspace (< 0: none in this plan), size, and whether anything reads it after the last step
+ *                      (a detection layer's raw output: the decode launch; every layer under keep_all_outputs). */
+BYOLO_API int32_t byolo_plan_num(byolo_t* h, int32_t B, int32_t T, int32_t inject, int32_t* n_steps, int32_t* n_tensors, int64_t* arena_bytes);
+BYOLO_API int32_t byolo_plan_step(byolo_t* h, int32_t step, int32_t* out_tensor, int32_t* fuses_next, int32_t reads[8], int32_t* n_reads);
+BYOLO_API int32_t byolo_plan_tensor(byolo_t* h, int32_t tensor, int64_t* offset, int64_t* bytes, int32_t* read_after_the_steps);
 /* d_img [B,H,W,C] NHWC fp32.  T = MC samples (1 for graphs without stack layers).
  * Outputs (any may be NULL to skip that stage's export):
  *   d_boxes   [B,N,D]               pre-NMS rows in concat_bbox order (inference_*.py concat_bbox)
