@@ -520,7 +520,7 @@ def main():
         eng.set_profile_depth(n_prof * n_sub)       # every profiled step's launch records stay readable until after the run
     eng.set_profiling(2 if prof else 0)
     acc = {}                      # variant -> [algorithmic flops, ms, launches, executed flops, useful flops, algorithmic read bytes, algorithmic write bytes]
-    acc_cn = {}                   # variant -> [sum C*N, sum C, sum N] over its launches (the convolution's own byte count)
+    acc_cn = {}                   # Winograd variants -> bytes of the CONVOLUTIONS their launches stand for (input + weights + output)
     per_launch = {}
     stage = {"backbone": 0.0, "heads": 0.0, "decode": 0.0, "sort_nms": 0.0}
     if pg:
@@ -553,8 +553,9 @@ def main():
                     n2 = (s["flops"] - 2.0 * s["M"] * s["N"] * s["K"]) / (2.0 * s["M"] * s["N"])      # the follower's output channels
                     s = dict(s, flops_executed=s["flops"])
                 a[0] += s["flops"]; a[1] += s["ms"]; a[2] += 1; a[3] += s["flops_executed"]
-                cn = acc_cn.setdefault(s["variant"], [0.0, 0.0, 0.0])
-                cn[0] += float(s["K"]) * s["N"]; cn[1] += s["K"]; cn[2] += s["N"]
+                if s["variant"] in (130, 140):      # the convolution's OWN bytes of a Winograd launch: input + 3x3 weights + output, once each
+                    px = s["flops"] / (18.0 * s["K"] * s["N"])
+                    acc_cn[s["variant"]] = acc_cn.get(s["variant"], 0.0) + 4.0 * (px * s["K"] + 9.0 * s["K"] * s["N"] + px * s["N"])
                 a[4] += s["flops"] / (1.5 if s["variant"] == 141 else 2.25) if wino else s["flops"]
                 # algorithmic bytes of the launch: A operand once + result once + weights once
                 # (a shared-tap 3x3 launch reads its input once: M * K / 9 elements, not the im2col matrix)
@@ -667,8 +668,7 @@ def main():
             # kernel must read -- which flatters the layer: V is a by-product of the method, written and re-read on top of the input)
             conv_bytes = None
             if dom in (130, 140):
-                px = f / n / (18.0 * acc_cn[dom][0] / n)              # pixels = direct FLOPs / (2 * 9 * C * N), averaged over the launches
-                conv_bytes = 4.0 * (px * acc_cn[dom][1] / n + 9.0 * acc_cn[dom][0] / n + px * acc_cn[dom][2] / n)
+                conv_bytes = acc_cn[dom] / n                          # (pixels of a launch = its direct FLOPs / (2 * 9 * C * N))
             tr_in = None                                              # the separate input-transform launch's measured traffic, if profiled
             ipath = os.path.join(REPO, "profiles", "traffic_cfg%d_wino_input.json" % args.config)
             if dom == 140 and os.path.exists(ipath) and traffic:
