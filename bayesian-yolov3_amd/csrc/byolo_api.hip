@@ -1,7 +1,8 @@
 // byolo_api.hip -- implementation of include/byolo.h: graph builder (mirror of
-// lib_yolo/model.py ModelBuilder), parameter store, BN folding + weight packing, liveness-based
-// workspace planner and the forward driver that lowers the reference's layer list to fused
-// gfx950 kernel launches on the caller's stream.
+// lib_yolo/model.py ModelBuilder), parameter store, lowering of the reference's layer list to steps,
+// and the forward driver that turns the steps into fused gfx950 kernel launches on the caller's stream.
+// (BN folding + weight packing: byolo_pack.hip; the liveness-based workspace planner: byolo_plan.hip;
+//  the handle and what the three share: byolo_internal.h.)
 //
 // Lowering rules (what the TF graph of lib_yolo/yolov3.py:518-628 becomes):
 //   conv -> [dropout] -> bn -> leaky                      one conv_igemm launch (fused epilogue)

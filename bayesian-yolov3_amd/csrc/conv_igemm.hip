@@ -77,7 +77,7 @@ __device__ __forceinline__ void finish_tile(const ConvParams& p, float* smem, f3
                                             const uint32_t tile_m, const uint32_t tile_n, const TileShare sh) {
     constexpr int NT = 64 * WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
     // injected dropout masks (ConvParams::mask_bits): every build but the fp32 128 x 128 tile, which sits at exactly 256
-    // registers and would spill -- byolo_api.hip plans the 64-wide tile for such a call in the fp32 mode
+    // registers and would spill -- byolo_plan.hip plans the 64-wide tile for such a call in the fp32 mode
     constexpr bool INJECT = SPLIT || BN < 128;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_igemm_kernel(const ConvP
     //  (otherwise) blocks [0, full_tiles): whole tiles, each XCD a contiguous range of them; blocks beyond: K slices of
     //    the remaining tiles -- slices of one tile on one XCD (block id % 8), neighbours in dispatch order:
     //    id = full_tiles + ((tile_local / 8) * ksplit + slice) * 8 + tile_local % 8
-    if constexpr (KX3 == 1 && BN == 256) {        // the 8-wave tile: whole tiles only (byolo_api.hip make_plan), walked by the workgroup itself
+    if constexpr (KX3 == 1 && BN == 256) {        // the 8-wave tile: whole tiles only (byolo_plan.hip make_plan), walked by the workgroup itself
         if ((int)blockIdx.x < p.full_tiles)
             conv_tile_kx3<BM, BN, WM, WN, true>(p, smem, (int)blockIdx.x, 0, p.KT, TileShare{-1, 0, 1, 0, 0, 0});
         return;

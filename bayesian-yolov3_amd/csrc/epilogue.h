@@ -76,7 +76,7 @@ __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
 }
 
 // Split-f16 storage of 4 consecutive channels (mfma_pipe.h): 16 bytes = [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3],
-// hi = RNE_f16(x), lo = RNE_f16(x - hi).  x is in the tensor's pre-scaled domain (byolo_api.hip folds the powers of two
+// hi = RNE_f16(x), lo = RNE_f16(x - hi).  x is in the tensor's pre-scaled domain (byolo_pack.hip folds the powers of two
 // into scale / shift); |x| >= 65520 overflows to infinity like any fp16.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // (hi as a packed pair by v_cvt_pk_f16_f32; lo = RNE_f16(x - hi) by v_fma_mix{lo,hi}_f16: fma(hi read as an f16 source, -1.0, x)

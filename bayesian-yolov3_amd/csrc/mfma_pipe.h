@@ -171,7 +171,7 @@ __device__ __forceinline__ void tile_body(const BT& t, f32x4 (&af0)[BT::TM], f32
 // Split-f16 operands ("hi + lo"): the same pipeline on v_mfma_f32_32x32x16_f16, three products per fp32 product.
 //
 // Every activation / weight element is stored as TWO fp16 values, hi = RNE_f16(x), lo = RNE_f16(x - hi) (x = hi + lo to
-// ~23 significant bits; tensors are pre-scaled by powers of two -- byolo_api.hip -- so that lo stays a normal fp16 for
+// ~23 significant bits; tensors are pre-scaled by powers of two -- byolo_pack.hip -- so that lo stays a normal fp16 for
 // every value that matters).  The product
 //     x * w  ~=  hi_x hi_w + hi_x lo_w + lo_x hi_w        (lo_x lo_w < 2^-22 |x w| is dropped)
 // runs as three MFMAs into ONE fp32 accumulator: products of fp16 values are exact in fp32 and the instruction sums its

@@ -94,7 +94,75 @@ __global__ __launch_bounds__(256) void wino_split_input_kernel(const WinoParams 
     }
 }
 
+// The same transform, TWO horizontally adjacent output tiles per thread (round 5): their 4x4 patches share two of four columns, so a
+// thread loads 4 x 6 pixels instead of 2 x 16 -- the one-tile kernel re-read the input 2.5x through the fabric (measured, FETCH_SIZE:
+// 0.68 GB per launch against 0.27 GB of input; every pixel belongs to four patches and the L2 caught a third of the repeats).  Same
+// arithmetic per tile, operation for operation: V is bit-identical.  thread = (sample, tile row, tile PAIR, 4 channels); the rows that
+// pad V to P_pad are zeroed by the threads behind the last pair.
+__global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams p, const FastDiv d_twp, const FastDiv d_ttp, const int twp) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t c4n = (uint32_t)p.C >> 2;
+    const uint32_t q = fdiv(gid, p.d_c4), c4 = gid - q * c4n;
+    const size_t xi_stride = (size_t)p.P_pad * p.C;
+    const uint32_t ttp = (uint32_t)(p.th * twp), n_pairs = (uint32_t)(p.P / (p.th * p.tw)) * ttp;
+    if (q >= n_pairs) {
+        const uint32_t t = (uint32_t)p.P + (q - n_pairs);
+        if (t >= (uint32_t)p.P_pad) return;
+        float* v = p.v + (size_t)t * p.C + c4 * 4;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(v + (size_t)k * xi_stride) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const uint32_t s = fdiv(q, d_ttp), r = q - s * ttp;
+    const uint32_t ty = fdiv(r, d_twp), txp = r - ty * (uint32_t)twp;
+    const uint32_t tx0 = 2u * txp;
+    const bool two = tx0 + 1u < (uint32_t)p.tw;
+    const float* img = p.x + ((size_t)(p.s0 + s) * p.H * p.W) * p.C + c4 * 4;
+    const int y0 = 2 * (int)ty - 1, x0 = 2 * (int)tx0 - 1;
+    f32x4 u[4][6];                                   // B^T d of the six patch columns x0 .. x0 + 5
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 d[4];
+        const int x = x0 + j;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = y0 + i;
+            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && (j < 4 || two);
+            const f32x4 raw = ok ? *reinterpret_cast<const f32x4*>(img + ((size_t)y * p.W + x) * p.C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[i] = epi::split_decode4(raw);
+        }
+        u[0][j] = d[0] - d[2];
+        u[1][j] = d[1] + d[2];
+        u[2][j] = d[2] - d[1];
+        u[3][j] = d[1] - d[3];
+    }
+    const float m = p.vmul;
+    const uint32_t t0 = ((s * (uint32_t)p.th + ty) * (uint32_t)p.tw + tx0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !two) break;
+        float* v = p.v + (size_t)(t0 + k) * p.C + c4 * 4;
+        const int o = 2 * k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 0) * xi_stride) = epi::split_encode4((u[i][o + 0] - u[i][o + 2]) * m);
+            *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 1) * xi_stride) = epi::split_encode4((u[i][o + 1] + u[i][o + 2]) * m);
+            *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 2) * xi_stride) = epi::split_encode4((u[i][o + 2] - u[i][o + 1]) * m);
+            *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 3) * xi_stride) = epi::split_encode4((u[i][o + 1] - u[i][o + 3]) * m);
+        }
+    }
+}
+
 hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st) {
+    static const int pair = [] { const char* e = getenv("BYOLO_WINO_IN_PAIR"); return e ? atoi(e) : 1; }();
+    if (pair) {
+        const int twp = (p.tw + 1) / 2;
+        const uint64_t rows = (uint64_t)(p.P / (p.th * p.tw)) * p.th * twp + (uint64_t)(p.P_pad - p.P);
+        const uint64_t total = rows * (uint64_t)(p.C >> 2);
+        hipLaunchKernelGGL(wino_split_input2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p,
+                           make_fastdiv((uint32_t)twp), make_fastdiv((uint32_t)(p.th * twp)), twp);
+        return hipGetLastError();
+    }
     const uint64_t total = (uint64_t)p.P_pad * (p.C >> 2);
     hipLaunchKernelGGL(wino_split_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     return hipGetLastError();

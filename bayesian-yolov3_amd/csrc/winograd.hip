@@ -12,7 +12,7 @@
 // with the standard matrices
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
 // The transforms are HBM-bound streaming kernels (V is 4x the input, M 4x the output), so the samples of a
-// layer are processed in chunks whose V and M stay in a bounded scratch region (byolo_api.hip).
+// layer are processed in chunks whose V and M stay in a bounded scratch region (byolo_plan.hip).
 // Same arithmetic type (fp32) as the direct path; the rounding differs (tests/: same tolerance).
 #include <hip/hip_runtime.h>
 #include "byolo_kernels.h"

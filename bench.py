@@ -218,6 +218,55 @@ def other_config_leg(num, device, steps=5, warmup=2, oracle="f32"):
     return res
 
 
+def t_shard_leg(device, ranks=8, reps=10):
+    """The T-sharded latency path (config['shard'] = 'T') at the reference's OWN default workload -- ONE
+    1024 x 1920 image per step, T = 50 (inference_epistemic.py:193, :218-221) -- as far as ONE GPU can show it: the device time of
+    rank 0's share of an N-rank job (backbone + its T / N samples of the heads + the per-box sums; then byolo_finish_tshard and the
+    NMS on the summed buffer), next to the one-GPU forward of all T samples.  NOT an N-GPU measurement: the all-reduce of the
+    N * (21 + C) floats (11 MB here) between the two is not in it, and the other ranks are assumed to take as long as rank 0."""
+    import torch
+    from byolo import synth, dist as bdist
+    cfg = dict(CONFIGS[6], nms=0)
+    m = build(cfg, device)
+    eng = m.engine
+    eng.set_async(True)
+    T = cfg["T"]
+    x = torch.from_numpy(synth.synthetic_images(1, cfg["H"], cfg["W"], seed=1234)).to("cuda:%d" % device)
+    t0, t1 = bdist.shard_range(T, 0, ranks)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+
+    def whole():
+        return eng.forward(x, T=T, seed=7, want_boxes=False, want_nms=True)
+
+    def shard():
+        sums = eng.forward(x, T=t1 - t0, seed=7, want_boxes=True, want_nms=False, t_shard=(t0, T))["boxes"]
+        e1.record()
+        rows = eng.finish_tshard(sums, T)
+        return eng.sort_nms(rows, m.obj_idx, m.cls_start_idx)
+    out = {}
+    for name, fn in (("one_gpu_all_samples_ms", whole), ("rank0_of_%d_ms" % ranks, shard)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        tot = part = 0.0
+        for _ in range(reps):
+            e0.record(); fn(); e2.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e2)
+            if fn is shard:
+                part += e0.elapsed_time(e1)
+        out[name] = tot / reps
+        if fn is shard:
+            out["rank0_forward_ms"] = part / reps
+            out["rank0_finish_and_nms_ms"] = (tot - part) / reps
+    N, D = eng.num_boxes()
+    out.update({"workload": "bayesian_yolov3_aleatoric 1024x1920, ONE image, T=%d; rank 0 of %d runs samples [%d, %d)" % (T, ranks, t0, t1),
+                "all_reduce_bytes": N * D * 4 + 8, "device_time_ratio": out["one_gpu_all_samples_ms"] / out["rank0_of_%d_ms" % ranks],
+                "note": "device time of ONE rank's share, measured on one GPU; the all-reduce between forward and finish and the other ranks are not in it"})
+    eng.close()
+    return out
+
+
 def entry_point_leg(cfg, device, n_frames=512, distinct=32, extras=True):
     """The drop-in path a user of the reference runs: `inference_epistemic.inference(config)` (inference_epistemic.py:186-208) over
     a TFRecord shard set generated here -- `distinct` synthetic frames (i.i.d. uniform, quantised to bytes) as PNG
@@ -771,6 +820,11 @@ def main():
                     line["entry_point_reference_default"] = ep6
                 except Exception as e:
                     line["entry_point_reference_default"] = {"img_s": None, "error": repr(e)}
+        if world == 1 and not args.no_other_configs and args.config == 4 and not args.batch and args.scaling == "weak":
+            try:
+                line["t_shard_latency_path"] = t_shard_leg(device)
+            except Exception as e:
+                line["t_shard_latency_path"] = {"error": repr(e)}
         if world == 1 and not args.no_other_configs and not args.batch and args.scaling == "weak":
             try:
                 line["training_side"] = training_side_leg(cfg, device)

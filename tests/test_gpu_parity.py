@@ -628,7 +628,7 @@ def test_one_dimensional_winograd_in_split_arithmetic(variant, monkeypatch, prec
 def test_the_eight_wave_shared_tap_tile_computes_the_same_bits(monkeypatch, precision):
     """BYOLO_KX3_WIDE=2: every shared-tap 3x3 convolution with cout % 256 == 0 on the 128 x 256 tile (8 waves, one workgroup owns
     all 256 output channels of its pixels; conv_igemm_kernel<128,256,1,8,kx3>) -- not the default (measured 4 % slower at config 4,
-    byolo_api.hip make_plan), kept as the starting point of a back-to-back fusion.  An output element is the same chain of MFMAs over
+    byolo_plan.hip make_plan), kept as the starting point of a back-to-back fusion.  An output element is the same chain of MFMAs over
     the same K order whichever wave owns it: the rows must equal the default plan's bit for bit (no split-K at this size)."""
     if precision != "split":
         pytest.skip("the shared-tap kernel belongs to the default precision")
@@ -714,7 +714,7 @@ def test_the_upsampled_concat_half_at_the_sources_resolution_computes_the_same_b
 
 def test_finalize_packs_the_same_weights_on_one_thread_and_on_all(monkeypatch, precision):
     """byolo_finalize packs the weights (hi/lo fragments, Winograd-domain weights in double, per-channel shifts) as independent tasks on
-    the host's cores (byolo_api.hip parallel_tasks, BYOLO_FINALIZE_THREADS): rows, kept indices, raw detection outputs and two
+    the host's cores (byolo_pack.hip parallel_tasks, BYOLO_FINALIZE_THREADS): rows, kept indices, raw detection outputs and two
     backbone taps are the same bits with one worker and with three, Winograd forced onto every eligible layer."""
     monkeypatch.setenv("BYOLO_WINO_SPLIT", "2")
     monkeypatch.setenv("BYOLO_WINOGRAD", "1")
