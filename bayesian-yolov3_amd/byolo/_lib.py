@@ -25,6 +25,15 @@ class Cfg(ctypes.Structure):
                 ("iou_thresh", ctypes.c_float), ("nms_mode", ctypes.c_int32), ("keep_all_outputs", ctypes.c_int32)]
 
 
+class PlanOpts(ctypes.Structure):
+    """include/byolo.h byolo_plan_opts (field for field; tests/test_abi.py compares the two)."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "struct_bytes", "graphs", "serialize_convs", "dedup", "lowmain", "kx3", "p1", "b2b", "kx3_wide", "wino_split", "wino_split_min_c",
+        "wino_split_bn", "wino_split_rounds", "winograd", "wino_fused", "stream1x1", "gemm_stream", "ksplit", "streamk",
+        "plain_epilogue", "wino_split_persist")] + [(n, ctypes.c_float) for n in (
+        "wino_split_min_gflop", "wino_split_chunk_mb", "wino_min_gflop", "wino_chunk_mb", "wino_min_ratio")]
+
+
 _i32, _i64, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 _vp, _cp, _sz, _u64 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64
 _P = ctypes.POINTER
@@ -80,6 +89,9 @@ PROTOTYPES = {
     "byolo_flops": (_i32, [_vp, _i32, _i32, _P(ctypes.c_double)]),
     "byolo_crc32c": (ctypes.c_uint32, [_vp, _sz]),
     "byolo_abi_version": (_i32, []),
+    "byolo_get_plan_opts": (_i32, [_vp, _P(PlanOpts)]),
+    "byolo_set_plan_opts": (_i32, [_vp, _P(PlanOpts)]),
+    "byolo_graph_stats": (_i32, [_vp, _P(_i32), _P(_i64), _P(_i64), _P(_i64)]),
     "byolo_plan_num": (_i32, [_vp, _i32, _i32, _i32, _P(_i32), _P(_i32), _P(_i64)]),
     "byolo_plan_step": (_i32, [_vp, _i32, _P(_i32), _P(_i32), _P(_i32), _P(_i32)]),
     "byolo_plan_tensor": (_i32, [_vp, _i32, _P(_i64), _P(_i64), _P(_i32)]),

@@ -52,6 +52,35 @@ class Engine:
         """Why finalize() chose the fp32 mode although split-f16 was asked for ('' if it did not)."""
         return lib.byolo_precision_note(self._h).decode()
 
+    # ---- the plan of this handle (include/byolo.h byolo_plan_opts) --------------------------------------------
+    def plan_opts(self):
+        """The handle's plan options as a dict (defaults + the BYOLO_* environment at creation, or what set_plan_opts left)."""
+        o = _lib.PlanOpts()
+        check(self._h, lib.byolo_get_plan_opts(self._h, ctypes.byref(o)))
+        return {n: getattr(o, n) for n, _ in _lib.PlanOpts._fields_ if n != "struct_bytes"}
+
+    def set_plan_opts(self, **kw):
+        """Change plan options of THIS handle (byolo_set_plan_opts): e.g. set_plan_opts(graphs=0, wino_split=2).  Options that change
+        what finalize() packs (dedup, lowmain, kx3, p1) un-finalize the handle: call finalize() again."""
+        o = _lib.PlanOpts()
+        check(self._h, lib.byolo_get_plan_opts(self._h, ctypes.byref(o)))
+        for k, v in kw.items():
+            if k == "struct_bytes" or not hasattr(o, k):
+                raise KeyError("byolo_plan_opts has no field %r" % k)
+            setattr(o, k, v)
+        check(self._h, lib.byolo_set_plan_opts(self._h, ctypes.byref(o)))
+        if any(k in kw for k in ("dedup", "lowmain", "kx3", "p1")):
+            self.finalized = False
+
+    def set_graphs(self, on):
+        """Launch-graph replay of forwards that do not fill the chip: True = the default rule (1), False = never, 2 = every forward."""
+        self.set_plan_opts(graphs=int(on) if on in (0, 1, 2) and not isinstance(on, bool) else (1 if on else 0))
+
+    def graph_stats(self):
+        n, r, c, u = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(self._h, lib.byolo_graph_stats(self._h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(c), ctypes.byref(u)))
+        return dict(graphs=n.value, replays=r.value, captures=c.value, updates=u.value)
+
     # ---- numeric status of the split-f16 mode (include/byolo.h: BYOLO_ERR_RANGE) -------------------------
     def set_async(self, on=True):
         """on: forward() neither waits for the stream nor checks the status words; the caller asks check_status() where
@@ -126,6 +155,7 @@ class Engine:
                    self.cfg.iou_thresh, self.cfg.nms_mode, bool(self.cfg.keep_all_outputs), self.device)
         for name, args in self._graph:
             getattr(t, name)(*args)
+        t.set_plan_opts(**self.plan_opts())               # the same plan on both handles (per-handle since round 6)
         t.set_precision(precision)
         t.set_params(self.get_params())
         t.finalize()
@@ -151,36 +181,42 @@ class Engine:
 
     # ---- graph construction (lib_yolo/model.py ModelBuilder.make_*) -------------------------
     def add_conv(self, scope, filters, ksize, stride, norm_flags):
-        self._graph.append(('add_conv', (scope, filters, ksize, stride, norm_flags)))
-        return check(self._h, lib.byolo_add_conv(self._h, scope.encode(), filters, ksize, stride, norm_flags))
+        idx = check(self._h, lib.byolo_add_conv(self._h, scope.encode(), filters, ksize, stride, norm_flags))
+        self._graph.append(('add_conv', (scope, filters, ksize, stride, norm_flags)))      # (recorded once the native call succeeded)
+        return idx
 
     def add_residual(self, shortcut):
+        idx = check(self._h, lib.byolo_add_residual(self._h, shortcut))
         self._graph.append(('add_residual', (shortcut,)))
-        return check(self._h, lib.byolo_add_residual(self._h, shortcut))
+        return idx
 
     def add_route(self, routes):
-        self._graph.append(('add_route', (list(routes),)))
         arr = (ctypes.c_int32 * len(routes))(*[int(r) for r in routes])
-        return check(self._h, lib.byolo_add_route(self._h, arr, len(routes)))
+        idx = check(self._h, lib.byolo_add_route(self._h, arr, len(routes)))
+        self._graph.append(('add_route', (list(routes),)))
+        return idx
 
     def add_upsample(self):
+        idx = check(self._h, lib.byolo_add_upsample(self._h))
         self._graph.append(('add_upsample', ()))
-        return check(self._h, lib.byolo_add_upsample(self._h))
+        return idx
 
     def add_stack(self, src):
+        idx = check(self._h, lib.byolo_add_stack(self._h, int(src)))
         self._graph.append(('add_stack', (src,)))
-        return check(self._h, lib.byolo_add_stack(self._h, int(src)))
+        return idx
 
     def add_detection(self, scope, kind, priors_hw):
-        self._graph.append(('add_detection', (scope, kind, [tuple(p) for p in priors_hw])))
         flat = [float(v) for p in priors_hw for v in p]
         assert len(flat) == 6, "exactly 3 priors (h, w) per detection layer"
         arr = (ctypes.c_float * 6)(*flat)
-        return check(self._h, lib.byolo_add_detection(self._h, scope.encode(), int(kind), arr))
+        idx = check(self._h, lib.byolo_add_detection(self._h, scope.encode(), int(kind), arr))
+        self._graph.append(('add_detection', (scope, kind, [tuple(p) for p in priors_hw])))
+        return idx
 
     def mark_backbone_end(self):
-        self._graph.append(('mark_backbone_end', ()))
         check(self._h, lib.byolo_mark_backbone_end(self._h))
+        self._graph.append(('mark_backbone_end', ()))
 
     # ---- parameters ------------------------------------------------------------------------------
     def param_shapes(self):

@@ -30,6 +30,9 @@ extern "C" int32_t byolo_abi_version(void) { return BYOLO_ABI_VERSION; }
 
 extern "C" const char* byolo_last_error(const byolo_t* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
+static void plan_opts_defaults(byolo_plan_opts& o);
+static void plan_opts_from_env(byolo_plan_opts& o);
+
 extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** out) {
     if (!cfg || !out) return fail(nullptr, BYOLO_ERR_ARG, "byolo_create: null argument");
     if (cfg->img_h <= 0 || cfg->img_w <= 0 || cfg->img_c <= 0)
@@ -45,9 +48,80 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
     if (!h) return fail(nullptr, BYOLO_ERR_NOMEM, "byolo_create: out of host memory");
     h->cfg = *cfg;
     h->device = device;
+    plan_opts_defaults(h->opts);
+    plan_opts_from_env(h->opts);
+    h->dedup = h->opts.dedup != 0;
     if (const char* e = getenv("BYOLO_PRECISION")) h->precision = (!strcmp(e, "f32") || !strcmp(e, "0")) ? 0 : 1;
     h->prec_requested = h->precision;
     *out = h;
+    return BYOLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan options (include/byolo.h byolo_plan_opts)
+// ------------------------------------------------------------------------------------------------
+static void plan_opts_defaults(byolo_plan_opts& o) {
+    memset(&o, 0, sizeof o);
+    o.struct_bytes = (int32_t)sizeof o;
+    o.graphs = 1; o.serialize_convs = 1; o.dedup = 1; o.lowmain = 1; o.kx3 = 1; o.p1 = 1; o.b2b = 1; o.kx3_wide = 0;
+    o.wino_split = 1; o.wino_split_min_c = 256; o.wino_split_bn = 256; o.wino_split_rounds = 0;
+    o.winograd = 1; o.wino_fused = 1; o.stream1x1 = 1; o.gemm_stream = 1; o.ksplit = -1; o.streamk = 1; o.plain_epilogue = 1; o.wino_split_persist = 1;
+    o.wino_split_min_gflop = 200.f; o.wino_split_chunk_mb = 1500.f; o.wino_min_gflop = 10.f; o.wino_chunk_mb = 800.f; o.wino_min_ratio = 80.f;
+}
+// The environment is the default filler of a NEW handle and nothing else: the A/B scripts under tools/ and the tests set a variable,
+// then build their model.  No other translation unit of the library reads a plan variable.
+static void plan_opts_from_env(byolo_plan_opts& o) {
+    auto geti = [](const char* name, int32_t& v) { if (const char* e = getenv(name)) v = atoi(e); };
+    auto getf = [](const char* name, float& v) { if (const char* e = getenv(name)) v = (float)atof(e); };
+    geti("BYOLO_GRAPHS", o.graphs); geti("BYOLO_SERIALIZE_CONVS", o.serialize_convs);
+    if (const char* e = getenv("BYOLO_NO_DEDUP")) o.dedup = atoi(e) ? 0 : 1;
+    geti("BYOLO_LOWMAIN", o.lowmain); geti("BYOLO_KX3", o.kx3); geti("BYOLO_P1", o.p1); geti("BYOLO_B2B", o.b2b); geti("BYOLO_KX3_WIDE", o.kx3_wide);
+    geti("BYOLO_WINO_SPLIT", o.wino_split); geti("BYOLO_WINO_SPLIT_MIN_C", o.wino_split_min_c); geti("BYOLO_WINO_SPLIT_BN", o.wino_split_bn);
+    geti("BYOLO_WINO_SPLIT_ROUNDS", o.wino_split_rounds); geti("BYOLO_WINOGRAD", o.winograd);
+    geti("BYOLO_WINO_FUSED", o.wino_fused); geti("BYOLO_STREAM1X1", o.stream1x1); geti("BYOLO_GEMM_STREAM", o.gemm_stream);
+    geti("BYOLO_KSPLIT", o.ksplit); geti("BYOLO_STREAMK", o.streamk); geti("BYOLO_PLAIN_EPILOGUE", o.plain_epilogue); geti("BYOLO_WINO_SPLIT_PERSIST", o.wino_split_persist);
+    getf("BYOLO_WINO_SPLIT_MIN_GFLOP", o.wino_split_min_gflop); getf("BYOLO_WINO_SPLIT_CHUNK_MB", o.wino_split_chunk_mb);
+    getf("BYOLO_WINO_MIN_GFLOP", o.wino_min_gflop); getf("BYOLO_WINO_CHUNK_MB", o.wino_chunk_mb); getf("BYOLO_WINO_MIN_RATIO", o.wino_min_ratio);
+}
+
+static void drop_graphs(byolo_t* h) {
+    for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
+extern "C" int32_t byolo_get_plan_opts(const byolo_t* h, byolo_plan_opts* out) {
+    if (!h || !out) return fail(const_cast<byolo_t*>(h), BYOLO_ERR_ARG, "byolo_get_plan_opts: null argument");
+    *out = h->opts;
+    out->struct_bytes = (int32_t)sizeof *out;
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_set_plan_opts(byolo_t* h, const byolo_plan_opts* o) {
+    if (!h || !o) return fail(h, BYOLO_ERR_ARG, "byolo_set_plan_opts: null argument");
+    if (o->struct_bytes != (int32_t)sizeof *o) return fail(h, BYOLO_ERR_ARG, "byolo_set_plan_opts: struct_bytes %d, this library's byolo_plan_opts has %d (include/byolo.h)", o->struct_bytes, (int)sizeof *o);
+    if (o->graphs < 0 || o->graphs > 2 || o->serialize_convs < 0 || o->serialize_convs > 2 || o->b2b < 0 || o->b2b > 2 || o->kx3_wide < 0 || o->kx3_wide > 2 ||
+        o->wino_split < 0 || o->wino_split > 2 || o->winograd < 0 || o->winograd > 2 || o->wino_fused < 0 || o->wino_fused > 2 || o->stream1x1 < 0 || o->stream1x1 > 2 ||
+        o->streamk < 0 || o->streamk > 2 || o->ksplit < -1 || o->ksplit > 64 || (o->wino_split_bn != 128 && o->wino_split_bn != 256) ||
+        o->wino_split_rounds < 0 || !(o->wino_split_chunk_mb > 0.f) || !(o->wino_chunk_mb > 0.f) || !(o->wino_split_min_gflop >= 0.f) || !(o->wino_min_gflop >= 0.f) || !(o->wino_min_ratio >= 0.f))
+        return fail(h, BYOLO_ERR_ARG, "byolo_set_plan_opts: a field outside its range (include/byolo.h)");
+    const byolo_plan_opts& c = h->opts;
+    // what byolo_lower / byolo_finalize have baked into steps and packed weights
+    const bool repack = (o->dedup != 0) != (c.dedup != 0) || (o->lowmain != 0) != (c.lowmain != 0) || (o->kx3 != 0) != (c.kx3 != 0) || (o->p1 != 0) != (c.p1 != 0);
+    h->opts = *o;
+    h->dedup = o->dedup != 0;
+    h->plan.B = -1; h->plan.T = -1; ++h->plan_epoch; h->wsm_B = -1;
+    if (h->d_blob || !h->graphs.empty()) { HIPCHK(h, hipSetDevice(h->device)); drop_graphs(h); }
+    if (repack && h->lowered) { h->lowered = false; h->finalized = false; }
+    return BYOLO_OK;
+}
+
+extern "C" int32_t byolo_graph_stats(const byolo_t* h, int32_t* n_graphs, int64_t* replays, int64_t* captures, int64_t* updates) {
+    if (!h) return BYOLO_ERR_ARG;
+    int n = 0; for (const auto& g : h->graphs) n += g.exec != nullptr;
+    if (n_graphs) *n_graphs = n;
+    if (replays) *replays = h->graph_replays;
+    if (captures) *captures = h->graph_captures;
+    if (updates) *updates = h->graph_updates;
     return BYOLO_OK;
 }
 
@@ -63,10 +137,12 @@ extern "C" int32_t byolo_get_precision(const byolo_t* h) { return h ? h->precisi
 
 extern "C" int32_t byolo_destroy(byolo_t* h) {
     if (!h) return BYOLO_OK;
-    bool on_device = h->d_blob || h->d_ones || h->d_status;
+    bool on_device = h->d_blob || h->d_ones || h->d_status || !h->graphs.empty() || h->cap_stream;
     for (auto& ps : h->prof) on_device = on_device || ps.ev[0] || !ps.step_ev.empty();
     if (on_device) {                               // a handle that never ran (builder-only use, no GPU) touches no HIP call
         (void)hipSetDevice(h->device);
+        drop_graphs(h);
+        if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
         if (h->d_blob) (void)hipFree(h->d_blob);
         if (h->d_ones) (void)hipFree(h->d_ones);
         if (h->d_zeros) (void)hipFree(h->d_zeros);
@@ -357,7 +433,7 @@ static int32_t lower_once(byolo_t* h) {
     h->steps.clear();
     h->aux.clear();
     h->last_use.assign(n, -1);
-    { const char* e = getenv("BYOLO_NO_DEDUP"); h->dedup = !(e && atoi(e)); }
+    h->dedup = h->opts.dedup != 0;
     for (int i = 0; i < n; ++i) {
         Layer& l = h->layers[i];
         if (is_view_op(l.op) && h->need_mat[i]) {           // copy the view into its tensor
@@ -421,8 +497,7 @@ static int32_t lower_once(byolo_t* h) {
                 st = main;
                 // the stacked half is an upsampled tensor and the convolution is 1x1: multiply at the source's resolution
                 // (STEP_PARTIAL with `low`), finish element-wise at the output's (STEP_FINISH)
-                const char* lme = getenv("BYOLO_LOWMAIN");
-                if ((!lme || atoi(lme) != 0) && l.ksize == 1 && l.stride == 1 && st.in.s[0].sh == 1 && st.in.s[0].layer >= 0 &&
+                if (h->opts.lowmain != 0 && l.ksize == 1 && l.stride == 1 && st.in.s[0].sh == 1 && st.in.s[0].layer >= 0 &&
                     !st.in.s[0].tile && (l.H & 1) == 0 && (l.W & 1) == 0 && (l.filters & 3) == 0 && l.fused_residual < 0 && (st.in.s[0].C % 32) == 0) {
                     Step lowst = st; lowst.mode = STEP_PARTIAL; lowst.low = true; lowst.addend_tensor = -1;
                     lowst.in.s[0].sh = 0;
@@ -542,6 +617,7 @@ static void fill_conv(const byolo_t* h, const Step& st, const float* d_img, char
     } else { p.addend = nullptr; p.addend_T = 1; }
     p.d_addT = make_fastdiv((uint32_t)p.addend_T);
     p.status = h->precision == 1 ? h->d_status : nullptr; p.layer_idx = st.layer;
+    p.no_plain = h->opts.plain_epilogue == 0;
 }
 
 // STEP_FINISH: mode 0 the raw sum (calibration), 1 / 2 the layer's epilogue with fp32 / hi-lo output
@@ -640,8 +716,7 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
             HIPCHK(h, launch_wino_fused(f, st));
             continue;
         }
-        static const bool stream_on = [] { const char* e = getenv("BYOLO_GEMM_STREAM"); return !e || atoi(e) != 0; }();
-        if (stream_on && gemm_stream_ok(c.C0, c.N)) {           // persistent row-streaming GEMM (gemm_stream.hip)
+        if (h->opts.gemm_stream != 0 && gemm_stream_ok(c.C0, c.N)) {           // persistent row-streaming GEMM (gemm_stream.hip)
             GemmStreamParams q; memset(&q, 0, sizeof q);
             q.a = V; q.a_bytes = (uint32_t)((uint64_t)rows * c.C0 * 4);
             q.w = dptr(h, s.wino_off); q.wstride = (uint32_t)((size_t)(c.C0 / 32) * c.N * 32 * 4); q.w_bytes = 16u * q.wstride;
@@ -671,7 +746,7 @@ static int32_t run_winograd(byolo_t* h, const Step& s, const Layer& l, const Con
         g.dst = Mb;
         g.d_hw = make_fastdiv((uint32_t)rows); g.d_wout = make_fastdiv((uint32_t)rows);
         g.d_sdiv0 = g.d_sdiv1 = g.d_addT = make_fastdiv(1u);
-        const ConvSplit sp = conv_plan_split(rows, c.Npad, g.KT, tile);
+        const ConvSplit sp = conv_plan_split(rows, c.Npad, g.KT, tile, 1.0, h->opts.ksplit, h->opts.streamk);
         if (conv_split_slab_bytes(sp, tile) <= h->plan.slab_bytes) {
             g.full_tiles = sp.full_tiles; g.split_tiles = sp.split_tiles; g.split_blocks = sp.split_blocks; g.ksplit = sp.ksplit;
             g.sk_grid = sp.sk_grid;
@@ -695,37 +770,6 @@ static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const C
     const int S = c.M / (l.H * l.W), tt = wp.th * wp.tw;
     float* V = reinterpret_cast<float*>(ws + h->plan.wino_off);
     const bool drop = c.flags & EPI_DROPOUT;
-    if (wp.oned) {
-        // ONE-DIMENSIONAL form (BYOLO_WINO1D): V rows = (sample, padded image row, pair); GEMM rows = output pairs
-        for (int s0 = 0; s0 < S; s0 += wp.chunk) {
-            const int ns = std::min(wp.chunk, S - s0);
-            const int Hp = l.H + 2;
-            WinoParams w; memset(&w, 0, sizeof w);
-            w.x = c.src0; w.v = V;
-            w.H = l.H; w.W = l.W; w.C = c.C0; w.N = c.N; w.th = Hp; w.tw = wp.tw;
-            w.s0 = s0; w.P = ns * Hp * wp.tw; w.P_pad = (int)align_up((size_t)w.P, 128);
-            w.d_tt = make_fastdiv((uint32_t)(Hp * wp.tw)); w.d_tw = make_fastdiv((uint32_t)wp.tw);
-            w.d_c4 = make_fastdiv((uint32_t)(c.C0 / 4)); w.d_n4 = make_fastdiv((uint32_t)(c.N / 4));
-            w.vmul = 2.f / ACT_SCALE;
-            if (prof && (rc = mark_launch(h, s.layer, -6, w.P, c.C0, 0, 0.0, st))) return rc;
-            HIPCHK(h, launch_wino1d_input(w, st));
-            WinoSplitParams f; memset(&f, 0, sizeof f);
-            const int P = ns * l.H * wp.tw, P_pad = (int)align_up((size_t)P, 64);
-            f.oned = 1; f.ky_stride = (uint32_t)((size_t)wp.tw * c.C0 * 4);
-            f.v = V; f.xi_stride = (uint32_t)((uint64_t)w.P_pad * c.C0 * 4); f.v_bytes = 4u * f.xi_stride;
-            f.w = dptr(h, s.wino_off); f.w_bytes = (uint32_t)((size_t)12 * c.C0 * c.N * 4);
-            f.y = c.dst; f.scale = dptr(h, drop ? l.wscalek_off : l.wscale_off); f.shift = c.shift;
-            f.C = c.C0; f.N = c.N; f.KT = 3 * c.C0 / 32; f.n_tiles = c.N / 256; f.bn = 256; f.bm = 64;
-            f.H = l.H; f.W = l.W; f.th = l.H; f.tw = wp.tw; f.s0 = s0; f.P = P; f.P_pad = P_pad;
-            f.units = (P_pad / 64) * f.n_tiles;
-            f.flags = c.flags; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base; f.mask_bits = c.mask_bits;
-            f.status = c.status; f.layer_idx = c.layer_idx;
-            f.d_ntiles = make_fastdiv((uint32_t)f.n_tiles); f.d_tt = make_fastdiv((uint32_t)(l.H * wp.tw)); f.d_tw = w.d_tw;
-            if (prof && (rc = mark_launch(h, s.layer, 141, (int64_t)4 * P_pad, c.N, 3 * c.C0, algo_flops * ns / S, st))) return rc;
-            HIPCHK(h, launch_wino_split(f, st));
-        }
-        return BYOLO_OK;
-    }
     for (int s0 = 0; s0 < S; s0 += wp.chunk) {
         const int ns = std::min(wp.chunk, S - s0);
         WinoParams w; memset(&w, 0, sizeof w);
@@ -744,7 +788,7 @@ static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const C
         f.y = c.dst; f.scale = dptr(h, drop ? l.wscalek_off : l.wscale_off); f.shift = c.shift;
         f.C = c.C0; f.N = c.N; f.KT = c.C0 / 32; f.n_tiles = c.N / wp.bn; f.bn = wp.bn;
         f.H = l.H; f.W = l.W; f.th = wp.th; f.tw = wp.tw; f.s0 = s0; f.P = w.P; f.P_pad = w.P_pad;
-        f.bm = wp.bm; f.units = (w.P_pad / wp.bm) * f.n_tiles;
+        f.bm = wp.bm; f.units = (w.P_pad / wp.bm) * f.n_tiles; f.persist = h->opts.wino_split_persist != 0;
         f.flags = c.flags; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base; f.mask_bits = c.mask_bits;
         f.status = c.status; f.layer_idx = c.layer_idx;
         f.d_ntiles = make_fastdiv((uint32_t)f.n_tiles); f.d_tt = w.d_tt; f.d_tw = w.d_tw;
@@ -872,6 +916,11 @@ extern "C" const char* byolo_precision_note(const byolo_t* h) { return h ? h->pr
 static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t T, uint64_t seed, int32_t dropout_on,
                              const uint32_t* d_mask_bits, void* d_workspace, size_t workspace_bytes, float* d_boxes, float* d_rows,
                              int32_t* d_kept, int32_t* d_count, void* stream);
+struct FwdArgs { const float* d_img; int32_t B, T; uint64_t seed; int32_t dropout_on; const uint32_t* d_mask_bits; void* d_workspace;
+                 float* d_boxes; float* d_rows; int32_t* d_kept; int32_t* d_count; };
+static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, bool capturing, bool wait_convs);
+static int32_t finish_forward(byolo_t* h, hipStream_t st, void* stream);
+static int32_t forward_graph(byolo_t* h, const FwdArgs& a, hipStream_t st, bool* done);
 
 // A batch beyond byolo_max_images(h, T) -- the convolutions address their sources with 32-bit byte offsets -- runs as consecutive
 // pieces of at most that many images in the SAME workspace: images are independent end to end (the NMS is per image) and every
@@ -917,13 +966,125 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
     if ((d_rows || d_kept || d_count) && !(d_rows && d_kept && d_count))
         return fail(h, BYOLO_ERR_ARG, "byolo_forward: d_rows, d_kept and d_count go together");
     const bool inject = d_mask_bits != nullptr && dropout_on;
+    // rate 0 (any rate whose 16-bit threshold is 2^16): the layer is the identity, as tf.layers.dropout(rate=0) is (byolo_rng.h);
+    // injected bits are applied whatever the rate
+    if (dropout_on && !inject && byolo_drop_is_identity((double)h->cfg.drop_prob)) dropout_on = 0;
     make_plan(h, B, T, inject);
     if (workspace_bytes < h->plan.total)
         return fail(h, BYOLO_ERR_NOMEM, "byolo_forward: workspace %zu < required %zu bytes", workspace_bytes, h->plan.total);
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    char* ws = reinterpret_cast<char*>(d_workspace);
     h->last_ws = d_workspace;
+    // (see ev_convs)  Only where a forward fills the chip by itself: a small one -- 8 images at 416 x 416 are 0.5 TFLOP in launches of
+    // a few dozen tiles -- gains from running beside the next (config 2: 2480 img/s one after the other, 3110 side by side).
+    // opts.serialize_convs: 0 never, 1 forwards of >= 1 TFLOP (default), 2 always.
+    bool serialize = h->opts.serialize_convs >= 2;
+    if (h->opts.serialize_convs == 1) { double f = 0; (void)byolo_flops(h, B, T, &f); serialize = f >= 1e12; }
+    if (h->tshard_T > 0 && (B != 1 || h->tshard_t0 + T > h->tshard_T)) return fail(h, BYOLO_ERR_ARG, "byolo_forward: a T shard (byolo_set_tshard) is ONE image and t0 + T <= T_total");
+    if (h->tshard_T > 0 && d_rows) return fail(h, BYOLO_ERR_ARG, "byolo_forward: a T shard (byolo_set_tshard) hands out per-box SUMS in d_boxes; the NMS runs after byolo_finish_tshard (byolo_sort_nms)");
+    if (h->tshard_T > 0 && !d_boxes) return fail(h, BYOLO_ERR_ARG, "byolo_forward: a T shard (byolo_set_tshard) needs d_boxes (the per-box sums are its result)");
+    if (h->tshard_T > 0)
+        for (const auto& l : h->layers)
+            if (l.op == OP_DETECTION && l.det_kind != BYOLO_DET_EPISTEMIC) return fail(h, BYOLO_ERR_ARG, "T sharding (byolo_set_tshard) is defined for epistemic detection layers");
+    const FwdArgs a{d_img, B, T, seed, dropout_on, d_mask_bits, d_workspace, d_boxes, d_rows, d_kept, d_count};
+    // Launch-graph replay (include/byolo.h byolo_plan_opts.graphs): a forward that does NOT fill the chip by itself (below the
+    // `serialize` threshold: detect.py's batch-1 loop, BASELINE configs[0..1]) is ~85 dependent launches of 5 - 60 us; its whole
+    // launch sequence is captured once per (arguments, plan) and replayed with ONE hipGraphLaunch.  Per-launch profiling, the
+    // big forwards and a call that differs in any argument run eagerly / are captured anew.
+    if (h->opts.graphs > 0 && !h->profiling && (!serialize || h->opts.graphs >= 2)) {
+        bool done = false;
+        if (serialize && h->ev_convs_valid && h->convs_stream != st) HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0));      // (graphs == 2 only)
+        rc = forward_graph(h, a, st, &done); if (rc) return rc;
+        if (done) return finish_forward(h, st, stream);
+    }
+    const bool wait = serialize && h->ev_convs_valid && h->convs_stream != st;
+    rc = enqueue_forward(h, a, st, false, wait); if (rc) return rc;
+    return finish_forward(h, st, stream);
+}
+
+// One forward as ONE hipGraphLaunch.  The first call with a given argument set runs eagerly (function attributes are set, one-off
+// shapes never pay for a capture); the second captures the launch sequence of enqueue_forward on the caller's stream (thread-local
+// capture mode: the memset node + the kernel nodes, a linear chain), instantiates it and launches it; later calls replay.  A call that
+// differs only in what the dropout masks are drawn from (seed, byolo_set_first_image) is captured anew and the executable graph is
+// UPDATED in place (hipGraphExecUpdate: same topology, other kernel arguments).  *done = false: nothing was enqueued, run eagerly.
+static int32_t forward_graph(byolo_t* h, const FwdArgs& a, hipStream_t st, bool* done) {
+    *done = false;
+    byolo::GraphKey key; memset(&key, 0, sizeof key);
+    key.d_img = a.d_img; key.d_mask_bits = a.d_mask_bits; key.d_workspace = a.d_workspace; key.d_boxes = a.d_boxes; key.d_rows = a.d_rows;
+    key.d_kept = a.d_kept; key.d_count = a.d_count; key.B = a.B; key.T = a.T; key.dropout_on = a.dropout_on; key.precision = h->precision;
+    key.plan_epoch = h->plan_epoch; key.tshard_t0 = h->tshard_t0; key.tshard_T = h->tshard_T;
+    const bool draws = a.dropout_on && h->n_dropout > 0;                   // seed / first_image reach a kernel argument
+    const uint64_t seed = draws ? a.seed : 0; const int64_t first = draws ? h->first_image : 0;
+    byolo::GraphEntry* e = nullptr;
+    for (auto& g : h->graphs) if (g.key.same(key)) { e = &g; break; }
+    if (!e) {
+        if (h->graphs.size() >= 8) {                                       // drop the least recently used
+            size_t lru = 0;
+            for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].used < h->graphs[lru].used) lru = i;
+            if (h->graphs[lru].exec) (void)hipGraphExecDestroy(h->graphs[lru].exec);
+            h->graphs.erase(h->graphs.begin() + lru);
+        }
+        h->graphs.emplace_back();
+        e = &h->graphs.back(); e->key = key;
+    }
+    e->used = ++h->graph_clock;
+    if (e->no_graph || e->seen++ == 0) return BYOLO_OK;                    // first sight (or not capturable here): eager
+    if (e->exec && e->seed == seed && e->first_image == first) {
+        HIPCHK(h, hipGraphLaunch(e->exec, st));
+        ++h->graph_replays; *done = true;
+    } else {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return BYOLO_OK; }     // the caller captures already: its graph, not ours
+        // captured on a stream of the handle's own (the caller's may be the legacy default stream, which cannot capture); the
+        // executable graph is launched on the caller's
+        if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->cap_stream = nullptr; e->no_graph = true; return BYOLO_OK; }
+        if (hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); e->no_graph = true; return BYOLO_OK; }
+        const int32_t rc = enqueue_forward(h, a, h->cap_stream, true, false);
+        hipGraph_t g = nullptr;
+        const hipError_t ce = hipStreamEndCapture(h->cap_stream, &g);
+        if (rc != BYOLO_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (ce != hipSuccess || !g) { (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g); e->no_graph = true; return BYOLO_OK; }      // not capturable here: eager from now on
+        bool ok = false;
+        if (e->exec) {
+            hipGraphNode_t bad = nullptr; hipGraphExecUpdateResult ur;
+            ok = hipGraphExecUpdate(e->exec, g, &bad, &ur) == hipSuccess;
+            if (ok) ++h->graph_updates; else { (void)hipGetLastError(); (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+        }
+        if (!ok) {
+            ok = hipGraphInstantiate(&e->exec, g, nullptr, nullptr, 0) == hipSuccess;
+            if (ok) ++h->graph_captures; else { (void)hipGetLastError(); e->exec = nullptr; e->no_graph = true; }
+        }
+        (void)hipGraphDestroy(g);
+        if (!ok) return BYOLO_OK;
+        e->seed = seed; e->first_image = first;
+        HIPCHK(h, hipGraphLaunch(e->exec, st));
+        *done = true;
+    }
+    // (the event a forward on another stream would wait for sits behind the whole graph: graphs are for forwards that are not serialised)
+    if (!h->ev_convs) HIPCHK(h, hipEventCreateWithFlags(&h->ev_convs, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->ev_convs, st)); h->convs_stream = st; h->ev_convs_valid = true;
+    return BYOLO_OK;
+}
+
+// Split precision: wait for the forward and read the status words, unless the caller does that itself (byolo_set_async +
+// byolo_status).  A raised status is an ERROR here, not a row of inf / NaN: the words are cleared for the next call.
+static int32_t finish_forward(byolo_t* h, hipStream_t st, void* stream) {
+    if (h->precision == 1 && !h->async_status) {
+        unsigned f = 0, ly = 0xFFFFFFFFu;
+        int32_t rc = read_status(h, st, &f, &ly); if (rc) return rc;
+        if (f) { (void)byolo_clear_status(h, stream); return range_error(h, "byolo_forward", f, ly); }
+    }
+    return BYOLO_OK;
+}
+
+// Everything one forward puts on the stream, in order: the split-K tickets' memset, the image's hi/lo copy, the convolution stack,
+// decode, sort + NMS.  `capturing`: the stream is in capture mode (forward_graph) -- no event is recorded or waited for in here.
+static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, bool capturing, bool wait_convs) {
+    const float* d_img = a.d_img; const int32_t B = a.B, T = a.T; const uint64_t seed = a.seed; const int32_t dropout_on = a.dropout_on;
+    const uint32_t* d_mask_bits = a.d_mask_bits; float* d_boxes = a.d_boxes; float* d_rows = a.d_rows; int32_t* d_kept = a.d_kept; int32_t* d_count = a.d_count;
+    const bool inject = d_mask_bits != nullptr && dropout_on;
+    int32_t rc;
+    char* ws = reinterpret_cast<char*>(a.d_workspace);
     if (h->profiling) {
         h->prof_w = (h->prof_w + 1) % (int)h->prof.size();
         byolo::ProfSlot& ps = h->wslot();
@@ -933,17 +1094,7 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
     }
     const bool per_step = h->profiling >= 2;
     bool backbone_marked = false;
-    // (see ev_convs)  Only where a forward fills the chip by itself: a small one -- 8 images at 416 x 416 are 0.5 TFLOP in launches of
-    // a few dozen tiles -- gains from running beside the next (config 2: 2480 img/s one after the other, 3110 side by side).
-    // BYOLO_SERIALIZE_CONVS: 0 never, 1 forwards of >= 1 TFLOP (default), 2 always.
-    static const int ser_knob = [] { const char* e = getenv("BYOLO_SERIALIZE_CONVS"); return e ? atoi(e) : 1; }();
-    bool serialize = ser_knob >= 2;
-    if (ser_knob == 1) { double f = 0; (void)byolo_flops(h, B, T, &f); serialize = f >= 1e12; }
-    // BYOLO_SERIALIZE_AT=1 (experiment): wait in front of the first HEAD launch instead, i.e. let this forward's backbone (small
-    // launches that leave CUs idle) run beside the previous forward's heads
-    static const int ser_at = [] { const char* e = getenv("BYOLO_SERIALIZE_AT"); return e ? atoi(e) : 0; }();
-    bool wait_pending = serialize && h->ev_convs_valid && h->convs_stream != st;
-    if (wait_pending && !(ser_at == 1 && h->backbone_end >= 0)) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0)); wait_pending = false; }
+    if (wait_convs && !capturing) HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0));
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     if (h->precision == 1 && h->img_split)
         HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st, h->d_status));
@@ -996,7 +1147,6 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
     for (size_t si = 0; si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
-        if (wait_pending && s.layer >= h->backbone_end) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0)); wait_pending = false; }
         if (h->profiling && !backbone_marked && h->backbone_end >= 0 && s.layer >= h->backbone_end) {
             HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); backbone_marked = true;
         }
@@ -1066,11 +1216,11 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
         ps.step_valid = true;
     }
     if (h->profiling) { if (!backbone_marked) HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); HIPCHK(h, hipEventRecord(h->wslot().ev[2], st)); }
-    if (!h->ev_convs) HIPCHK(h, hipEventCreateWithFlags(&h->ev_convs, hipEventDisableTiming));
-    HIPCHK(h, hipEventRecord(h->ev_convs, st)); h->convs_stream = st; h->ev_convs_valid = true;
+    if (!capturing) {
+        if (!h->ev_convs) HIPCHK(h, hipEventCreateWithFlags(&h->ev_convs, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->ev_convs, st)); h->convs_stream = st; h->ev_convs_valid = true;
+    }
     float* boxes = d_boxes ? d_boxes : reinterpret_cast<float*>(ws + h->plan.boxes_off);
-    if (h->tshard_T > 0 && (B != 1 || h->tshard_t0 + T > h->tshard_T)) return fail(h, BYOLO_ERR_ARG, "byolo_forward: a T shard (byolo_set_tshard) is ONE image and t0 + T <= T_total");
-    if (h->tshard_T > 0 && d_rows) return fail(h, BYOLO_ERR_ARG, "byolo_forward: a T shard (byolo_set_tshard) hands out per-box SUMS in d_boxes; the NMS runs after byolo_finish_tshard (byolo_sort_nms)");
     if (d_boxes || d_rows) { rc = run_decode(h, ws, boxes, B, T, st, h->tshard_T > 0 ? 1 : 0); if (rc) return rc; }
     if (h->profiling) HIPCHK(h, hipEventRecord(h->wslot().ev[3], st));
     if (d_rows) {
@@ -1083,13 +1233,6 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
         HIPCHK(h, launch_sort_nms(n, st));
     }
     if (h->profiling) { HIPCHK(h, hipEventRecord(h->wslot().ev[4], st)); h->wslot().ev_valid = true; }
-    // Split precision: wait for the forward and read the status words, unless the caller does that itself (byolo_set_async +
-    // byolo_status).  A raised status is an ERROR here, not a row of inf / NaN: the words are cleared for the next call.
-    if (h->precision == 1 && !h->async_status) {
-        unsigned f = 0, ly = 0xFFFFFFFFu;
-        rc = read_status(h, st, &f, &ly); if (rc) return rc;
-        if (f) { (void)byolo_clear_status(h, stream); return range_error(h, "byolo_forward", f, ly); }
-    }
     return BYOLO_OK;
 }
 

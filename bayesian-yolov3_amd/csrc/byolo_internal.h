@@ -66,7 +66,6 @@ struct Layer {
     bool direct = false;
     std::vector<int> wshift;       // split precision, per OUTPUT CHANNEL n: the packed weights hold w[.][n] * 2^wshift[n] (the channel's largest |w'| in [2^13, 2^14)); folded into scale[n]
     std::vector<int> wshift_u;     // split precision, Winograd (wino_split.hip): per output channel, for U = G g G^T
-    bool wino1d = false;           // ... packed for the ONE-DIMENSIONAL form instead (BYOLO_WINO1D, round 5 experiment): U[xi][ky] = G g[ky, :]
     size_t wscale_off = 0, wscalek_off = 0;    // ... and the per-channel scale arrays that go with it (the shift is the layer's)
     float in_scale = 1.f;          // split precision: scale of the layer's input (ACT_SCALE for activations, 1 for the fp32 image of a direct convolution)
     int64_t box_base = 0;
@@ -112,7 +111,7 @@ struct Step {
     bool kx3 = false;              // split precision: 3x3 / stride 1 over one plain source -- shared-tap stages (conv_tile_kx3), weights in (ky, chunk, kx) order
 };
 // per-(B, T) decision for a Winograd-capable step: samples per chunk (0 = direct convolution)
-struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; int bm = 0, bn = 0; /* split precision: output tiles / channels per workgroup */ bool oned = false; };
+struct WinoPlan { int chunk = 0; int th = 0, tw = 0; size_t v_bytes = 0, m_bytes = 0; bool fused = false; int bm = 0, bn = 0; /* split precision: output tiles / channels per workgroup */ };
 struct AuxTensor { int H, W, C; bool stacked = false; };      // stacked: one row per SAMPLE pixel (else per image pixel)
 
 struct Plan {
@@ -155,7 +154,18 @@ struct byolo {
     mutable int want_mat = -1;     // lowering: the view whose materialisation would resolve the last failure
     std::vector<Step> steps;
     std::vector<AuxTensor> aux;    // auxiliary tensors (ids n_layers + k): partial sums of split convs
-    bool dedup = true;             // T-invariant de-duplication (BYOLO_NO_DEDUP=1 disables, for A/B)
+    byolo_plan_opts opts;          // include/byolo.h: defaults + the environment at byolo_create, byolo_set_plan_opts afterwards
+    // Launch graphs of whole forwards (opts.graphs; byolo_api.hip forward_graph): keyed by everything a launch's arguments depend on
+    struct GraphKey {
+        const void* d_img; const void* d_mask_bits; const void* d_workspace; const void* d_boxes; const void* d_rows; const void* d_kept; const void* d_count;
+        int32_t B, T, dropout_on, precision, plan_epoch, tshard_t0, tshard_T;
+        bool same(const GraphKey& o) const { return !memcmp(this, &o, sizeof *this); }
+    };
+    struct GraphEntry { GraphKey key; uint64_t seed; int64_t first_image; hipGraphExec_t exec = nullptr; uint64_t used = 0; int seen = 0; bool no_graph = false; };
+    std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;  // the capture stream (created with the first capture)
+    uint64_t graph_clock = 0; int64_t graph_replays = 0, graph_captures = 0, graph_updates = 0;
+    bool dedup = true;             // T-invariant de-duplication (opts.dedup)
     // Arithmetic of the convolution stack (byolo_set_precision; BYOLO_PRECISION=f32|split):
     //   0  fp32 operands on v_mfma_f32_32x32x2_f32 (+ Winograd F(2x2,3x3) where it pays)
     //   1  split-f16 operands ("hi + lo", ~23 significant bits, fp32 accumulation) on v_mfma_f32_32x32x16_f16:

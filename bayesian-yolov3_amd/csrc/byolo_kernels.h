@@ -84,6 +84,7 @@ struct ConvParams {
     // set by launch_conv_igemm: a split-f16 launch whose epilogue is the plain case -- no addend, residual, T-replay, raw / fp32 output
     // or injected masks, cout % 32 == 0, 16-byte rows -- and may run the straight-line epilogue (conv_igemm.hip finish_plain)
     int plain;
+    int no_plain;              // byolo_plan_opts.plain_epilogue == 0: the general epilogue (finish_tile) on every launch (A/B)
     FastDiv d_hw, d_wout, d_sdiv0, d_sdiv1, d_addT;   // Hout*Wout, Wout, sdiv0, sdiv1, addend_T
     // split-K of the last partial round of tiles (conv_plan_split): blocks [0, full_tiles) compute whole
     // tiles, the remaining split_tiles tiles are computed by ksplit K-slice blocks each
@@ -137,21 +138,15 @@ struct WinoSplitParams {
     const float* scale; const float* shift;
     int C, N, KT, n_tiles;                // KT = C / 32 (a multiple of 4), n_tiles = N / bn
     int H, W, th, tw, s0, P, P_pad;       // as WinoParams
-    int bm, bn;                           // output tiles / channels per workgroup: 64 | 128 (P_pad is a multiple of it), 128 | 256
-    // ONE-DIMENSIONAL form (round 5 experiment, BYOLO_WINO1D): F(2,3) along W, the three filter rows direct.  V is
-    // [4][samples * (H + 2) rows (a zero row above and below every sample)][tw pairs][C]; a GEMM row = an output PAIR (s, y, j),
-    // P = samples * H * tw; its operand for filter row ky sits ky_stride bytes (one padded row) further per ky; KT = 3 * C / 32
-    // K-tiles per point in (ky, chunk) order; th = H, tw = ceil(W / 2), d_tt = H * tw, d_tw = tw
-    int oned; uint32_t ky_stride;
-    int units;                            // P_pad / bm * n_tiles workgroups
+    int bm, bn;                           // output tiles / channels per workgroup: 64 (P_pad is a multiple of it), 128 | 256
+    int persist;                          // the workgroups walk the unit list (grid = resident workgroups): byolo_plan_opts.wino_split_persist
+    int units;                            // P_pad / bm * n_tiles units of (64 output tiles, bn channels)
     int flags; uint32_t k0, k1, thr; uint64_t idx_base; const uint32_t* mask_bits;
     unsigned* status; int layer_idx;
     FastDiv d_ntiles, d_tt, d_tw;
 };
 bool wino_split_ok(int C, int N);
 hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st);
-// 1-D form: WinoParams with th = H + 2 (padded rows per sample), tw = ceil(W / 2), P = samples * th * tw V rows, d_tt = th * tw
-hipError_t launch_wino1d_input(const WinoParams& p, hipStream_t st);
 hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st);
 // Row-streaming persistent GEMM (gemm_stream.hip): the Winograd-domain GEMM (epi 0: 16 row blocks of RT row tiles, one
 // weight matrix each, raw accumulators out), a 1x1 / stride-1 convolution with its fused epilogue (epi 1), or a
@@ -196,7 +191,7 @@ void wino_weight_transform(const float g[9], float u[16]);   // host: U = G g G^
 
 struct ConvSplit { int full_tiles, split_tiles, split_blocks, ksplit; int sk_grid = 0; };
 // decision (shape-only, deterministic); KT in the launch's scheduling units, tk_scale = time of a unit / time of an fp32 K-tile
-ConvSplit conv_plan_split(int M, int Npad, int KT, int tile, double tk_scale = 1.0);
+ConvSplit conv_plan_split(int M, int Npad, int KT, int tile, double tk_scale = 1.0, int ksplit_knob = -1, int streamk_knob = 1);      // knobs: byolo_plan_opts.ksplit / .streamk
 size_t conv_split_slab_bytes(const ConvSplit& sp, int tile);
 
 // tile configuration ids

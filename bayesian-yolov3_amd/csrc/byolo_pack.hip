@@ -228,31 +228,16 @@ static int32_t finalize_impl(byolo_t* h) {
         if (st.wino_ok && h->precision == 1 && wino_split_ok(Cs, N) && st.Npad == N) {
             // Winograd in split arithmetic (wino_split.hip): U[xi][c][n] = (G g G^T)[xi] in double, rounded once; one power of two per
             // output channel over all 16 points; hi/lo pairs in fragment order, K-tile order (point, chunk)
-            // BYOLO_WINO1D=1 (round 5 experiment): the 128-channel layers as ONE-DIMENSIONAL F(2,3) along W with the
-            // three filter rows direct -- U[xi][ky][c][n] = sum_kx G[xi][kx] g[ky][kx][c][n], K order (ky, c) per point: 12 of the 16
-            // matrices' worth of space; V at scale 2 (wino_split.hip wino1d_input_kernel), which wshift_u absorbs (+ 1)
-            const char* w1e = getenv("BYOLO_WINO1D");
-            const int wino1d_env = w1e ? atoi(w1e) : 0;
-            const bool oned = wino1d_env && Cs == 128 && l.Cin == 128 && (N % 256) == 0;
-            const int NP = oned ? 4 : 16, KC = oned ? 3 * Cs : Cs;                   // points; K rows per point
+            const int NP = 16, KC = Cs;                                              // points; K rows per point
             std::vector<float> U((size_t)NP * KC * N);
             float g9[9], u16[16];
             for (int c = 0; c < Cs; ++c)
                 for (int nn = 0; nn < N; ++nn) {
                     for (int tap = 0; tap < 9; ++tap) g9[tap] = w[((size_t)tap * l.Cin + st.c_lo + c) * N + nn];
-                    if (oned) {
-                        static const double G[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
-                        for (int ky = 0; ky < 3; ++ky)
-                            for (int xi = 0; xi < 4; ++xi)
-                                U[((size_t)xi * KC + (size_t)ky * Cs + c) * N + nn] =
-                                    (float)(G[xi][0] * g9[ky * 3 + 0] + G[xi][1] * g9[ky * 3 + 1] + G[xi][2] * g9[ky * 3 + 2]);
-                        continue;
-                    }
                     wino_weight_transform(g9, u16);
                     for (int xi = 0; xi < 16; ++xi) U[((size_t)xi * Cs + c) * N + nn] = u16[xi];
                 }
             Layer& lw = h->layers[st.layer];
-            lw.wino1d = oned;
             lw.wshift_u.assign((size_t)N, 0);
             std::vector<float> wsu((size_t)N), mxu((size_t)N, 0.f);
             for (size_t r = 0; r < (size_t)NP * KC; ++r) {
@@ -265,7 +250,6 @@ static int32_t finalize_impl(byolo_t* h) {
                 if (mx > 0.f) (void)std::frexp(mx, &e);
                 lw.wshift_u[nn] = mx > 0.f ? std::min(126, std::max(-126, 14 - e)) : 0;
                 wsu[nn] = ldexpf(1.f, lw.wshift_u[nn]);
-                if (oned) lw.wshift_u[nn] += 1;                                          // the accumulators also carry V's scale 2
             }
             _Float16* d16 = reinterpret_cast<_Float16*>(blob.data() + st.wino_off);
             const size_t blocks = N / 32;

@@ -38,9 +38,7 @@ void step_geometry(const byolo_t* h, const Step& st, int B, int T, int* M, int* 
 // graph is lowered (a plan made before byolo_finalize is then the plan made after it: byolo_workspace_bytes, tests/test_planner.py)
 // and again by byolo_finalize once it has settled the precision; the weights are packed in the K-tile order of the loop.
 void decide_loops(byolo_t* h) {
-    const char* kxe = getenv("BYOLO_KX3");
-    const char* p1e = getenv("BYOLO_P1");
-    const bool kx3_on = !kxe || atoi(kxe) != 0, p1_on = !p1e || atoi(p1e) != 0;
+    const bool kx3_on = h->opts.kx3 != 0, p1_on = h->opts.p1 != 0;
     for (auto& st : h->steps) {
         st.kx3 = false; st.p1 = false;
         if (!st.is_conv()) continue;
@@ -89,17 +87,15 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
     // two must not share memory (unfused, the follower's output may take the place of the 3x3 layer's dead input).
     // Measured at config 4 (round 4, three A/B runs on one box each, gpurun_out/r4f-r4h): the three pairs of the 76x76 head
     // 2.11 + 0.56 -> 2.60, 2.11 + 0.56 -> 2.59, 2.09 + 0.38 -> 2.32 ms; 342.6 -> 348.3, 344.5 -> 349.9, 347.1 -> 350.4 img/s.
-    // BYOLO_B2B: 0 never, 1 launches of >= 4 rounds of 256 workgroups (default), 2 every eligible pair (tests)
+    // opts.b2b: 0 never, 1 launches of >= 4 rounds of 256 workgroups (default), 2 every eligible pair (tests)
     p.fuse.assign(h->steps.size(), 0);
-    { const char* be = getenv("BYOLO_B2B");
-      const int b2b = be ? atoi(be) : 1;
+    { const int b2b = h->opts.b2b;
       for (size_t si = 0; b2b && h->precision == 1 && !inject && !h->cfg.keep_all_outputs && si + 1 < h->steps.size(); ++si) {
           const Step& s = h->steps[si];
           const Layer& l = h->layers[s.layer];
           if (!(s.is_conv() && s.kx3 && s.mode == STEP_NORMAL && l.op == OP_CONV && !l.direct && l.filters == 256 && s.Npad == 256 && l.fused_residual < 0)) continue;
           int M, KT; step_geometry(h, s, B, T, &M, &KT);
           if (b2b < 2 && (int64_t)((M + 127) / 128) < 4 * 256) continue;
-          if (l.wino1d && 2.0 * M * l.filters * 9.0 * l.Cin >= 200e9) continue;   // (BYOLO_WINO1D experiment: the unfused 1-D Winograd launch instead)
           const Step& s2 = h->steps[si + 1];
           const Layer& l2 = h->layers[s2.layer];
           const int out_t = s.out_tensor;
@@ -152,9 +148,8 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
         // config 4 (round 4, gpurun_out/r4b_*): the three 76x76 head convolutions 2.13 -> 2.22 ms each (-4 %): with ONE workgroup per
         // CU the epilogues of all eight waves coincide and nothing multiplies meanwhile, where two independent 4-wave workgroups
         // overlap one's epilogue with the other's K loop -- so it is NOT the default.
-        // BYOLO_KX3_WIDE: 0 never (default), 1 launches of >= 4 rounds of 256 workgroups, 2 every eligible launch (tests)
-        const char* kwe = getenv("BYOLO_KX3_WIDE");           // (read per plan, like BYOLO_WINO_SPLIT: tests and fuzzers flip it inside one process)
-        const int kx3_wide = kwe ? atoi(kwe) : 0;
+        // opts.kx3_wide: 0 never (default), 1 launches of >= 4 rounds of 256 workgroups, 2 every eligible launch (tests)
+        const int kx3_wide = h->opts.kx3_wide;
         if (h->precision == 1 && s.kx3 && (s.Npad % 256) == 0 && kx3_wide && (l.filters % 128) == 0 &&
             (kx3_wide >= 2 ? (tile == TILE_128x128 || tile == TILE_128x64)       // (forced: also where the grid-fill rule above went narrow)
                            : (tile == TILE_128x128 && (int64_t)((M + 127) / 128) * (s.Npad / 256) >= 4 * 256)))
@@ -163,7 +158,7 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
         p.tile[si] = tile;
         // split precision: a K-tile takes ~0.4 of the fp32 kernel's; a shared-tap launch is scheduled in stages of 3 K-tiles
         const bool sp = h->precision == 1, kx3 = sp && s.kx3;
-        p.split[si] = conv_plan_split(M, s.Npad, kx3 ? KT / 3 : KT, tile, sp ? (kx3 ? 1.2 : 0.4) : 1.0);
+        p.split[si] = conv_plan_split(M, s.Npad, kx3 ? KT / 3 : KT, tile, sp ? (kx3 ? 1.2 : 0.4) : 1.0, h->opts.ksplit, h->opts.streamk);
         if (s.low) p.split[si] = ConvSplit{((M + 127) / 128) * (s.Npad / conv_tile_bn(tile)), 0, 0, 1};      // whole tiles: the accumulation order of a STEP_MAIN tile
         if (tile == TILE_128x256) p.split[si] = ConvSplit{((M + 127) / 128) * (s.Npad / 256), 0, 0, 1};      // whole tiles only: its workgroups walk the tile list (conv_igemm.hip WALK); a follower needs a finished tile
         slab = std::max(slab, conv_split_slab_bytes(p.split[si], tile));
@@ -175,18 +170,14 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
     size_t wino_scratch = 0;
     // Split precision: Winograd F(2x2,3x3) in split arithmetic (wino_split.hip) for the LARGE 3x3 / stride-1 convolutions -- the
     // nine 3x3 convolutions of the heads at T >= ~10 samples.  The transform streams 5x the input through HBM, so small layers keep
-    // the shared-tap direct kernel.  BYOLO_WINO_SPLIT: 0 never, 1 layers of >= BYOLO_WINO_SPLIT_MIN_GFLOP (default 200), 2 every
-    // eligible layer (tests); BYOLO_WINO_SPLIT_BM / _BN: 64 | 128 output tiles, 256 | 128 channels per workgroup; BYOLO_WINO_SPLIT_CHUNK_MB: V bytes of a chunk.
+    // the shared-tap direct kernel.  opts.wino_split: 0 never, 1 layers of >= opts.wino_split_min_gflop (default 200), 2 every
+    // eligible layer (tests); opts.wino_split_bn: 256 | 128 channels per workgroup (64 output tiles; the 128-tile workgroup of rounds
+    // 3 - 5 lost both of its A/Bs -- 298 against 310 img/s, one wave per SIMD -- and is gone); opts.wino_split_chunk_mb: V bytes of a chunk.
     if (h->precision == 1) {
-        const char* e = getenv("BYOLO_WINO_SPLIT");
-        const int on = e ? atoi(e) : 1;
-        const char* mf = getenv("BYOLO_WINO_SPLIT_MIN_GFLOP");
-        const char* cb = getenv("BYOLO_WINO_SPLIT_CHUNK_MB");
-        const char* be = getenv("BYOLO_WINO_SPLIT_BM");
-        const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 200.0) * 1e9, budget = (cb ? atof(cb) : 1500.0) * 1e6;
-        const int bm = be && atoi(be) == 128 ? 128 : 64;
-        const char* bne = getenv("BYOLO_WINO_SPLIT_BN");
-        const int bn_pref = bne ? atoi(bne) : 256;             // measured at config 4: 1.29 -> 1.19 ms per fused launch
+        const int on = h->opts.wino_split;
+        const double min_flops = on >= 2 ? 0.0 : (double)h->opts.wino_split_min_gflop * 1e9, budget = (double)h->opts.wino_split_chunk_mb * 1e6;
+        const int bm = 64;
+        const int bn_pref = h->opts.wino_split_bn;             // measured at config 4: 1.29 -> 1.19 ms per fused launch
         for (size_t si = 0; on && si < h->steps.size(); ++si) {
             const Step& s = h->steps[si];
             const Layer& l = h->layers[s.layer];
@@ -196,29 +187,17 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
             // per transform point the K loop is only Cin / 32 tiles long, and the fold + the 5x input stream are paid per point:
             // measured at config 4 (direct -> transform + fused): Cin 512 2.00 -> 0.19 + 1.36 ms, 256 2.02 -> 0.35 + 1.37,
             // 128 2.15 -> 2 x (0.36 + 0.80) -- the 128-channel layers stay direct (BYOLO_WINO_SPLIT_MIN_C)
-            static const int min_c = [] { const char* e = getenv("BYOLO_WINO_SPLIT_MIN_C"); return e ? atoi(e) : 256; }();
-            if (on < 2 && l.Cin < min_c && !l.wino1d) continue;
+            if (on < 2 && l.Cin < h->opts.wino_split_min_c) continue;
             WinoPlan& w = p.wino[si];
             w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2; w.bm = bm; w.fused = true;
             w.bn = (bn_pref == 256 && bm == 64 && (l.filters % 256) == 0) ? 256 : 128;
             const int S = M / (l.H * l.W);
-            if (l.wino1d) {                                     // one-dimensional form: V [4][chunk * (H + 2) * tw rows][C]
-                w.oned = true; w.th = l.H; w.bm = 64; w.bn = 256;
-                const double per = 4.0 * (l.H + 2) * w.tw * l.Cin * 4.0;
-                const int nch = std::max(1, (int)std::ceil(S * per / budget));
-                w.chunk = (S + nch - 1) / nch;
-                const size_t R_pad = align_up((size_t)w.chunk * (l.H + 2) * w.tw, 128);
-                w.v_bytes = align_up((size_t)4 * R_pad * l.Cin * 4, 256);
-                if (w.v_bytes > CONV_MAX_SRC_BYTES) { w = WinoPlan{}; continue; }
-                wino_scratch = std::max(wino_scratch, w.v_bytes);
-                continue;
-            }
             const double per_sample = 16.0 * w.th * w.tw * l.Cin * 4.0;
             const int nchunks = std::max(1, (int)std::ceil(S * per_sample / budget));          // equal chunks
             w.chunk = (S + nchunks - 1) / nchunks;
             // BYOLO_WINO_SPLIT_ROUNDS=k (experiment): chunks whose fused launch is k whole rounds of resident workgroups, so that a
             // chunk's V (<= ~140 MB per round) is still in the Infinity Cache when the GEMM reads it
-            static const int rounds = [] { const char* e = getenv("BYOLO_WINO_SPLIT_ROUNDS"); return e ? atoi(e) : 0; }();
+            const int rounds = h->opts.wino_split_rounds;
             if (rounds > 0) {
                 const int slots = (w.bn == 256 ? 256 : 512), n_tiles = l.filters / w.bn;
                 const int64_t row_tiles = (int64_t)rounds * slots / n_tiles;                // of w.bm rows each
@@ -234,15 +213,14 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
             wino_scratch = std::max(wino_scratch, w.v_bytes);
         }
     }
-    { const char* e = getenv("BYOLO_WINOGRAD");
-      const int on = (h->precision == 1 || inject) ? 0 : (e ? atoi(e) : 1);   // split precision: direct convolutions only (memory-bound transforms do not pay there); injected masks: conv_igemm's epilogue reads them
-      const char* mf = getenv("BYOLO_WINO_MIN_GFLOP");                     // tuning knob: smallest layer (direct GFLOP) to transform
+    { const int on = (h->precision == 1 || inject) ? 0 : h->opts.winograd;   // split precision: direct convolutions only (memory-bound transforms do not pay there); injected masks: conv_igemm's epilogue reads them
+      // opts.wino_min_gflop: tuning knob: smallest layer (direct GFLOP) to transform
       // (measured at config 4: 100 -> 144.97, 20 -> 147.35, 5 -> 147.32 img/s; at config 2 (416x416, 8 images) the 52x52
       //  layers are 12.8 GFLOP: 20 -> 1375, 10 -> 1506, 5 -> 1504 img/s.  Default 10.)
-      const char* bm = getenv("BYOLO_WINO_CHUNK_MB");                      // tuning knob: V + M bytes of one chunk
+      // opts.wino_chunk_mb: tuning knob: V + M bytes of one chunk
       // (chunk budget measured at config 4: 2600 MB 177.6, 600 MB 179.4, 300 MB 150.6 img/s -- below ~500 MB the fused
       //  kernel's slots run out of row tiles; 800 MB keeps the scratch small without costing rounds)
-      const double min_flops = on >= 2 ? 0.0 : (mf ? atof(mf) : 10.0) * 1e9, budget = (bm ? atof(bm) : 800.0) * 1e6;   // on == 2: every eligible layer (tests)
+      const double min_flops = on >= 2 ? 0.0 : (double)h->opts.wino_min_gflop * 1e9, budget = (double)h->opts.wino_chunk_mb * 1e6;   // on == 2: every eligible layer (tests)
       for (size_t si = 0; on && si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
@@ -252,7 +230,7 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
         // The transforms stream 4x the input + 4x the output through HBM (measured 5.2 TB/s); per output pixel the GEMM
         // saves 5/9 of 2*9*Cin*cout FLOPs.  That pays when Cin*cout/(Cin+cout) is large: measured at config 4
         // 512x1024 channels (19x19) -33 %, 256x512 (38x38) -24 %, 128x256 (76x76) +6 % -> direct below ~128.
-        static const double min_ratio = [] { const char* e = getenv("BYOLO_WINO_MIN_RATIO"); return e ? atof(e) : 80.0; }();
+        const double min_ratio = (double)h->opts.wino_min_ratio;
         if (on < 2 && (double)l.Cin * l.filters / (l.Cin + l.filters) < min_ratio) continue;
         WinoPlan& w = p.wino[si];
         w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2;
@@ -263,8 +241,7 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
         // Fused kernel (wino_fused.hip; no M): its work unit is a row tile of 128 output tiles through all 16 transform
         // points, dealt out statically to 512 / (cout/64) slots -- pick the chunk size (samples) whose row-tile count
         // wastes the fewest slot rounds, and use the fused kernel only when every slot gets >= 3 row tiles.
-        const char* fe = getenv("BYOLO_WINO_FUSED");
-        const int fused_mode = fe ? atoi(fe) : 1;                              // 0 never, 2 always (tests); read per plan
+        const int fused_mode = h->opts.wino_fused;                             // 0 never, 2 always (tests)
         if (fused_mode && wino_fused_ok(l.Cin, l.filters)) {
             const int slots = 512 / (l.filters / 64), tt = w.th * w.tw;
             const int max_c = (int)std::max(1.0, std::min((double)S, std::floor(budget / (16.0 * tt * l.Cin * 4.0))));
@@ -284,17 +261,16 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
         w.m_bytes = w.fused ? 0 : align_up((size_t)16 * P_pad * l.filters * 4, 256);
         wino_scratch = std::max(wino_scratch, w.v_bytes + w.m_bytes);
         const int rows = (int)(16 * P_pad);
-        p.split[si] = conv_plan_split(rows, s.Npad, l.Cin / 32, s.tile);
+        p.split[si] = conv_plan_split(rows, s.Npad, l.Cin / 32, s.tile, 1.0, h->opts.ksplit, h->opts.streamk);
         p.tile[si] = s.tile;
         slab = std::max(slab, conv_split_slab_bytes(p.split[si], s.tile));
       }
     }
     // Row-streaming launch for the 1x1 / stride-1 convolutions over one plain source (gemm_stream.hip): the 1x1
     // convolutions of the heads, the concat convolutions' stacked half (STEP_MAIN) and the detection heads.
-    // BYOLO_STREAM1X1=0 keeps them on conv_igemm (A/B), =2 takes it for every shape the kernel can express (tests).
+    // opts.stream1x1 = 0 keeps them on conv_igemm (A/B), 2 takes it for every shape the kernel can express (tests).
     p.stream1x1.assign(h->steps.size(), 0);
-    { const char* e = getenv("BYOLO_STREAM1X1");
-      const bool on = h->precision == 0 && !inject && (!e || atoi(e) != 0), force = e && atoi(e) >= 2;
+    { const bool on = h->precision == 0 && !inject && h->opts.stream1x1 != 0, force = h->opts.stream1x1 >= 2;
       for (size_t si = 0; on && si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];

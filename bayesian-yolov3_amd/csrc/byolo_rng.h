@@ -39,6 +39,12 @@ BYOLO_HD uint32_t byolo_mix32(uint32_t x) {          // full lowbias32 (key deri
 
 struct byolo_drop_keys { uint32_t k0, k1, thr; };    // thr = thr16 in [0, 65535]
 
+// A rate whose 16-bit threshold rounds to 2^16 (p < 2^-17, p = 0 included) keeps EVERY element and scales by 1 / (1 - p) = 1 to
+// float32: tf.layers.dropout(rate=0) is the identity (lib_yolo/layers.py:521-524), and so is the layer here -- the callers do not
+// raise the dropout flag at all.  (The clamp of thr16 to 65535 below only guards the in-place compares' shift; without this rule it
+// would drop each element with probability 2^-16 at scale 1.)
+inline bool byolo_drop_is_identity(double drop_prob) { return (1.0 - drop_prob) * 65536.0 + 0.5 >= 65536.0; }
+
 inline byolo_drop_keys byolo_layer_keys(uint64_t seed, uint32_t layer, double drop_prob) {
     byolo_drop_keys k;
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);

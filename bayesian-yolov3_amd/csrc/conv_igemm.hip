@@ -1075,13 +1075,12 @@ static int tile_slots(int tile) { return 256 * (tile == TILE_128x256 ? 1 : (tile
 // the chip-time idle).  The tiles of that last partial round are therefore cut into `ksplit` K slices so that
 // they fill the chip once more with shorter blocks.  Cost model in tile-times of a whole tile; t_k, t_o from
 // DESIGN.md section 3 (per-K-tile and per-tile overhead), a slice pays the overhead + the hand-off fences.
-ConvSplit conv_plan_split(int M, int Npad, int KT, int tile, double tk_scale) {
+ConvSplit conv_plan_split(int M, int Npad, int KT, int tile, double tk_scale, int ksplit_knob, int streamk_knob) {
     const int BN = conv_tile_bn(tile), slots = tile_slots(tile);
     const int tiles = ((M + 127) / 128) * (Npad / BN);
     ConvSplit r; r.full_tiles = tiles; r.split_tiles = 0; r.ksplit = 1; r.split_blocks = 0; r.sk_grid = 0;
-    // BYOLO_KSPLIT: 0 = never split, n > 1 = always n slices (tests, A/B); read when a handle plans a (B, T)
-    const char* env = getenv("BYOLO_KSPLIT");
-    const int knob = env ? atoi(env) : -1;
+    // byolo_plan_opts.ksplit: -1 the cost model below, 0 = never split, n > 1 = always n slices (tests, A/B)
+    const int knob = ksplit_knob;
     // microseconds: K-tile and tile overhead of a whole tile, overhead of a slice (prologue, sc1 slab
     // round trip, ticket; measured on the 19x19 .. 76x76 head shapes and the small backbone launches)
     const double t_k = 1.8 * BN / 128.0 * tk_scale, t_o = 3.3, t_slice = 16.0;    // tk_scale: K unit of the launch relative to an fp32 K-tile
@@ -1091,9 +1090,8 @@ ConvSplit conv_plan_split(int M, int Npad, int KT, int tile, double tk_scale) {
     // CUs: a tile runs on ONE CU, however long its K loop) or pays a nearly empty last round (676 tiles on 512 slots
     // = 2 rounds for 1.32 rounds of work).  Here every resident workgroup takes an equal share of the launch's
     // tiles * KT K-tile units; cost in tile-times = share + hand-off of the (at most two) partial tiles of a workgroup.
-    // BYOLO_STREAMK: 0 never, 1 when the model predicts a gain (default), 2 whenever admissible (tests).
-    const char* se = getenv("BYOLO_STREAMK");
-    const int sk_knob = se ? atoi(se) : 1;
+    // byolo_plan_opts.streamk: 0 never, 1 when the model predicts a gain (default), 2 whenever admissible (tests).
+    const int sk_knob = streamk_knob;
     if (sk_knob && knob < 0 && KT >= 2) {
         const int64_t U = (int64_t)tiles * KT;
         int G = (int)std::min<int64_t>(slots, U / (sk_knob >= 2 ? 1 : 6)) & ~7;       // >= 6 K-tiles per workgroup
@@ -1134,9 +1132,8 @@ size_t conv_split_slab_bytes(const ConvSplit& sp, int tile) {
 
 // ConvParams::plain (finish_plain)
 static bool conv_epilogue_is_plain(const ConvParams& p) {
-    const char* e = getenv("BYOLO_PLAIN_EPILOGUE");      // A/B knob, read per launch (tests flip it inside one process): 0 = finish_tile everywhere
-    const bool off = e && atoi(e) == 0;
-    return !off && p.split == 1 && !p.addend && p.rep <= 1 && !(p.flags & (EPI_F32OUT | EPI_RAW)) && !p.mask_bits &&
+    // (p.no_plain: byolo_plan_opts.plain_epilogue = 0 -- finish_tile everywhere, the A/B of tests/test_gpu_parity.py)
+    return !p.no_plain && p.split == 1 && !p.addend && p.rep <= 1 && !(p.flags & (EPI_F32OUT | EPI_RAW)) && !p.mask_bits &&
            !((p.flags & EPI_RESIDUAL) && (p.flags & EPI_DROPOUT)) && ((p.N | p.ldc) & 3) == 0 && (p.N % 32) == 0;
 }
 
@@ -1158,15 +1155,12 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t st) {
         q.d_skq = make_fastdiv((uint32_t)q.sk_q); q.d_skq1 = make_fastdiv((uint32_t)q.sk_q + 1u); q.d_kt = make_fastdiv((uint32_t)p.KT);
         grid = q.sk_grid;
     }
-    // BYOLO_PERSIST = workgroups per CU of a persistent grid (0 = one workgroup per tile; tuning knob)
-    static const int persist = [] { const char* e = getenv("BYOLO_PERSIST"); return e ? atoi(e) : 0; }();
-    if (persist > 0 && q.sk_grid == 0 && grid > 256 * persist) grid = 256 * persist;
-    // the 8-wave tile runs ONE workgroup per CU: nothing covers the turn-over between two workgroups (dispatch, kernel-argument
-    // loads, address prologue) there, so its workgroups walk the tile list themselves.  BYOLO_WIDE_PERSIST=0: one workgroup per tile
+    // (a persistent grid for the 4-wave tiles measured +-0 in round 4 -- two workgroups per CU cover each other's turn-over -- and its
+    //  knob is gone.)  The 8-wave tile runs ONE workgroup per CU: nothing covers the turn-over between two workgroups (dispatch,
+    // kernel-argument loads, address prologue) there, so its workgroups walk the tile list themselves.
     if constexpr (BN == 256) {
         if (q.split_blocks != 0 || q.sk_grid != 0) return hipErrorInvalidValue;      // whole tiles only on this tile
-        static const int wide_persist = [] { const char* e = getenv("BYOLO_WIDE_PERSIST"); return e ? atoi(e) : 1; }();
-        if (wide_persist > 0 && q.sk_grid == 0 && grid > 256 * wide_persist) grid = 256 * wide_persist;
+        if (grid > 256) grid = 256;
     }
     const bool fast = p.C1 == 0 && p.sh0 == 0 && p.ksize <= 3;
     if (p.split != (SPLITCFG ? 1 : 0)) return hipErrorInvalidValue;

@@ -6,7 +6,7 @@
 // socket's power cap: the only way to a faster convolution is FEWER PRODUCTS.  F(2x2, 3x3) spends 16 multiplies per 2x2 output
 // tile and channel pair instead of 36:
 //
-//   V[xi][p][c] = (B^T d B)[xi]        wino_split_input_kernel: one 4x4 input patch per output tile p, fp32 arithmetic on the
+//   V[xi][p][c] = (B^T d B)[xi]        wino_split_input2_kernel: one 4x4 input patch per output tile p, fp32 arithmetic on the
 //                                      decoded hi + lo values, V stored as hi/lo pairs again (scale 1: |V| <= 4 |d| sits in
 //                                      the fp16 range the activations' 4 * value occupies)
 //   M[xi]       = V[xi] . U[xi]        wino_split_kernel: per transform point a 64 x 256 x C GEMM (per workgroup) on
@@ -22,9 +22,18 @@
 //
 // The default workgroup (8 waves side by side along N, each 64 x 32) owns 64 output tiles x 256 channels and keeps 4 x 32
 // output accumulators + 32 product accumulators per lane (about 230 registers, two waves per SIMD); the template also builds
-// 64 x 128 (4 waves) and 128 x 128 (4 waves of 128 x 32: 473 registers, one wave per SIMD; measured slower).  Five accumulator
-// sets per tile element pin the tile at 64 x 256 per CU, and its weight-fragment stream (32 KB per 768 matrix-pipe cycles through
-// the vector L1) is what bounds the launch: DESIGN.md 3.6.  Numerics: emulated around the oracle before the kernel was built
+// 64 x 128 (4 waves) for layers whose output channels are not a multiple of 256.  Five accumulator sets per tile element pin the
+// tile at 64 x 256 per CU, and its weight-fragment stream (32 KB per 768 matrix-pipe cycles through the vector L1) is what bounds
+// the launch: DESIGN.md section 3.  (Rounds 3 - 5 also carried a 128 x 128 workgroup -- 473 registers, one wave per SIMD, 298 against
+// 310 img/s --, a one-tile input transform and a one-dimensional F(2,3) form for the 128-channel layers, transform + GEMM 2.12 ms
+// against the direct kernel's 2.01: all three lost their A/Bs and are gone; profiles/HISTORY.md, profiles/r5_wino1d.md.)
+//
+// Round 6: the workgroups WALK the unit list (grid = resident workgroups; byolo_plan_opts.wino_split_persist).  A unit = 64 output
+// tiles x WINO_BN channels through all 16 points; the K-tile stream of a workgroup runs on across its units: while unit u multiplies
+// its last K-tiles, the V rows and U fragments of unit u + 1's first tiles are already being fetched, staged and read, so the pipeline
+// fill (5 loads + a barrier per unit) and the workgroup turn-over (dispatch, kernel arguments, address prologue: one workgroup per
+// CU, nothing covers it) are paid once per workgroup instead of once per unit.  Same K order, same arithmetic per output element:
+// the rows are the rows of the one-unit-per-workgroup launch bit for bit (wino_split_persist = 0; tools/rows_digest.py).  Numerics: emulated around the oracle before the kernel was built
 // (tests/test_split_numerics.py: 0.62 of the bound from float64 where float32 sits at 0.98).
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -46,59 +55,12 @@ using namespace pipe;
 static constexpr int WS_ABL = BYOLO_WS_ABLATE;
 
 // ---------------------------------------------------------------------------------------------------------------------
-// input transform: thread = (tile p, 4 channels): 16 x 16-byte loads, 16 x 16-byte stores; hi/lo groups in and out
+// input transform: thread = (sample, tile row, tile PAIR, 4 channels): 4 x 6 16-byte loads, 2 x 16 16-byte stores; hi/lo groups in
+// and out.  TWO horizontally adjacent output tiles per thread (round 5): their 4x4 patches share two of four columns -- a one-tile
+// thread re-read the input 2.5x through the fabric (measured, FETCH_SIZE: 0.68 GB per launch against 0.27 GB of input; every pixel
+// belongs to four patches and the L2 caught a third of the repeats).  The rows that pad V to P_pad are zeroed by the threads behind
+// the last pair.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino_split_input_kernel(const WinoParams p) {
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t c4n = (uint32_t)p.C >> 2;
-    const uint32_t t = fdiv(gid, p.d_c4), c4 = gid - t * c4n;
-    if (t >= (uint32_t)p.P_pad) return;
-    float* v = p.v + (size_t)t * p.C + c4 * 4;
-    const size_t xi_stride = (size_t)p.P_pad * p.C;
-    if (t >= (uint32_t)p.P) {                        // rows that pad the last row tile: zeros (they are multiplied, never stored)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(v + (size_t)k * xi_stride) = f32x4{0.f, 0.f, 0.f, 0.f};
-        return;
-    }
-    const uint32_t tt = (uint32_t)(p.th * p.tw);
-    const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
-    const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
-    const float* img = p.x + ((size_t)(p.s0 + s) * p.H * p.W) * p.C + c4 * 4;
-    const int y0 = 2 * (int)ty - 1, x0 = 2 * (int)tx - 1;
-    f32x4 d[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int y = y0 + i, x = x0 + j;
-            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            const f32x4 raw = ok ? *reinterpret_cast<const f32x4*>(img + ((size_t)y * p.W + x) * p.C) : f32x4{0.f, 0.f, 0.f, 0.f};
-            d[i][j] = epi::split_decode4(raw);       // ACT_SCALE * value, exact
-        }
-    f32x4 u[4][4];                                   // B^T d
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        u[0][j] = d[0][j] - d[2][j];
-        u[1][j] = d[1][j] + d[2][j];
-        u[2][j] = d[2][j] - d[1][j];
-        u[3][j] = d[1][j] - d[3][j];
-    }
-    // (B^T d) B, times 1 / ACT_SCALE (p.vmul, a power of two): |V| <= 4 |d| stays inside the range the inputs occupied
-    const float m = p.vmul;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 0) * xi_stride) = epi::split_encode4((u[i][0] - u[i][2]) * m);
-        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 1) * xi_stride) = epi::split_encode4((u[i][1] + u[i][2]) * m);
-        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 2) * xi_stride) = epi::split_encode4((u[i][2] - u[i][1]) * m);
-        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 3) * xi_stride) = epi::split_encode4((u[i][1] - u[i][3]) * m);
-    }
-}
-
-// The same transform, TWO horizontally adjacent output tiles per thread (round 5): their 4x4 patches share two of four columns, so a
-// thread loads 4 x 6 pixels instead of 2 x 16 -- the one-tile kernel re-read the input 2.5x through the fabric (measured, FETCH_SIZE:
-// 0.68 GB per launch against 0.27 GB of input; every pixel belongs to four patches and the L2 caught a third of the repeats).  Same
-// arithmetic per tile, operation for operation: V is bit-identical.  thread = (sample, tile row, tile PAIR, 4 channels); the rows that
-// pad V to P_pad are zeroed by the threads behind the last pair.
 __global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams p, const FastDiv d_twp, const FastDiv d_ttp, const int twp) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t c4n = (uint32_t)p.C >> 2;
@@ -154,207 +116,137 @@ __global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams
 }
 
 hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st) {
-    static const int pair = [] { const char* e = getenv("BYOLO_WINO_IN_PAIR"); return e ? atoi(e) : 1; }();
-    if (pair) {
-        const int twp = (p.tw + 1) / 2;
-        const uint64_t rows = (uint64_t)(p.P / (p.th * p.tw)) * p.th * twp + (uint64_t)(p.P_pad - p.P);
-        const uint64_t total = rows * (uint64_t)(p.C >> 2);
-        hipLaunchKernelGGL(wino_split_input2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p,
-                           make_fastdiv((uint32_t)twp), make_fastdiv((uint32_t)(p.th * twp)), twp);
-        return hipGetLastError();
-    }
-    const uint64_t total = (uint64_t)p.P_pad * (p.C >> 2);
-    hipLaunchKernelGGL(wino_split_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// ONE-DIMENSIONAL form, F(2,3) along W (round 5 experiment for the 128-channel 76x76 head convolutions):
-// V[xi][(s, yp, j)][c] = (B^T d)[xi] over the four pixels 2j-1 .. 2j+2 of image row yp - 1; rows yp = 0 and yp = H + 1 of every
-// sample are zeros (the filter rows above / below the image), so that the GEMM's operand for filter row ky is the SAME row
-// sequence ky padded rows further on -- no validity logic in its loader.  V is 2x the input (the 2-D form: 4x).
-// thread = (V row, 4 channels): 4 loads, 4 stores.  |V| <= 2 |d|: stored at scale 2 (vmul = 2 / ACT_SCALE), the range the inputs had.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino1d_input_kernel(const WinoParams p) {
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t c4n = (uint32_t)p.C >> 2;
-    const uint32_t t = fdiv(gid, p.d_c4), c4 = gid - t * c4n;
-    if (t >= (uint32_t)p.P_pad) return;
-    float* v = p.v + (size_t)t * p.C + c4 * 4;
-    const size_t xi_stride = (size_t)p.P_pad * p.C;
-    const uint32_t tt = (uint32_t)(p.th * p.tw);
-    const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
-    const uint32_t yp = fdiv(r, p.d_tw), j = r - yp * (uint32_t)p.tw;
-    const int y = (int)yp - 1;
-    if (t >= (uint32_t)p.P || (unsigned)y >= (unsigned)p.H) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(v + (size_t)k * xi_stride) = f32x4{0.f, 0.f, 0.f, 0.f};
-        return;
-    }
-    const float* row = p.x + (((size_t)(p.s0 + s) * p.H + y) * p.W) * p.C + c4 * 4;
-    const int x0 = 2 * (int)j - 1;
-    f32x4 d[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = x0 + k;
-        const f32x4 raw = (unsigned)x < (unsigned)p.W ? *reinterpret_cast<const f32x4*>(row + (size_t)x * p.C) : f32x4{0.f, 0.f, 0.f, 0.f};
-        d[k] = epi::split_decode4(raw);
-    }
-    const float m = p.vmul;
-    *reinterpret_cast<f32x4*>(v + 0 * xi_stride) = epi::split_encode4((d[0] - d[2]) * m);
-    *reinterpret_cast<f32x4*>(v + 1 * xi_stride) = epi::split_encode4((d[1] + d[2]) * m);
-    *reinterpret_cast<f32x4*>(v + 2 * xi_stride) = epi::split_encode4((d[2] - d[1]) * m);
-    *reinterpret_cast<f32x4*>(v + 3 * xi_stride) = epi::split_encode4((d[1] - d[3]) * m);
-}
-
-hipError_t launch_wino1d_input(const WinoParams& p, hipStream_t st) {
-    const uint64_t total = (uint64_t)p.P_pad * (p.C >> 2);
-    hipLaunchKernelGGL(wino1d_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    const int twp = (p.tw + 1) / 2;
+    const uint64_t rows = (uint64_t)(p.P / (p.th * p.tw)) * p.th * twp + (uint64_t)(p.P_pad - p.P);
+    const uint64_t total = rows * (uint64_t)(p.C >> 2);
+    hipLaunchKernelGGL(wino_split_input2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p,
+                       make_fastdiv((uint32_t)twp), make_fastdiv((uint32_t)(p.th * twp)), twp);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // fused GEMM + output transform + epilogue
 // ---------------------------------------------------------------------------------------------------------------------
-// WINO_BM = output tiles per workgroup (rows of the transform-domain GEMM): 64 -> 230 registers, two workgroups per CU;
-// 128 -> 473 registers (the outputs in the accumulator file), one workgroup per CU
-// WINO_BN = output channels per workgroup: 128 (4 waves) or 256 (8 waves side by side: ONE workgroup per CU stages a V row for 256
-// columns -- the column tiles of a row tile re-read V through the fabric, measured 4.7 GB per launch against 0.8 .. 1.4 GB of V)
-// ONED: the one-dimensional form (4 points, K = (filter row, chunk), two outputs per GEMM row; WinoSplitParams.oned)
-template <int WINO_BM, int WINO_BN, bool ONED = false>
-__global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split_kernel(const WinoSplitParams p) {
+// coefficient of point xi = (i, j) in output o = (a, b): cA(a, i) * cA(b, j), cA = A^T = [1 1 1 0; 0 1 -1 -1]
+__host__ __device__ constexpr int wino_cA(int a, int i) { return a == 0 ? (i < 3 ? 1 : 0) : (i == 0 ? 0 : (i == 1 ? 1 : -1)); }
+
+// WINO_BN = output channels per workgroup: 256 (8 waves side by side: ONE workgroup per CU stages a V row for 256 columns -- the
+// column tiles of a row tile re-read V through the fabric, measured 4.7 GB per launch against 0.8 .. 1.4 GB of V with 128) or 128
+// (4 waves, two workgroups per CU).  64 output tiles per workgroup (rows of the transform-domain GEMM): 230 registers.
+template <int WINO_BN>
+__global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSplitParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WINO_BM = 64;
     using BT = SplitTile<WINO_BM, WINO_BN, 1, WINO_BN / 32>;
-    constexpr int TM = BT::TM, A_LD = BT::A_LD;            // 4 row blocks of 32 per wave; 4 staging rows per thread
+    constexpr int TM = BT::TM, A_LD = BT::A_LD;            // 2 row blocks of 32 per wave; 1 (8 waves) or 2 staging rows per thread
     static_assert(BT::TN == 1, "one 32-column block per wave");
     const BT bt(smem);
 
-    // unit -> (row tile, column tile): the column tiles of a row tile are neighbours on one XCD (V rows shared in its L2)
-    const int nwg = (int)gridDim.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    // ---- this workgroup's units.  Workgroup b sits on XCD b & 7 (round-robin dispatch); the units are dealt out to the XCDs in
+    // contiguous ranges, and inside an XCD unit x0 + k goes to the XCD's workgroup k mod (its workgroups): what the workgroups of one
+    // XCD multiply at the same time are neighbouring units = the column tiles of a few row tiles (their V rows shared in that L2).
+    // One unit per workgroup (grid = units): the same code, the list has one entry.
+    const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t n_units = (uint32_t)p.units, uq = n_units >> 3, ur = n_units & 7u;
+    const uint32_t x0 = xcd * uq + (xcd < ur ? xcd : ur), xn = uq + (xcd < ur ? 1u : 0u);
+    const uint32_t ustep = (nwg >> 3) + (xcd < (nwg & 7u) ? 1u : 0u);
+    if (slot >= xn) return;
     const uint32_t n_tiles = (uint32_t)p.n_tiles;
-    const uint32_t unit = (uint32_t)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bi);
-    const uint32_t rt = fdiv(unit, p.d_ntiles), ct = unit - rt * n_tiles;
-
-    // ---- staging rows (V row = output tile index inside the chunk; every row of the padded extent exists) -------------
-    uint32_t a_voff[A_LD];
+    auto unit_of = [&](uint32_t k, uint32_t& rt, uint32_t& ct) __attribute__((always_inline)) { const uint32_t u = x0 + k; rt = fdiv(u, p.d_ntiles); ct = u - rt * n_tiles; };
+    // staging rows (V row = output tile index inside the chunk; every row of the padded extent exists)
+    auto voff_of = [&](uint32_t rt, uint32_t (&v)[A_LD]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j) {
-        uint32_t m = rt * (uint32_t)WINO_BM + (uint32_t)bt.a_r + (uint32_t)(BT::NT / 8) * j;
-        if constexpr (ONED) {                                  // output pair (s, y, jj) -> V row (s, yp = y [+ ky], jj) of the padded extent:
-            const uint32_t sm = fdiv(m, p.d_tt);               // two padded rows per earlier sample; the sample's own first padded row is ky = 0's
-            m += 2u * sm * (uint32_t)p.tw;
-        }
-        a_voff[j] = (m * (uint32_t)p.C + (uint32_t)bt.a_q * 4u) * 4u;
-    }
+        for (int j = 0; j < A_LD; ++j) v[j] = ((rt * (uint32_t)WINO_BM + (uint32_t)bt.a_r + (uint32_t)(BT::NT / 8) * j) * (uint32_t)p.C + (uint32_t)bt.a_q * 4u) * 4u;
+    };
     const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.v, p.v_bytes);
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, p.w_bytes);
-    // K-tile sequence: (xi, chunk); scalar offsets
     const uint32_t KT = (uint32_t)p.KT;
     const uint32_t w_step = (uint32_t)p.N * BK * 4;                        // one K-tile of all column blocks (N / 32 blocks of 4 KB)
-    uint32_t a_soff = 0, a_kt = 0, a_xi_base = 0;                          // the NEXT tile to load
-    uint32_t a_ky = 0, a_ky_off = 0;                                       // ONED: filter row of the next tile and its byte offset
-    const uint32_t CT = (uint32_t)p.C / BK;                                // ONED: chunks per filter row
-    uint32_t w_soff = ct * (WINO_BN / 32) * SPLIT_WBLOCK;
+
+    // ---- the two operand streams, each one sequence over ALL units of this workgroup: K-tile order (unit, point, chunk).
     // V streams from HBM (a chunk is far larger than the caches) and a K-tile of this tile is short (12 MFMAs per wave): the
     // activations of tile t + 1 + NSET are fetched while tile t multiplies, into a ring of NSET staging sets (timing ablation
-    // with one set: without the activation path the launch ran 35 % faster -- the loop was waiting for its loads)
-    constexpr int NSET = WINO_BM == 64 ? 4 : 2;
+    // with one set: without the activation path the launch ran 35 % faster -- the loop was waiting for its loads); the weight
+    // fragments of tile t + 1.  Past a unit's last tile the streams go on with the NEXT unit's first tiles; past the last unit's, with
+    // addresses beyond the buffers' extents -> zeros, staged and never multiplied.
+    constexpr int NSET = WINO_BN == 256 ? 4 : 2;       // (the 4-wave workgroup stages two rows per thread and sits at 256 registers: a ring of two)
     f32x4 a_reg[NSET][A_LD];
     f16x8 bfr[2][2][1][2];
-    auto next_tile = [&]() {
-        if constexpr (ONED) {
-            a_soff = a_xi_base + a_ky_off + a_kt * (BK * 4);
-            if (++a_kt == CT) { a_kt = 0; a_ky_off += p.ky_stride; if (++a_ky == 3) { a_ky = 0; a_ky_off = 0; a_xi_base += p.xi_stride; } }
-        } else {
-            a_soff = a_xi_base + a_kt * (BK * 4);
-            if (++a_kt == KT) { a_kt = 0; a_xi_base += p.xi_stride; }      // past point 15: beyond v_bytes -> zeros
-        }
-    };
-    auto load_a = [&](auto set_tag) {
+    uint32_t a_voff[A_LD];                                                 // a lane's staging rows inside a row tile (the same for every unit)
+    voff_of(0u, a_voff);
+    // V stream, all scalar and branch-free (a branch inside the K loop splits the accumulators' live ranges: the first build with one
+    // spilled 850 bytes per lane): the NEXT tile to load = (row tile's byte offset) + (point's) + (chunk's); when the unit's last tile
+    // has been issued the stream moves to the row tile of this workgroup's next unit, which the unit loop has looked up (a_next_base)
+    uint32_t a_base, a_soff, a_kt = 0, a_pt = 0, a_xi_base = 0, a_next_base = 0, a_has_next = 0;
+    uint32_t w_soff = 0;                                                   // U stream: the next tile's offset (set at every unit's start)
+    const uint32_t rt_bytes = (uint32_t)WINO_BM * (uint32_t)p.C * 4u;
+    { uint32_t rt, ct; unit_of(slot, rt, ct); a_base = rt * rt_bytes; a_soff = a_base; }
+    auto load_a = [&](auto set_tag) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) a_reg[decltype(set_tag)::value][j] = buffer_load_x4(a_rsrc, a_voff[j], a_soff);
+        ++a_kt;
+        const uint32_t wrap = a_kt == KT ? 1u : 0u;
+        a_kt = wrap ? 0u : a_kt;
+        a_xi_base += wrap ? p.xi_stride : 0u;
+        a_pt += wrap;
+        const uint32_t roll = (a_pt == 16u ? 1u : 0u) & a_has_next;        // (without a next unit: on beyond V's extent, never multiplied)
+        a_pt = roll ? 0u : a_pt;
+        a_xi_base = roll ? 0u : a_xi_base;
+        a_base = roll ? a_next_base : a_base;
+        a_soff = a_base + a_xi_base + a_kt * (BK * 4);
     };
-    auto load_b = [&](auto set_tag) { bt.load_b(bfr[decltype(set_tag)::value], w_rsrc, w_soff); w_soff += w_step; };
+    // (the weight fragments do NOT run on across units: 32 registers that would have to live through the epilogue, which has none to
+    //  spare -- the build with them spilled 1.2 KB per lane; a unit's first fragments are fetched behind the previous unit's epilogue:
+    //  one L2 round trip per unit.  What a unit's last K-tile fetches lies beyond U's extent: zeros, never used.)
+    auto load_b = [&](auto set_tag) __attribute__((always_inline)) { bt.load_b(bfr[decltype(set_tag)::value], w_rsrc, w_soff); w_soff += w_step; };
 
-    constexpr int NOUT = ONED ? 2 : 4, NPT = ONED ? 4 : 16;
-    f32x16 Y[NOUT][TM], M[TM][1];
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Y[o][i][r] = 0.f;
-
+    f32x16 Y[4][TM], M[TM][1];
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    using c3 = std::integral_constant<int, 3>;
     f16x8 af0[TM][2], af1[TM][2];
-    next_tile(); load_a(c0{}); load_b(c0{});
+    load_a(c0{});
     bt.template store_a<0>(a_reg[0]);
-    {   // tiles 1 .. NSET wait in the sets 1 .. NSET - 1, 0
-        next_tile(); load_a(std::integral_constant<int, 1 % NSET>{});
-        next_tile(); load_a(std::integral_constant<int, 2 % NSET>{});
-        if constexpr (NSET == 4) { next_tile(); load_a(std::integral_constant<int, 3>{}); next_tile(); load_a(c0{}); }
-    }
+    if constexpr (NSET == 4) { load_a(c1{}); load_a(c2{}); load_a(c3{}); load_a(c0{}); }       // tiles 1 .. NSET wait in the sets 1 .. NSET - 1, 0
+    else { load_a(c1{}); load_a(c0{}); }
     __syncthreads();
-    bt.template read_frags<0, 0>(af0);
 
     // one K-tile in LDS buffer BUF: the uniform body of the split pipeline (mfma_pipe.h tile_body_split) -- stage tile t+1,
-    // fetch tile t+2 and the weight fragments of t+1; past the end the loads read zeros and what they stage is never used
+    // fetch tile t+1+NSET and the weight fragments of t+1
     // K-tile t: LDS buffer BUF = t & 1; tile t + 1 is staged from set SET = (t + 1) % NSET, which then receives tile t + 1 + NSET
-    auto ktile = [&](auto buf_tag, auto set_tag) {
+    auto ktile = [&](auto buf_tag, auto set_tag) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
         using ST = decltype(set_tag);
         pipe::tile_body_split<BUF, true, (WS_ABL & 1) ? 0 : BT::NBF, (WS_ABL & 4) ? 0 : A_LD, (WS_ABL & 4) ? 0 : A_LD, ((WS_ABL & 16) ? 4 : 0) | ((WS_ABL & 32) ? 8 : 0)>(
-            bt, M, af0, af1, bfr[(WS_ABL & 1) ? 0 : BUF], [&] { load_b(std::integral_constant<int, BUF ^ 1>{}); },
-            [&] { next_tile(); load_a(ST{}); }, [&] { if constexpr (!(WS_ABL & 4)) bt.template store_a<BUF ^ 1>(a_reg[ST::value]); });
+            bt, M, af0, af1, bfr[(WS_ABL & 1) ? 0 : BUF], [&]() __attribute__((always_inline)) { load_b(std::integral_constant<int, BUF ^ 1>{}); },
+            [&]() __attribute__((always_inline)) { load_a(ST{}); }, [&]() __attribute__((always_inline)) { if constexpr (!(WS_ABL & 4)) bt.template store_a<BUF ^ 1>(a_reg[ST::value]); });
     };
-    auto run_point = [&]() {
+    auto run_point = [&]() __attribute__((always_inline)) {
         if constexpr (!(WS_ABL & 8)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) M[i][0][r] = 0.f;
         }
-        using c2 = std::integral_constant<int, 2>;
-        using c3 = std::integral_constant<int, 3>;
         if constexpr (NSET == 4) { for (uint32_t kt = 0; kt < KT; kt += 4) { ktile(c0{}, c1{}); ktile(c1{}, c2{}); ktile(c0{}, c3{}); ktile(c1{}, c0{}); } }
         else { for (uint32_t kt = 0; kt < KT; kt += 2) { ktile(c0{}, c1{}); ktile(c1{}, c0{}); } }
     };
-    // fold M into the four outputs: Y[a][b] += cA(a, i) * cA(b, j) * M for point xi = (i, j), cA = A^T = [1 1 1 0; 0 1 -1 -1].
-    // The coefficients (0, +-1) are block-uniform scalars and every point runs the SAME 4 x 32 fused multiply-adds: a switch
-    // over 16 specialised folds (36 of the 64 (point, output) pairs are non-zero) made the register allocator copy the output
-    // accumulators at the join and spill.
-    auto cA = [](int a, int i) -> float { return a == 0 ? (i < 3 ? 1.f : 0.f) : (i == 0 ? 0.f : (i == 1 ? 1.f : -1.f)); };
-    for (int xi = 0; xi < NPT; ++xi) {
-        run_point();
-        const int I = xi >> 2, J = xi & 3;
-        if constexpr (WS_ABL & 2) { if (xi != NPT - 1) continue; }
-        // as packed fp32 fused multiply-adds (v_pk_fma_f32: two accumulators per instruction, IEEE per element): fp32 vector
-        // instructions are paid in full in matrix-pipe time on this part (tools/mfma_valu_coexec_probe.hip), the fold is 128 of them per point
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            const float c = ONED ? cA(o, xi) : cA(o >> 1, I) * cA(o & 1, J);       // ONED: Y = A^T M along W only
-            const f32x2 c2 = {c, c};
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const f32x2 y2 = __builtin_elementwise_fma(c2, f32x2{M[i][0][r], M[i][0][r + 1]}, f32x2{Y[o][i][r], Y[o][i][r + 1]});
-                    Y[o][i][r] = y2[0]; Y[o][i][r + 1] = y2[1];
-                }
-        }
-    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 
     // ---- epilogue: lane = output tile li (+32 per block), 4 groups of 4 consecutive channels from 4 * lh (mfma_pipe.h) ----
     // Straight-line per dropout mode (0 none, 1 the library's hash, 2 injected bits), decided ONCE: vector instructions are paid in
     // matrix-pipe time, and a block-uniform branch per channel group costs scalar spills and hazard no-ops (conv_igemm.hip finish_plain)
-    auto epilogue = [&](auto mode_tag) {
+    auto epilogue = [&](auto mode_tag, uint32_t rt, uint32_t ct) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
         const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
         const uint32_t tt = (uint32_t)(p.th * p.tw);
-        const int nb = (int)(ct * WINO_BN) + bt.wn * 32 + 4 * bt.lh;
+        // the lane's position from a thread index the compiler cannot see through: otherwise everything the epilogue derives from it
+        // is hoisted out of the unit loop and lives in registers through all K loops, which have none to spare (896 spilled bytes)
+        int tid_e = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid_e));
+        const int e_wn = tid_e >> 6, e_li = tid_e & 31, e_lh = (tid_e >> 5) & 1;
+        const int nb = (int)(ct * WINO_BN) + e_wn * 32 + 4 * e_lh;
         float vmax = 0.f;
         f32x4 sc4[4], sf4[4];
 #pragma unroll
@@ -364,13 +256,13 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const uint32_t t = rt * (uint32_t)WINO_BM + (uint32_t)i * 32u + (uint32_t)bt.li;
+            const uint32_t t = rt * (uint32_t)WINO_BM + (uint32_t)i * 32u + (uint32_t)e_li;
             if (t >= (uint32_t)p.P) continue;
             const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
             const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                const uint32_t oy = ONED ? ty : 2 * ty + (o >> 1), ox = 2 * tx + (ONED ? o : (o & 1));
+            for (int o = 0; o < 4; ++o) {
+                const uint32_t oy = 2 * ty + (o >> 1), ox = 2 * tx + (o & 1);
                 if (oy >= (uint32_t)p.H || ox >= (uint32_t)p.W) continue;
                 const uint64_t pix = ((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox;
                 const uint64_t idx_row = p.idx_base + pix * (uint64_t)p.N + (uint64_t)nb;
@@ -397,26 +289,71 @@ __global__ __launch_bounds__(WINO_BN * 2, WINO_BM == 64 ? 2 : 1) void wino_split
         }
         if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
     };
-    if (!(p.flags & EPI_DROPOUT)) epilogue(std::integral_constant<int, 0>{});
-    else if (p.mask_bits) epilogue(std::integral_constant<int, 2>{});
-    else epilogue(std::integral_constant<int, 1>{});
+
+    for (uint32_t k = slot; k < xn; k += ustep) {
+        uint32_t rt, ct; unit_of(k, rt, ct);
+        a_has_next = k + ustep < xn ? 1u : 0u;
+        { uint32_t rt2, ct2; unit_of(a_has_next ? k + ustep : k, rt2, ct2); a_next_base = rt2 * rt_bytes; }
+        // the unit's first weight fragments, and (again: the last K-tile of the unit before read them already, into registers the
+        // epilogue then took) the activation fragments of its first K-tile, which sits in LDS buffer 0 since that K-tile's barrier
+        __builtin_amdgcn_sched_barrier(0);
+        w_soff = ct * (WINO_BN / 32) * SPLIT_WBLOCK;
+        load_b(c0{});
+        bt.template read_frags<0, 0>(af0);
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[o][i][r] = 0.f;
+            // fold M into the four outputs: Y[a][b] += cA(a, i) * cA(b, j) * M for point xi = (i, j), cA = A^T = [1 1 1 0; 0 1 -1 -1].
+            // The coefficients (0, +-1) are block-uniform scalars and every point runs the SAME 4 x 32 fused multiply-adds, as packed
+            // fp32 operations (v_pk_fma_f32: two accumulators per instruction, IEEE per element): fp32 vector instructions are paid in full
+            // in matrix-pipe time on this part (tools/mfma_valu_coexec_probe.hip), the fold is 64 of them per point.  Only 36 of the 64
+            // (point, output) pairs are non-zero, but the two ways to issue just those both cost more than they save: a switch over
+            // specialised folds makes the register allocator copy the output accumulators at the join and spill (round 3); the point loop
+            // unrolled 16 x with compile-time coefficients (round 6) is 70 KB of code for a 64 KB instruction cache and still spilled 565
+            // bytes per lane (16 copies of the K loop, each with 160 accumulator registers live across it).
+            for (int xi = 0; xi < 16; ++xi) {
+                run_point();
+                if constexpr (WS_ABL & 2) { if (xi != 15) continue; }
+                const int I = xi >> 2, J = xi & 3;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const float c = (float)(wino_cA(o >> 1, I) * wino_cA(o & 1, J));
+                    const f32x2 cc = {c, c};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const f32x2 y2 = __builtin_elementwise_fma(cc, f32x2{M[i][0][r], M[i][0][r + 1]}, f32x2{Y[o][i][r], Y[o][i][r + 1]});
+                            Y[o][i][r] = y2[0]; Y[o][i][r + 1] = y2[1];
+                        }
+                }
+            }
+        if (!(p.flags & EPI_DROPOUT)) epilogue(std::integral_constant<int, 0>{}, rt, ct);
+        else if (p.mask_bits) epilogue(std::integral_constant<int, 2>{}, rt, ct);
+        else epilogue(std::integral_constant<int, 1>{}, rt, ct);
+    }
 }
 
 bool wino_split_ok(int C, int N) { return C >= 128 && (C % 128) == 0 && N >= 128 && (N % 128) == 0; }     // K-tiles in groups of 4
 
-template <int WINO_BM, int WINO_BN, bool ONED = false>
-static hipError_t launch_wino_split_bm(const WinoSplitParams& p, hipStream_t st) {
-    using BT = SplitTile<WINO_BM, WINO_BN, 1, WINO_BN / 32>;
-    auto k = wino_split_kernel<WINO_BM, WINO_BN, ONED>;
+template <int WINO_BN>
+static hipError_t launch_wino_split_bn(const WinoSplitParams& p, hipStream_t st) {
+    using BT = SplitTile<64, WINO_BN, 1, WINO_BN / 32>;
+    auto k = wino_split_kernel<WINO_BN>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = set_dynamic_lds_once(reinterpret_cast<const void*>(k), BT::LDS_BYTES, attr_done); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((unsigned)p.units), dim3(WINO_BN * 2), BT::LDS_BYTES, st, p);
+    // persistent: as many workgroups as the chip holds at once (256 CUs x 1 workgroup of 8 waves, or x 2 of 4 waves)
+    const int resident = 256 * (WINO_BN == 256 ? 1 : 2);
+    const int grid = (p.persist && p.units > resident) ? resident : p.units;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(WINO_BN * 2), BT::LDS_BYTES, st, p);
     return hipGetLastError();
 }
 hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st) {
-    if (p.oned) return (p.bn == 256 && p.bm == 64) ? launch_wino_split_bm<64, 256, true>(p, st) : hipErrorInvalidValue;
-    if (p.bn == 256) return p.bm == 64 ? launch_wino_split_bm<64, 256>(p, st) : hipErrorInvalidValue;
-    return p.bm == 64 ? launch_wino_split_bm<64, 128>(p, st) : launch_wino_split_bm<128, 128>(p, st);
+    if (p.bm != 64) return hipErrorInvalidValue;
+    return p.bn == 256 ? launch_wino_split_bn<256>(p, st) : launch_wino_split_bn<128>(p, st);
 }
 
 }  // namespace byk

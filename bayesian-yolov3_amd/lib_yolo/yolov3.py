@@ -183,7 +183,8 @@ class bayesian_yolov3_aleatoric(_Yolo):
     def __init__(self, config):
         self._aleatoric_loss = config['aleatoric_loss']          # required keys (yolov3.py:456, :461)
         self._inference_mode = config['inference_mode']
-        self._drop_prob = 0.1                                      # yolov3.py:462
+        # yolov3.py:462 hard-codes 0.1; the build lets engine_options['drop_prob'] override it (0 = tf.layers.dropout(rate=0) = identity)
+        self._drop_prob = float(config.get('engine_options', {}).get('drop_prob', 0.1))
         if self._inference_mode:
             self._T = config['T']
         self._standard_test_dropout = config.get('standard_test_dropout', False)

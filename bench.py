@@ -52,6 +52,10 @@ CONFIGS = {   # BASELINE.json configs[0..4]  (per-GPU batch)
     5: dict(variant="bayesian_yolov3_aleatoric", H=1024, W=1024, B=1, T=50, nms=1),
     # the reference's own default frame (inference_epistemic.py:218, full ECP image), not a BASELINE line
     6: dict(variant="bayesian_yolov3_aleatoric", H=1024, W=1920, B=1, T=50, nms=1),
+    # the reference's own default workloads of the two non-epistemic scripts (inference_aleatoric.py:219-227,
+    # inference_standard_yolov3.py:210-218): the full ECP frame, batch_size 11, class-agnostic NMS -- not BASELINE lines either
+    7: dict(variant="yolov3_aleatoric", H=1024, W=1920, B=11, T=1, nms=0),
+    8: dict(variant="yolov3", H=1024, W=1920, B=11, T=1, nms=0),
 }
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA = 2500e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense (no sparsity)
@@ -665,7 +669,7 @@ def main():
                                           "arithmetic in this run") if eng.precision == "split" else
                                          "fp32 operands on v_mfma_f32_32x32x2_f32, Winograd F(2x2,3x3) on the large 3x3 layers"},
         }
-        SPLIT = (4256, 3256, 3128, 3064, 2128, 2064, 1128, 1064, 1032, 140, 141)
+        SPLIT = (4256, 3256, 3128, 3064, 2128, 2064, 1128, 1064, 1032, 140)
         KERNELS = {4256: "conv_igemm_kernel<128,256,1,8,kx3>+fused_tail (split-f16 3x3/stride-1 on shared-tap stages with the following 1x1 convolution / detection head fused in; BYOLO_B2B)",
                    3256: "conv_igemm_kernel<128,256,1,8,kx3> (split-f16 3x3/stride-1 on shared-tap stages, 8 waves; BYOLO_KX3_WIDE)",
                    3128: "conv_igemm_kernel<128,128,1,4,kx3> (split-f16 3x3/stride-1 on shared-tap stages, v_mfma_f32_32x32x16_f16 x3)",
@@ -674,8 +678,7 @@ def main():
                    2064: "conv_igemm_kernel<128,64,2,2,p1> (split-f16 1x1 convolutions / detection heads on the uniform loop)",
                    1128: "conv_igemm_kernel<128,128,1,4,split> (split-f16 1x1 / stride-2 / two-source convolutions)",
                    1064: "conv_igemm_kernel<128,64,2,2,split>", 1032: "conv_igemm_kernel<128,32,4,1,split>",
-                   140: "wino_split_kernel (Winograd F(2x2,3x3) in split-f16: transform-domain GEMM + output transform + epilogue, v_mfma_f32_32x32x16_f16 x3)",
-                   141: "wino_split_kernel<64,256,ONED> (1-D Winograd F(2,3) along W in split-f16, three filter rows direct; BYOLO_WINO1D experiment)",
+                   140: "wino_split_kernel (Winograd F(2x2,3x3) in split-f16: transform-domain GEMM + output transform + epilogue, v_mfma_f32_32x32x16_f16 x3; workgroups walk the unit list)",
                    130: "wino_fused_kernel (Winograd-domain GEMM + output transform + epilogue, fp32 v_mfma_f32_32x32x2_f32)",
                    129: "gemm_stream_kernel<128,0> (Winograd-domain GEMM, fp32 v_mfma_f32_32x32x2_f32)",
                    131: "gemm_stream_kernel<128,1> (row-streaming 1x1 convolution)",
@@ -794,7 +797,9 @@ def main():
         if world == 1 and not args.no_other_configs and args.config == 4 and not args.batch and args.scaling == "weak":
             line["other_configs"] = {}
             for num, name, orc in ((1, "configs[0]", "f64"), (2, "configs[1]", "f64"), (3, "configs[2]", "f64"), (5, "configs[4]", "f32"),
-                                   (6, "reference default frame (inference_epistemic.py:218-221)", False)):
+                                   (6, "reference default frame (inference_epistemic.py:218-221)", False),
+                                   (7, "reference default aleatoric workload (inference_aleatoric.py:219-227: 1024x1920, batch_size 11)", False),
+                                   (8, "reference default standard workload (inference_standard_yolov3.py:210-218: 1024x1920, batch_size 11)", False)):
                 try:
                     line["other_configs"][name] = other_config_leg(num, device, oracle=orc and not args.no_cpu_baseline and (orc if num != 5 or not args.quick_parity else False))
                 except Exception as e:

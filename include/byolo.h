@@ -90,6 +90,59 @@ BYOLO_API const char* byolo_version(void);
 #define BYOLO_ABI_VERSION 6
 BYOLO_API int32_t byolo_abi_version(void);
 
+/* ---- the plan of a handle: which kernel carries which layer, and how a forward is put on the stream -------------------------------
+ * The reference leaves all of this to TensorFlow's placer and kernel registry (`sess.run`, inference_epistemic.py:76); here it is a
+ * per-HANDLE struct, so that two handles in one process may differ and nothing outside a handle steers it.  byolo_create fills it
+ * with the defaults below and then applies the environment variables named in brackets (the A/B switches of tools/ and tests/;
+ * read ONCE, at byolo_create, never again); byolo_set_plan_opts replaces it.  Fields marked [pack] change what byolo_finalize packs:
+ * set them before byolo_finalize (a finalized handle is marked un-finalized when one of them changes); the others may change between
+ * forwards (the next forward plans again).  Every setting computes the layer functions of lib_yolo/layers.py:545-575; settings that
+ * change the order of a floating-point sum (split-K, stream-K, Winograd on / off) change results within the fp32 re-association
+ * error, all others bit for bit -- tests/test_gpu_parity.py holds each of them to the oracle. */
+typedef struct byolo_plan_opts {
+    int32_t struct_bytes;          /* sizeof(byolo_plan_opts) of the caller's header: a mismatch is BYOLO_ERR_ARG                      */
+    int32_t graphs;                /* launch-graph replay of a whole forward: 0 never, 1 forwards that do not fill the chip by
+                                      themselves (< 1 TFLOP: detect.py's batch-1 loop, BASELINE configs[0..1]; default), 2 every forward
+                                      that can be captured [BYOLO_GRAPHS]                                                             */
+    int32_t serialize_convs;       /* forwards of one handle on several streams: convolution stacks one after the other: 0 never,
+                                      1 forwards of >= 1 TFLOP (default), 2 always [BYOLO_SERIALIZE_CONVS]                            */
+    int32_t dedup;                 /* [pack] T-invariant de-duplication (a convolution over a T-fold tile runs once per image): 1
+                                      [BYOLO_NO_DEDUP inverts]                                                                        */
+    int32_t lowmain;               /* [pack] the 1x1 convolution over an upsampled source at the source's resolution: 1 [BYOLO_LOWMAIN] */
+    int32_t kx3, p1;               /* [pack] split-f16 K loops: shared-tap 3x3 stages / uniform 1x1 loop: 1, 1 [BYOLO_KX3, BYOLO_P1]   */
+    int32_t b2b;                   /* 3x3 + following 1x1 in one launch (76x76 head pairs): 0 never, 1 launches of >= 4 rounds
+                                      (default), 2 every eligible pair [BYOLO_B2B]                                                    */
+    int32_t kx3_wide;              /* the 8-wave 128 x 256 shared-tap tile without a follower: 0 (default; measured 4 % slower), 1, 2
+                                      [BYOLO_KX3_WIDE]                                                                                */
+    int32_t wino_split;            /* Winograd F(2x2,3x3) in split-f16: 0 never, 1 layers >= wino_split_min_gflop with >=
+                                      wino_split_min_c input channels (default), 2 every eligible layer [BYOLO_WINO_SPLIT]            */
+    int32_t wino_split_min_c;      /* 256 [BYOLO_WINO_SPLIT_MIN_C]                                                                    */
+    int32_t wino_split_bn;         /* output channels per workgroup: 256 (8 waves; default) or 128 [BYOLO_WINO_SPLIT_BN]              */
+    int32_t wino_split_rounds;     /* experiment: chunks of k whole rounds of workgroups, 0 = off [BYOLO_WINO_SPLIT_ROUNDS]           */
+    int32_t winograd;              /* fp32 mode: Winograd for the large 3x3 layers: 0, 1 (default), 2 every eligible [BYOLO_WINOGRAD] */
+    int32_t wino_fused;            /* fp32 mode: GEMM + output transform in one kernel: 0, 1 (default), 2 [BYOLO_WINO_FUSED]          */
+    int32_t stream1x1;             /* fp32 mode: row-streaming 1x1 launches: 0, 1 (default), 2 [BYOLO_STREAM1X1]                      */
+    int32_t gemm_stream;           /* fp32 mode: the unfused Winograd GEMM on the row-streaming kernel: 1 [BYOLO_GEMM_STREAM]         */
+    int32_t ksplit;                /* split-K of a launch's last partial round: -1 the cost model (default), 0 never, n > 1 always n
+                                      slices [BYOLO_KSPLIT]                                                                           */
+    int32_t streamk;               /* stream-K for small launches: 0 never, 1 the cost model (default), 2 whenever admissible
+                                      [BYOLO_STREAMK]                                                                                 */
+    int32_t plain_epilogue;        /* straight-line epilogues of the split-f16 convolutions (one decision per tile): 1; 0 = the general
+                                      epilogue everywhere (A/B; the same bits) [BYOLO_PLAIN_EPILOGUE]                                 */
+    int32_t wino_split_persist;    /* the Winograd GEMM's workgroups walk the unit list themselves, next unit prefetched: 0 | 1
+                                      [BYOLO_WINO_SPLIT_PERSIST]                                                                      */
+    float   wino_split_min_gflop;  /* 200 [BYOLO_WINO_SPLIT_MIN_GFLOP]                                                                */
+    float   wino_split_chunk_mb;   /* V bytes of one chunk: 1500 [BYOLO_WINO_SPLIT_CHUNK_MB]                                          */
+    float   wino_min_gflop;        /* fp32 mode: 10 [BYOLO_WINO_MIN_GFLOP]                                                            */
+    float   wino_chunk_mb;         /* fp32 mode: V + M bytes of one chunk: 800 [BYOLO_WINO_CHUNK_MB]                                  */
+    float   wino_min_ratio;        /* fp32 mode: Cin * cout / (Cin + cout) at least: 80 [BYOLO_WINO_MIN_RATIO]                        */
+} byolo_plan_opts;
+BYOLO_API int32_t byolo_get_plan_opts(const byolo_t* h, byolo_plan_opts* out);       /* out->struct_bytes is set                     */
+BYOLO_API int32_t byolo_set_plan_opts(byolo_t* h, const byolo_plan_opts* opts);
+/* Launch graphs kept by the handle (one per distinct argument set of a replayed forward; at most 8, least recently used dropped) and
+ * how often a forward was replayed / captured / updated in place (a forward whose dropout seed differs from the captured one). */
+BYOLO_API int32_t byolo_graph_stats(const byolo_t* h, int32_t* n_graphs, int64_t* replays, int64_t* captures, int64_t* updates);
+
 /* ---- graph construction: one call per ModelBuilder.make_* (lib_yolo/model.py:52-185).
  * Each returns the new layer's index (>= 0) in the reference's `ModelBuilder.__layers` numbering
  * (model.py:40-41) or a negative error.  Layer references (`shortcut`, `routes`, `src`) follow

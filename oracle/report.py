@@ -14,8 +14,9 @@ RTOL = ATOL = 1e-4      # BASELINE.json north_star: coords / scores / sigma with
 #             float32 arithmetic gets.  F > 1 occurs in ONE place: exp(logvar) of a single pass (T = 1, BASELINE configs[1]),
 #             F = 1.37 -- there the device's fp32 MODE measures E = 1.03 (the excess is float32's own: VERDICT r4 asked which), the
 #             default split-f16 mode E = 0.75.  Everywhere else the literal 1 applies (largest measured E: 0.70).
-#   D(g) <= max(1, F(g)) + F(g)     the device against the FLOAT32 CPU evaluation where F was measured: both are within max(1, F) of the
-#             exact value, so they are that far plus F apart at most.  Two float32-grade evaluations of an ill-conditioned column
+#   D(g) <= max(1, F(g)) + F(g)     the device against the FLOAT32 CPU evaluation where F was measured, FOR THE exp(logvar) GROUPS (and any group
+#             whose F itself exceeds 1): both are within max(1, F) of the exact value, so they are that far plus F apart at most.
+#             Every other group -- coordinates, scores, entropies: values bounded by 1 -- is held to the literal 1 against float32 too.  Two float32-grade evaluations of an ill-conditioned column
 #             are NOT within one bound of each other (configs[1], image 0: F = 1.01, E = 0.64, D = 1.27) -- which also holds between
 #             the reference's TensorFlow kernels and any other float32 evaluation, this repo's CPU oracle included -- so a claim
 #             of D <= 1 there would be a claim about rounding luck, not about the arithmetic.
@@ -71,7 +72,11 @@ def allowance(floor=None, against="float64"):
         return {}
     if against == "float64":
         return {k: max(1.0, v["worst_in_bounds"]) for k, v in floor.items()}
-    return {k: max(1.0, v["worst_in_bounds"]) + v["worst_in_bounds"] for k, v in floor.items()}
+    # against the float32 run: max(1, F) + F for the UNBOUNDED groups only -- exp(logvar) columns, the one place two float32-grade
+    # evaluations are not within one bound of each other -- and wherever F itself was measured above 1; coordinates, scores and
+    # entropies are bounded by 1 and stay at the literal 1.0 (measured <= 0.7): a wider allowance there would only hide a
+    # regression
+    return {k: (max(1.0, v["worst_in_bounds"]) + v["worst_in_bounds"]) if ("(exp)" in k or v["worst_in_bounds"] > 1.0) else 1.0 for k, v in floor.items()}
 
 
 def check(rep, allowed=None):

@@ -54,6 +54,12 @@ def keep_threshold(drop_prob):
     return np.uint32(min(65535, int((1.0 - float(np.float32(drop_prob))) * 65536.0 + 0.5)))
 
 
+def is_identity(drop_prob):
+    """A rate whose 16-bit threshold rounds to 2^16 keeps everything (csrc/byolo_rng.h byolo_drop_is_identity): rate 0 is the
+    identity, as tf.layers.dropout(rate=0) is."""
+    return (1.0 - float(np.float32(drop_prob))) * 65536.0 + 0.5 >= 65536.0
+
+
 def next_word(h0):
     """The second 32 mask bits of a group from its first."""
     with np.errstate(over="ignore"):
@@ -81,6 +87,8 @@ def pair_hash(g, k0, k1):
 def keep_mask(seed, layer, shape, drop_prob=0.1, offset=0):
     """Boolean keep-mask for a dropout input of NHWC `shape` (element order = C order)."""
     n = int(np.prod(shape))
+    if is_identity(drop_prob):
+        return np.ones(shape, dtype=bool)
     idx = np.arange(offset, offset + n, dtype=np.uint64)
     k0, k1 = layer_keys(seed, layer)
     h = pair_hash(idx >> np.uint64(2), k0, k1)
@@ -94,6 +102,8 @@ def keep_mask_torch(seed, layer, shape, drop_prob=0.1, offset=0, chunk=1 << 24):
     the large tensors of the CPU baseline.  Bit-identical to keep_mask (tests/test_oracle.py)."""
     import torch
     n = int(np.prod(shape))
+    if is_identity(drop_prob):
+        return torch.ones(shape, dtype=torch.bool)
     k0, k1 = (int(v) for v in layer_keys(seed, layer))
     thr = int(keep_threshold(drop_prob))
     M = 0xFFFFFFFF

@@ -77,7 +77,7 @@ def _oracle_images(cfgnum, cfg, imgs, which, seed, f64=False):
     return refs
 
 
-def _compare(cfgnum, cfg, eng, imgs, out, which, seed, what, f64=True):
+def _compare(cfgnum, cfg, eng, imgs, out, which, seed, what, f64=True, f64_all=False):
     """THE PARITY CONTRACT (oracle/report.py) at a benched shape.  With a float64 run (`f64`: the first image of `which`): the
     device within max(1, F(g)) of it and within max(1, F(g)) + F(g) of the float32 oracle, F = that oracle's own distance from the
     float64 run measured here (F <= 0.45 at T >= 10: the literal bound).  The other images, and shapes whose float64 image takes minutes of host time: within the literal
@@ -95,8 +95,14 @@ def _compare(cfgnum, cfg, eng, imgs, out, which, seed, what, f64=True):
         rep64 = assert_rows_close(boxes[i], ref64, cfg["variant"], "%s image %d vs the float64 oracle" % (what, i), allowed=allowance(floor))
         print("%s image %d: device vs float64: %s | float32 oracle vs float64: %s" % (what, i, format_report(rep64), format_report(floor)))
     for k, (i, ref) in enumerate(ref32.items()):
+        fl = floor if k == 0 else None
+        if f64 and f64_all and k > 0:                     # T = 1 shapes: every compared image gets its own float64 run and floor
+            r64 = _oracle_images(cfgnum, cfg, imgs, (i,), seed, f64=True)[i]
+            fl = rows_report(ref, r64, cfg["variant"])
+            record_parity("%s image %d: float32 oracle vs float64 oracle (the floor)" % (what, i), fl)
+            assert_rows_close(boxes[i], r64, cfg["variant"], "%s image %d vs the float64 oracle" % (what, i), allowed=allowance(fl))
         rep = assert_rows_close(boxes[i], ref, cfg["variant"], "%s image %d vs the float32 oracle" % (what, i),
-                                allowed=allowance(floor, "float32") if (f64 and k == 0) else None)
+                                allowed=allowance(fl, "float32") if (f64 and fl is not None) else None)
         print("%s image %d: device vs float32: %s" % (what, i, format_report(rep)))
     _check_nms_against_oracle(boxes, out, cfg["variant"], two_class=bool(cfg["nms"]))     # every image of the batch
 
@@ -202,3 +208,28 @@ def test_config5_as_benched(precision):
     if precision == "split":
         assert any(s["variant"] == 3128 for s in launches)
     _compare(5, cfg, eng, imgs, out, (0,), 1000, "config 5 (1024x1024 T=50 2-class)", f64=False)
+
+
+@pytest.mark.parametrize("cfgnum,rows_d", [(7, 16), (8, 7)])
+def test_reference_default_batched_workloads(cfgnum, rows_d):
+    """The reference's OWN default workloads of the two non-epistemic scripts: `yolov3_aleatoric` (inference_aleatoric.py:219-227) and
+    `yolov3` (inference_standard_yolov3.py:210-218) on the full 1024 x 1920 ECP frame with `batch_size` 11 -- 11 x 120 960 boxes
+    through the batched NMS of inference_aleatoric.py:104-145 / inference_standard_yolov3.py:104-145 (VERDICT r5 "missing" 2: the
+    product mirrored the literal, nothing ran it at size).  First and last image of the batch against the float64 and the float32
+    oracle (each image's float64 run sets that image's allowances: with T = 1 the sigma columns are exp(logvar) of ONE pass and the
+    float32 evaluation itself sits ~1.4 bounds from float64 there, oracle/report.py; every bounded group is held to the literal
+    1.0); the tail of ALL 11 images bit-exact against the oracle NMS on the device's rows.  The reference's
+    `tf.concat` of the per-image results (inference_aleatoric.py:137-143) only exists when every image keeps the same number of
+    boxes; the product hands out [B, 1000, D] padded rows + a count per image (include/byolo.h byolo_forward), which is that tensor
+    whenever it exists: checked below on the counts."""
+    cfg, eng, imgs, out, launches = _step(cfgnum)
+    B = cfg["B"]
+    assert B == 11 and out["boxes"].shape == (11, 120960, rows_d)
+    print("config %d launch variants:" % cfgnum, _variants(launches))
+    _compare(cfgnum, cfg, eng, imgs, out, (0, B - 1), 1000, "reference default %s workload (1024x1920 B=11)" % cfg["variant"], f64_all=True)
+    counts = out["count"][:, 0].cpu().numpy()
+    rows = out["rows"].cpu().numpy()
+    assert (counts >= 1).all() and (counts <= 1000).all()
+    for b in range(B):                                   # rows beyond an image's count are padding: zeros, never stale rows
+        assert not rows[b, counts[b]:].any()
+    print("config %d: kept per image %s (the reference's tf.concat needs them equal: %s)" % (cfgnum, counts.tolist(), len(set(counts.tolist())) == 1))

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import (REPO, RTOL, ATOL, golden, golden_params, golden_images, build_model, assert_close, format_report,
+from conftest import (REPO, RTOL, ATOL, _literal_tol, golden, golden_params, golden_images, build_model, assert_close, format_report,
                       assert_rows_close_vs_oracle)
 
 pytestmark = pytest.mark.gpu
@@ -97,6 +97,12 @@ def test_forward_vs_golden(variant, precision):
         if precision == "f32":
             efix = assert_close(got, fix, "%s layer %d vs the float32 fixture (%s)" % (variant, i, precision))
         else:
+            # ... and ASSERTED against the fixture at what the contract derives from this very fixture: max(1, F) + F bounds, F = the
+            # fixture's own distance from the float64 run in units of the bound (a printed distance guards nothing)
+            tol = _literal_tol(ref64, ATOL, RTOL)
+            F = float((np.abs(fix - ref64) / tol).max())
+            D = float((np.abs(got - fix) / _literal_tol(fix, ATOL, RTOL)).max())
+            assert D <= max(1.0, F) + F, "%s layer %d vs the float32 fixture: %.2f bounds, allowed max(1, F) + F = %.2f (F = %.2f)" % (variant, i, D, max(1.0, F) + F, F)
             efix = float(np.abs(got - fix).max())
         print("%s layer %d (%s): |err| vs float64 %.2e; vs the float32 fixture %.2e (the fixture vs float64: %.2e)"
               % (variant, i, precision, e64, efix, np.abs(fix - ref64).max()))
@@ -426,6 +432,116 @@ def test_dropout_quirk_and_determinism():
     assert not torch.equal(o3["boxes"], o5["boxes"])
 
 
+def test_drop_prob_zero_is_the_identity():
+    """tf.layers.dropout(rate=0) is the identity (lib_yolo/layers.py:521-524): a handle created with drop_prob = 0 (reachable through
+    engine_options and the C-ABI; the reference hard-codes 0.1) gives the bits of dropout_on=False -- the 16-bit threshold's clamp to
+    65535 alone would drop one element in 65 536 at scale 1."""
+    torch = _torch()
+    v = "bayesian_yolov3_aleatoric"
+    _, ref, _, _ = _run(v, 1, dropout_on=False)
+    _, off, _, _ = _run(v, 1, dropout_on=False, drop_prob=0.0)
+    _, on, _, _ = _run(v, 1, dropout_on=True, drop_prob=0.0)
+    assert torch.equal(ref["boxes"], off["boxes"])
+    assert torch.equal(off["boxes"], on["boxes"]) and torch.equal(off["kept"], on["kept"])
+    _, on2, _, _ = _run(v, 1, dropout_on=True, seed=43, drop_prob=0.0)
+    assert torch.equal(on["boxes"], on2["boxes"])           # no stream is drawn at all
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_launch_graph_replay_equals_the_eager_forward(variant, precision):
+    """include/byolo.h byolo_plan_opts.graphs: a forward that does not fill the chip (detect.py's batch-1 loop, detect.py:112-135;
+    BASELINE configs[0..1]) is captured into a launch graph the second time its arguments are seen and replayed from then on -- one
+    hipGraphLaunch instead of ~85 launches.  The rows, kept indices and counts of a replayed forward are the eager forward's bit
+    for bit; another dropout seed updates the graph in place (hipGraphExecUpdate) and gives THAT seed's eager bits; another output
+    buffer is another graph; profiling and graphs = 0 run eagerly."""
+    torch = _torch()
+    B = 1 if variant.startswith("bayes") else 2
+    params = golden_params(variant)
+    _, m = build_model(variant, 64, 96, T=3, params=params, engine_options=dict(keep_all_outputs=False))
+    m.finalize()
+    eng = m.engine
+    assert eng.plan_opts()["graphs"] == 1
+    x = torch.from_numpy(golden_images(B)).cuda()
+    N, D = eng.num_boxes()
+    mk = lambda: {"boxes": torch.empty((B, N, D), device="cuda"), "rows": torch.empty((B, eng.out_cap, D), device="cuda"),
+                  "kept": torch.empty((B, eng.out_cap), dtype=torch.int32, device="cuda"), "count": torch.empty((B, 2), dtype=torch.int32, device="cuda")}
+    snap = lambda o: [o[k].clone() for k in ("boxes", "rows", "kept", "count")]
+    eng.set_graphs(False)
+    ref = {seed: snap(eng.forward(x, T=3, seed=seed, want_boxes=True, out=mk())) for seed in (42, 43)}
+    assert eng.graph_stats() == dict(graphs=0, replays=0, captures=0, updates=0)
+    eng.set_graphs(True)
+    out = mk()
+    for i in range(4):                                   # eager, capture, replay, replay
+        for t in out.values():
+            t.fill_(-7)
+        got = snap(eng.forward(x, T=3, seed=42, want_boxes=True, out=out))
+        for a, b in zip(got, ref[42]):
+            assert torch.equal(a, b), "forward %d differs from the eager one" % i
+    st = eng.graph_stats()
+    assert st["graphs"] == 1 and st["captures"] == 1 and st["replays"] == 2, st
+    draws = variant.startswith("bayes")
+    got = snap(eng.forward(x, T=3, seed=43, want_boxes=True, out=out))      # Bayesian model: other masks -> the graph's kernel arguments change
+    for a, b in zip(got, ref[43]):
+        assert torch.equal(a, b)
+    assert (ref[43][0] != ref[42][0]).any().item() == draws
+    st = eng.graph_stats()
+    assert (st["updates"], st["replays"]) == ((1, 2) if draws else (0, 3)), st
+    out2 = mk()                                          # other buffers: a second graph, after one eager sight
+    for i in range(3):
+        got = snap(eng.forward(x, T=3, seed=42, want_boxes=True, out=out2))
+        for a, b in zip(got, ref[42]):
+            assert torch.equal(a, b)
+    assert eng.graph_stats()["graphs"] == 2
+    eng.set_profiling(2)                                 # per-launch profiling: eager, with a launch list
+    eng.forward(x, T=3, seed=42, want_boxes=True, out=out)
+    torch.cuda.synchronize()
+    assert len(eng.step_profile()) > 60
+    eng.set_profiling(0)
+    before = eng.graph_stats()["replays"]
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):                          # a graph is replayed on whatever stream the caller is on
+        s2.wait_stream(torch.cuda.current_stream())
+        got = snap(eng.forward(x, T=3, seed=42, want_boxes=True, out=out))
+    s2.synchronize()
+    for a, b in zip(got, ref[42]):
+        assert torch.equal(a, b)
+    assert eng.graph_stats()["replays"] == before + 1
+    eng.close()
+
+
+def test_the_persistent_unit_walk_computes_the_same_bits(precision):
+    """wino_split.hip, round 6: the Winograd GEMM's workgroups walk the unit list with the next unit's first K-tiles prefetched
+    (byolo_plan_opts.wino_split_persist) -- the same K order and arithmetic per output element as one workgroup per unit: rows, raw
+    kept indices bit for bit, at a shape with several units per workgroup (608 x 608, T = 30, 2 images: 376 / 678 units on 256
+    workgroups) and on two handles IN ONE PROCESS whose plans differ only in that option."""
+    _default_precision_only(precision, "Winograd in split arithmetic belongs to the default precision")
+    torch = _torch()
+    from byolo import synth
+    v = "bayesian_yolov3_aleatoric"
+    outs = []
+    for persist in (1, 0):
+        _, m = build_model(v, 608, 608, T=30, params=None)
+        eng = m.engine
+        eng.set_params(synth.base_params(eng.param_shapes(), v, 2, seed=7))
+        eng.set_plan_opts(wino_split_persist=persist)
+        m.finalize()
+        if not outs:
+            eng.calibrate_bn(torch.from_numpy(synth.synthetic_images(2, 608, 608, seed=999)).cuda())
+            params = eng.get_params()
+        else:
+            eng.set_params(params)
+            m.finalize()
+        eng.set_profiling(2)
+        out = eng.forward(torch.from_numpy(synth.synthetic_images(2, 608, 608, seed=1234)).cuda(), T=30, seed=42, want_boxes=True)
+        torch.cuda.synchronize()
+        assert sum(1 for s in eng.step_profile() if s["variant"] == 140) == 6
+        eng.set_profiling(0)
+        outs.append([out[k].cpu().numpy() for k in ("boxes", "rows", "kept", "count")])
+        eng.close()
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_workspace_reuse_matches_keep_all():
     """The liveness-planned (buffer-reusing) workspace gives the same bits as one buffer per layer."""
     torch = _torch()
@@ -561,11 +677,11 @@ def test_winograd_on_every_eligible_layer(variant, fused, monkeypatch, precision
     assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
 
 
-@pytest.mark.parametrize("variant,bm,bn", [(v, "64", "256") for v in VARIANTS] + [(VARIANTS[2], "64", "128"), (VARIANTS[2], "128", "128")])
-def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, bn, monkeypatch, precision):
+@pytest.mark.parametrize("variant,bn,persist", [(v, "256", "1") for v in VARIANTS] + [(VARIANTS[2], "128", "1"), (VARIANTS[2], "256", "0"), (VARIANTS[2], "128", "0")])
+def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bn, persist, monkeypatch, precision):
     """Default precision: the large 3x3 / stride-1 head convolutions as Winograd F(2x2,3x3) in split-f16 arithmetic
     (csrc/wino_split.hip: hi/lo input transform, then GEMM + output transform + epilogue in one launch).  BYOLO_WINO_SPLIT=2
-    forces it on EVERY eligible layer, both workgroup shapes: odd grids (2x3 ... 8x12 pad to 2x2 tiles), dropout and BN-only
+    forces it on EVERY eligible layer, both workgroup shapes, with and without the persistent unit walk: odd grids (2x3 ... 8x12 pad to 2x2 tiles), dropout and BN-only
     layers.  Same rows as the fixtures of the reference's graph at the same bound, close to the direct path, and the launch
     list shows the fused kernel."""
     if precision != "split":
@@ -574,9 +690,10 @@ def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, bn, m
     monkeypatch.setenv("BYOLO_WINO_SPLIT", "0")
     _, direct, _, _ = _run(variant, B, keep_all=False)
     monkeypatch.setenv("BYOLO_WINO_SPLIT", "2")
-    monkeypatch.setenv("BYOLO_WINO_SPLIT_BM", bm)
     monkeypatch.setenv("BYOLO_WINO_SPLIT_BN", bn)
+    monkeypatch.setenv("BYOLO_WINO_SPLIT_PERSIST", persist)        # 1: the workgroups walk the unit list (round 6; at 64 x 96 a list of one or two units)
     m, wino, params, imgs = _run(variant, B)
+    assert m.engine.plan_opts()["wino_split_bn"] == int(bn) and m.engine.plan_opts()["wino_split_persist"] == int(persist)
     m.engine.set_profiling(2)
     torch = _torch()
     m.run(torch.from_numpy(imgs).cuda(), seed=42)
@@ -590,38 +707,6 @@ def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bm, bn, m
         assert_close(dl.raw_output.cpu().numpy(), g["raw_%d" % k], "%s raw det output %d (winograd, split)" % (variant, k))
     assert_close(wino["boxes"].cpu().numpy(), gb, "%s pre-NMS rows (winograd, split)" % variant)
     assert_close(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy(), "%s winograd vs direct (split)" % variant)
-    assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
-
-
-@pytest.mark.parametrize("variant", [VARIANTS[2], VARIANTS[1]])
-def test_one_dimensional_winograd_in_split_arithmetic(variant, monkeypatch, precision):
-    """Round 5 experiment (BYOLO_WINO1D=1): the 128-channel 3x3 / stride-1 convolutions without a fused residual --
-    the three stride-8 head convolutions, 76x76 at the benchmark's size -- as ONE-DIMENSIONAL Winograd F(2,3) along W with the
-    three filter rows direct (wino_split.hip wino1d_input_kernel + wino_split_kernel<64,256,ONED>): 12 products per output pair
-    instead of 18, V twice the input instead of four times.  Forced onto every such layer (BYOLO_WINO_SPLIT=2) beside the 2-D form
-    on the others: the launch list shows variant 141, rows and raw detection outputs hold the fixtures of the reference's graph at
-    the literal bound, and differ from the direct path's (it really ran)."""
-    if precision != "split":
-        pytest.skip("Winograd in split arithmetic belongs to the default precision")
-    B = 1 if variant.startswith("bayes") else 2
-    monkeypatch.setenv("BYOLO_WINO_SPLIT", "0")
-    _, direct, _, _ = _run(variant, B, keep_all=False)
-    monkeypatch.setenv("BYOLO_WINO_SPLIT", "2")
-    monkeypatch.setenv("BYOLO_WINO1D", "1")
-    m, wino, params, imgs = _run(variant, B)
-    m.engine.set_profiling(2)
-    torch = _torch()
-    m.run(torch.from_numpy(imgs).cuda(), seed=42)
-    torch.cuda.synchronize()
-    v = [s["variant"] for s in m.engine.step_profile()]
-    m.engine.set_profiling(0)
-    assert v.count(141) == 3 and v.count(-6) == 3 and v.count(140) >= 6, "one-dimensional Winograd launches: %s" % v
-    g = golden("fwd_%s.npz" % variant)
-    gb = g["bbox"] if g["bbox"].ndim == 3 else g["bbox"][None]
-    for k, dl in enumerate(m.det_layers):
-        assert_close(dl.raw_output.cpu().numpy(), g["raw_%d" % k], "%s raw det output %d (1-D winograd, split)" % (variant, k))
-    assert_close(wino["boxes"].cpu().numpy(), gb, "%s pre-NMS rows (1-D winograd, split)" % variant)
-    assert_close(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy(), "%s 1-D winograd vs direct (split)" % variant)
     assert not np.array_equal(wino["boxes"].cpu().numpy(), direct["boxes"].cpu().numpy())     # it really ran
 
 

@@ -161,6 +161,10 @@ def test_rng_definition():
     """The dropout stream: known answers + torch fast path == numpy definition + offset semantics."""
     assert int(rng.keep_threshold(0.1)) == 58982            # round((1 - float32(0.1)) * 2^16)
     assert int(rng.keep_threshold(0.0)) == 65535 and int(rng.keep_threshold(1.0)) == 0       # thr16 << 16 fits a word
+    # ... and a rate whose threshold rounds to 2^16 is the IDENTITY, as tf.layers.dropout(rate=0) is (the clamp alone would drop
+    # one element in 65536 at scale 1): csrc/byolo_rng.h byolo_drop_is_identity
+    assert rng.is_identity(0.0) and rng.is_identity(2.0 ** -18) and not rng.is_identity(2.0 ** -16) and not rng.is_identity(0.1)
+    assert rng.keep_mask(42, 3, (2, 3, 4, 64), drop_prob=0.0).all() and bool(rng.keep_mask_torch(42, 3, (2, 3, 4, 64), drop_prob=0.0).all())
     k0, k1 = rng.layer_keys(42, 0)
     assert (int(k0), int(k1)) == (int(rng.mix32(np.uint32(42 ^ 0x9E3779B9))), int(rng.mix32(np.uint32((0 + int(k0) + 0) & 0xFFFFFFFF))))
     m = rng.keep_mask(42, 3, (4, 5, 6, 32))

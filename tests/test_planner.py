@@ -91,7 +91,7 @@ def check_plan(steps, tensors, arena, what):
 
 
 KNOBS = {"BYOLO_B2B": ("0", "1", "2"), "BYOLO_LOWMAIN": ("0", "1"), "BYOLO_NO_DEDUP": ("0", "1"), "BYOLO_WINO_SPLIT": ("0", "1", "2"),
-         "BYOLO_WINOGRAD": ("0", "1"), "BYOLO_KX3_WIDE": ("0", "2"), "BYOLO_WINO1D": ("0", "1")}
+         "BYOLO_WINOGRAD": ("0", "1"), "BYOLO_KX3_WIDE": ("0", "2")}
 
 
 @pytest.mark.parametrize("precision", ["split", "f32"])
