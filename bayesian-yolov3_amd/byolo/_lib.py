@@ -28,9 +28,9 @@ class Cfg(ctypes.Structure):
 class PlanOpts(ctypes.Structure):
     """include/byolo.h byolo_plan_opts (field for field; tests/test_abi.py compares the two)."""
     _fields_ = [(n, ctypes.c_int32) for n in (
-        "struct_bytes", "graphs", "serialize_convs", "dedup", "lowmain", "kx3", "p1", "b2b", "kx3_wide", "wino_split", "wino_split_min_c",
+        "struct_bytes", "graphs", "serialize_convs", "serialize_heads", "dedup", "lowmain", "kx3", "p1", "b2b", "kx3_wide", "wino_split", "wino_split_min_c",
         "wino_split_bn", "wino_split_rounds", "winograd", "wino_fused", "stream1x1", "gemm_stream", "ksplit", "streamk",
-        "plain_epilogue", "wino_split_persist")] + [(n, ctypes.c_float) for n in (
+        "plain_epilogue", "wshift_per_layer", "nms_general", "wino_split_persist")] + [(n, ctypes.c_float) for n in (
         "wino_split_min_gflop", "wino_split_chunk_mb", "wino_min_gflop", "wino_chunk_mb", "wino_min_ratio")]
 
 

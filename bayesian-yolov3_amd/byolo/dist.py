@@ -86,6 +86,21 @@ def agree_on_error(err, src=0):
     return err if err is not None else RuntimeError("rank %d failed: %s" % (src, box[0]))
 
 
+def agree_on_any_error(err):
+    """Every rank passes an exception (or None); if ANY rank has one, every rank gets one back (its own, or a RuntimeError naming the
+    first failing rank) -- for a step every rank takes at the same point of the job and any of them may fail at (building the fp32
+    twin handle: a second weight pack and workspace on a nearly full GPU).  No-op without a process group."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return err
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, repr(err) if err is not None else None)
+    bad = [(r, m) for r, m in enumerate(box) if m is not None]
+    if not bad:
+        return None
+    return err if err is not None else RuntimeError("rank %d failed: %s" % bad[0])
+
+
 def shard_range(n_items, rank, world):
     """Contiguous block of the batch axis owned by `rank` (first ranks get the remainder)."""
     q, r = divmod(n_items, world)

@@ -61,7 +61,7 @@ class Engine:
 
     def set_plan_opts(self, **kw):
         """Change plan options of THIS handle (byolo_set_plan_opts): e.g. set_plan_opts(graphs=0, wino_split=2).  Options that change
-        what finalize() packs (dedup, lowmain, kx3, p1) un-finalize the handle: call finalize() again."""
+        what finalize() packs (dedup, lowmain, kx3, p1, wshift_per_layer) un-finalize the handle: call finalize() again."""
         o = _lib.PlanOpts()
         check(self._h, lib.byolo_get_plan_opts(self._h, ctypes.byref(o)))
         for k, v in kw.items():
@@ -69,7 +69,7 @@ class Engine:
                 raise KeyError("byolo_plan_opts has no field %r" % k)
             setattr(o, k, v)
         check(self._h, lib.byolo_set_plan_opts(self._h, ctypes.byref(o)))
-        if any(k in kw for k in ("dedup", "lowmain", "kx3", "p1")):
+        if any(k in kw for k in ("dedup", "lowmain", "kx3", "p1", "wshift_per_layer")):
             self.finalized = False
 
     def set_graphs(self, on):

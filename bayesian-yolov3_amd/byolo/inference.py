@@ -350,6 +350,19 @@ class InferenceLoop:
         if self.cuda:
             torch.cuda.synchronize(self.dev)                      # ... while the re-runs' copy_status sits on the slots' streams
         self.stats['precision_switches'] += 1                     # -> fp32
+        # the fp32 twin handle (a second weight pack + workspace arena) is built HERE, by every rank at the same point, and the ranks
+        # agree that it exists before any of them enters the re-run's collective: a rank whose allocation fails would otherwise raise
+        # alone and leave its peers waiting in the all-gather
+        from byolo import dist as bdist
+        err = None
+        try:
+            if hasattr(eng, 'twin'):
+                eng.twin('f32')
+        except Exception as e:
+            err = e
+        err = bdist.agree_on_any_error(err)
+        if err is not None:
+            raise err
         redo = self._enqueue(jobs[0]['shard'], jobs[0]['step'], jobs[0]['slot'], precision='f32')
         if not self._complete(redo):
             raise RuntimeError('BYOLO_ERR_RANGE in the fp32 mode: a raw detection output is inf / NaN (batch %d)' % jobs[0]['step'])

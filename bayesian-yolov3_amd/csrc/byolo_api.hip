@@ -63,9 +63,9 @@ extern "C" int32_t byolo_create(const byolo_cfg* cfg, int32_t device, byolo_t** 
 static void plan_opts_defaults(byolo_plan_opts& o) {
     memset(&o, 0, sizeof o);
     o.struct_bytes = (int32_t)sizeof o;
-    o.graphs = 1; o.serialize_convs = 1; o.dedup = 1; o.lowmain = 1; o.kx3 = 1; o.p1 = 1; o.b2b = 1; o.kx3_wide = 0;
+    o.graphs = 1; o.serialize_convs = 1; o.serialize_heads = 1; o.dedup = 1; o.lowmain = 1; o.kx3 = 1; o.p1 = 1; o.b2b = 1; o.kx3_wide = 0;
     o.wino_split = 1; o.wino_split_min_c = 256; o.wino_split_bn = 256; o.wino_split_rounds = 0;
-    o.winograd = 1; o.wino_fused = 1; o.stream1x1 = 1; o.gemm_stream = 1; o.ksplit = -1; o.streamk = 1; o.plain_epilogue = 1; o.wino_split_persist = 1;
+    o.winograd = 1; o.wino_fused = 1; o.stream1x1 = 1; o.gemm_stream = 1; o.ksplit = -1; o.streamk = 1; o.plain_epilogue = 1; o.wino_split_persist = 0;
     o.wino_split_min_gflop = 200.f; o.wino_split_chunk_mb = 1500.f; o.wino_min_gflop = 10.f; o.wino_chunk_mb = 800.f; o.wino_min_ratio = 80.f;
 }
 // The environment is the default filler of a NEW handle and nothing else: the A/B scripts under tools/ and the tests set a variable,
@@ -73,13 +73,14 @@ static void plan_opts_defaults(byolo_plan_opts& o) {
 static void plan_opts_from_env(byolo_plan_opts& o) {
     auto geti = [](const char* name, int32_t& v) { if (const char* e = getenv(name)) v = atoi(e); };
     auto getf = [](const char* name, float& v) { if (const char* e = getenv(name)) v = (float)atof(e); };
-    geti("BYOLO_GRAPHS", o.graphs); geti("BYOLO_SERIALIZE_CONVS", o.serialize_convs);
+    geti("BYOLO_GRAPHS", o.graphs); geti("BYOLO_SERIALIZE_CONVS", o.serialize_convs); geti("BYOLO_SERIALIZE_HEADS", o.serialize_heads);
     if (const char* e = getenv("BYOLO_NO_DEDUP")) o.dedup = atoi(e) ? 0 : 1;
     geti("BYOLO_LOWMAIN", o.lowmain); geti("BYOLO_KX3", o.kx3); geti("BYOLO_P1", o.p1); geti("BYOLO_B2B", o.b2b); geti("BYOLO_KX3_WIDE", o.kx3_wide);
     geti("BYOLO_WINO_SPLIT", o.wino_split); geti("BYOLO_WINO_SPLIT_MIN_C", o.wino_split_min_c); geti("BYOLO_WINO_SPLIT_BN", o.wino_split_bn);
     geti("BYOLO_WINO_SPLIT_ROUNDS", o.wino_split_rounds); geti("BYOLO_WINOGRAD", o.winograd);
     geti("BYOLO_WINO_FUSED", o.wino_fused); geti("BYOLO_STREAM1X1", o.stream1x1); geti("BYOLO_GEMM_STREAM", o.gemm_stream);
     geti("BYOLO_KSPLIT", o.ksplit); geti("BYOLO_STREAMK", o.streamk); geti("BYOLO_PLAIN_EPILOGUE", o.plain_epilogue); geti("BYOLO_WINO_SPLIT_PERSIST", o.wino_split_persist);
+    geti("BYOLO_WSHIFT_PER_LAYER", o.wshift_per_layer); geti("BYOLO_NMS_GENERAL", o.nms_general);
     getf("BYOLO_WINO_SPLIT_MIN_GFLOP", o.wino_split_min_gflop); getf("BYOLO_WINO_SPLIT_CHUNK_MB", o.wino_split_chunk_mb);
     getf("BYOLO_WINO_MIN_GFLOP", o.wino_min_gflop); getf("BYOLO_WINO_CHUNK_MB", o.wino_chunk_mb); getf("BYOLO_WINO_MIN_RATIO", o.wino_min_ratio);
 }
@@ -102,11 +103,11 @@ extern "C" int32_t byolo_set_plan_opts(byolo_t* h, const byolo_plan_opts* o) {
     if (o->graphs < 0 || o->graphs > 2 || o->serialize_convs < 0 || o->serialize_convs > 2 || o->b2b < 0 || o->b2b > 2 || o->kx3_wide < 0 || o->kx3_wide > 2 ||
         o->wino_split < 0 || o->wino_split > 2 || o->winograd < 0 || o->winograd > 2 || o->wino_fused < 0 || o->wino_fused > 2 || o->stream1x1 < 0 || o->stream1x1 > 2 ||
         o->streamk < 0 || o->streamk > 2 || o->ksplit < -1 || o->ksplit > 64 || (o->wino_split_bn != 128 && o->wino_split_bn != 256) ||
-        o->wino_split_rounds < 0 || !(o->wino_split_chunk_mb > 0.f) || !(o->wino_chunk_mb > 0.f) || !(o->wino_split_min_gflop >= 0.f) || !(o->wino_min_gflop >= 0.f) || !(o->wino_min_ratio >= 0.f))
+        o->wino_split_rounds < 0 || o->wino_split_persist < 0 || o->wino_split_persist > 2 || !(o->wino_split_chunk_mb > 0.f) || !(o->wino_chunk_mb > 0.f) || !(o->wino_split_min_gflop >= 0.f) || !(o->wino_min_gflop >= 0.f) || !(o->wino_min_ratio >= 0.f))
         return fail(h, BYOLO_ERR_ARG, "byolo_set_plan_opts: a field outside its range (include/byolo.h)");
     const byolo_plan_opts& c = h->opts;
     // what byolo_lower / byolo_finalize have baked into steps and packed weights
-    const bool repack = (o->dedup != 0) != (c.dedup != 0) || (o->lowmain != 0) != (c.lowmain != 0) || (o->kx3 != 0) != (c.kx3 != 0) || (o->p1 != 0) != (c.p1 != 0);
+    const bool repack = (o->wshift_per_layer != 0) != (c.wshift_per_layer != 0) || (o->dedup != 0) != (c.dedup != 0) || (o->lowmain != 0) != (c.lowmain != 0) || (o->kx3 != 0) != (c.kx3 != 0) || (o->p1 != 0) != (c.p1 != 0);
     h->opts = *o;
     h->dedup = o->dedup != 0;
     h->plan.B = -1; h->plan.T = -1; ++h->plan_epoch; h->wsm_B = -1;
@@ -788,7 +789,11 @@ static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const C
         f.y = c.dst; f.scale = dptr(h, drop ? l.wscalek_off : l.wscale_off); f.shift = c.shift;
         f.C = c.C0; f.N = c.N; f.KT = c.C0 / 32; f.n_tiles = c.N / wp.bn; f.bn = wp.bn;
         f.H = l.H; f.W = l.W; f.th = wp.th; f.tw = wp.tw; f.s0 = s0; f.P = w.P; f.P_pad = w.P_pad;
-        f.bm = wp.bm; f.units = (w.P_pad / wp.bm) * f.n_tiles; f.persist = h->opts.wino_split_persist != 0;
+        f.bm = wp.bm; f.units = (w.P_pad / wp.bm) * f.n_tiles;
+        // (persist 2 claims units from 8 words of this step's ticket area, zeroed by the forward's memset: one set per chunk)
+        const int chunk_idx = s0 / wp.chunk;
+        f.persist = (h->opts.wino_split_persist == 2 && c.counters && chunk_idx < CNT_PER_STEP / 8) ? 2 : (h->opts.wino_split_persist ? 1 : 0);
+        f.claims = c.counters ? c.counters + 8 * chunk_idx : nullptr;
         f.flags = c.flags; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base; f.mask_bits = c.mask_bits;
         f.status = c.status; f.layer_idx = c.layer_idx;
         f.d_ntiles = make_fastdiv((uint32_t)f.n_tiles); f.d_tt = w.d_tt; f.d_tw = w.d_tw;
@@ -918,7 +923,7 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
                              int32_t* d_kept, int32_t* d_count, void* stream);
 struct FwdArgs { const float* d_img; int32_t B, T; uint64_t seed; int32_t dropout_on; const uint32_t* d_mask_bits; void* d_workspace;
                  float* d_boxes; float* d_rows; int32_t* d_kept; int32_t* d_count; };
-static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, bool capturing, bool wait_convs);
+static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, bool capturing, bool wait_convs, bool heads_only = false);
 static int32_t finish_forward(byolo_t* h, hipStream_t st, void* stream);
 static int32_t forward_graph(byolo_t* h, const FwdArgs& a, hipStream_t st, bool* done);
 
@@ -998,7 +1003,12 @@ static int32_t forward_piece(byolo_t* h, const float* d_img, int32_t B, int32_t 
         if (done) return finish_forward(h, st, stream);
     }
     const bool wait = serialize && h->ev_convs_valid && h->convs_stream != st;
-    rc = enqueue_forward(h, a, st, false, wait); if (rc) return rc;
+    // Per-launch profiling wants a quiet device: a forward recorded at level 2, and the one enqueued after it, wait for the other
+    // stream's WHOLE convolution stack (otherwise the recorded forward's backbone launches sit between the previous forward's head
+    // launches and its head launches between the next forward's backbone launches, and a launch's hipEvent time is no longer its own)
+    const bool quiet = h->profiling >= 2 || h->quiet_next;
+    h->quiet_next = h->profiling >= 2;
+    rc = enqueue_forward(h, a, st, false, wait, h->opts.serialize_heads != 0 && !quiet); if (rc) return rc;
     return finish_forward(h, st, stream);
 }
 
@@ -1079,7 +1089,7 @@ static int32_t finish_forward(byolo_t* h, hipStream_t st, void* stream) {
 
 // Everything one forward puts on the stream, in order: the split-K tickets' memset, the image's hi/lo copy, the convolution stack,
 // decode, sort + NMS.  `capturing`: the stream is in capture mode (forward_graph) -- no event is recorded or waited for in here.
-static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, bool capturing, bool wait_convs) {
+static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, bool capturing, bool wait_convs, bool heads_only) {
     const float* d_img = a.d_img; const int32_t B = a.B, T = a.T; const uint64_t seed = a.seed; const int32_t dropout_on = a.dropout_on;
     const uint32_t* d_mask_bits = a.d_mask_bits; float* d_boxes = a.d_boxes; float* d_rows = a.d_rows; int32_t* d_kept = a.d_kept; int32_t* d_count = a.d_count;
     const bool inject = d_mask_bits != nullptr && dropout_on;
@@ -1094,7 +1104,12 @@ static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, boo
     }
     const bool per_step = h->profiling >= 2;
     bool backbone_marked = false;
-    if (wait_convs && !capturing) HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0));
+    // heads_only (opts.serialize_heads): the wait sits in front of the first HEAD launch instead -- this forward's backbone (52 launches
+    // on B images that leave CUs idle: tile quantisation, fixed launch costs) runs beside the previous forward's heads and fills their
+    // last rounds.  Measured at config 4 (same box, three interleaved runs each): 368.0 / 369.3 / 368.7 -> 375.1 / 375.0 / 375.7 img/s
+    // (+1.8 %; profiles/r6_serialize_heads.md); the rows are the same bits (nothing but the order of independent launches changes).
+    bool wait_pending = wait_convs && !capturing;
+    if (wait_pending && !(heads_only && h->backbone_end >= 0)) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0)); wait_pending = false; }
     HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
     if (h->precision == 1 && h->img_split)
         HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st, h->d_status));
@@ -1147,6 +1162,7 @@ static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, boo
     for (size_t si = 0; si < h->steps.size(); ++si) {
         const Step& s = h->steps[si];
         const Layer& l = h->layers[s.layer];
+        if (wait_pending && s.layer >= h->backbone_end) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0)); wait_pending = false; }
         if (h->profiling && !backbone_marked && h->backbone_end >= 0 && s.layer >= h->backbone_end) {
             HIPCHK(h, hipEventRecord(h->wslot().ev[1], st)); backbone_marked = true;
         }
@@ -1228,7 +1244,7 @@ static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, boo
         n.boxes = boxes; n.B = B; n.N = h->n_boxes; n.D = h->row_len; n.obj_idx = h->obj_idx; n.cls_start = h->cls_start;
         n.two_class = h->cfg.nms_mode == BYOLO_NMS_TWO_CLASS; n.max_out = h->cfg.max_out; n.iou_thr = h->cfg.iou_thresh;
         n.ws = ws + h->plan.nms_off; n.ws_bytes = nms_workspace_bytes(B, h->n_boxes);
-        n.rows = d_rows; n.kept = d_kept; n.count = d_count;
+        n.rows = d_rows; n.kept = d_kept; n.count = d_count; n.general_only = h->opts.nms_general != 0;
         if (n.two_class && h->cfg.cls_cnt != 2) return fail(h, BYOLO_ERR_ARG, "byolo_forward: 2-class NMS needs cls_cnt == 2");
         HIPCHK(h, launch_sort_nms(n, st));
     }
@@ -1315,7 +1331,7 @@ extern "C" int32_t byolo_sort_nms(byolo_t* h, const float* d_boxes, int32_t B, i
     NmsParams n; memset(&n, 0, sizeof n);
     n.boxes = d_boxes; n.B = B; n.N = N; n.D = D; n.obj_idx = obj_idx; n.cls_start = cls_start_idx;
     n.two_class = nms_mode == BYOLO_NMS_TWO_CLASS; n.max_out = max_out; n.iou_thr = iou_thresh;
-    n.ws = d_sort_ws; n.ws_bytes = ws_bytes; n.rows = d_rows; n.kept = d_kept; n.count = d_count;
+    n.ws = d_sort_ws; n.ws_bytes = ws_bytes; n.rows = d_rows; n.kept = d_kept; n.count = d_count; n.general_only = h->opts.nms_general != 0;
     HIPCHK(h, launch_sort_nms(n, reinterpret_cast<hipStream_t>(stream)));
     return BYOLO_OK;
 }
@@ -1524,11 +1540,14 @@ extern "C" int32_t byolo_set_tshard(byolo_t* h, int32_t t0, int32_t T_total) {
     h->tshard_t0 = T_total ? t0 : 0; h->tshard_T = T_total;
     return BYOLO_OK;
 }
-extern "C" int32_t byolo_finish_tshard(byolo_t* h, float* d_sums, int32_t B, int32_t T_total, void* stream) {
+static int32_t finish_tshard_impl(byolo_t* h, float* d_sums, int32_t B, int32_t T_total, void* stream) {
     if (!h || !d_sums || B < 1 || T_total < 1) return fail(h, BYOLO_ERR_ARG, "byolo_finish_tshard: bad argument");
     if (!h->finalized) return fail(h, BYOLO_ERR_STATE, "byolo_finish_tshard: finalize first");
     HIPCHK(h, hipSetDevice(h->device));
     return run_decode(h, nullptr, d_sums, B, T_total, reinterpret_cast<hipStream_t>(stream), 2);
+}
+extern "C" int32_t byolo_finish_tshard(byolo_t* h, float* d_sums, int32_t B, int32_t T_total, void* stream) {
+    return guarded(h, "byolo_finish_tshard", [&] { return finish_tshard_impl(h, d_sums, B, T_total, stream); });
 }
 
 extern "C" int32_t byolo_set_first_image(byolo_t* h, int64_t first_image) {

@@ -186,6 +186,7 @@ struct byolo {
     // -- while a step's latency-bound tail (decode, sort, NMS) overlaps the next step's convolutions.  ev_convs is recorded
     // behind the last convolution launch of a forward; a forward on ANOTHER stream waits for it before its first launch.
     hipEvent_t ev_convs = nullptr; hipStream_t convs_stream = nullptr; bool ev_convs_valid = false;
+    bool quiet_next = false;       // the forward before this one was recorded at profiling level 2: this one does not run beside its heads
     std::vector<int> last_use;     // per tensor id: index of the last step reading it
     float* d_blob = nullptr;       // packed weights + scale/shift
     size_t blob_floats = 0;

@@ -139,7 +139,9 @@ struct WinoSplitParams {
     int C, N, KT, n_tiles;                // KT = C / 32 (a multiple of 4), n_tiles = N / bn
     int H, W, th, tw, s0, P, P_pad;       // as WinoParams
     int bm, bn;                           // output tiles / channels per workgroup: 64 (P_pad is a multiple of it), 128 | 256
-    int persist;                          // the workgroups walk the unit list (grid = resident workgroups): byolo_plan_opts.wino_split_persist
+    int persist;                          // byolo_plan_opts.wino_split_persist: 0 one unit per workgroup, 1 the resident workgroups walk a static unit list,
+                                          // 2 they claim the next unit of their XCD from `claims` (8 words, zero before the launch)
+    unsigned* claims;
     int units;                            // P_pad / bm * n_tiles units of (64 output tiles, bn channels)
     int flags; uint32_t k0, k1, thr; uint64_t idx_base; const uint32_t* mask_bits;
     unsigned* status; int layer_idx;
@@ -262,6 +264,7 @@ struct NmsParams {
     int two_class, max_out; float iou_thr;
     void* ws; size_t ws_bytes;
     float* rows; int32_t* kept; int32_t* count;
+    int general_only;        // byolo_plan_opts.nms_general: the general path for every image (tests)
 };
 hipError_t launch_sort_nms(const NmsParams& p, hipStream_t st);
 

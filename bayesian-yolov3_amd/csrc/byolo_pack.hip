@@ -133,8 +133,7 @@ static int32_t finalize_impl(byolo_t* h) {
     std::vector<float> sc, sf;
     h->img_split = false;
     if (h->precision == 1) {
-        const char* ple = getenv("BYOLO_WSHIFT_PER_LAYER");
-        const bool per_layer = ple && atoi(ple);
+        const bool per_layer = h->opts.wshift_per_layer != 0;
         const bool ok = parallel_tasks((int)h->layers.size(), [&](int li) {
             Layer& l = h->layers[li];
             if (l.op != OP_CONV && l.op != OP_DETECTION) return;

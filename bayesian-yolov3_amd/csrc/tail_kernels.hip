@@ -870,7 +870,7 @@ hipError_t launch_sort_nms(const NmsParams& p, hipStream_t st) {
     if (p.ws_bytes < nms_workspace_bytes(p.B, p.N)) return hipErrorInvalidValue;
     NmsWs w;
     nms_ws_layout(p.B, p.N, reinterpret_cast<char*>(p.ws), &w);
-    static const bool general_only = [] { const char* e = getenv("BYOLO_NMS_GENERAL"); return e && atoi(e); }();
+    const bool general_only = p.general_only != 0;            // byolo_plan_opts.nms_general
     const int* need = nullptr;
     if (!general_only) {
         static std::atomic<uint64_t> attr_done{0};

@@ -28,13 +28,18 @@
 // 310 img/s --, a one-tile input transform and a one-dimensional F(2,3) form for the 128-channel layers, transform + GEMM 2.12 ms
 // against the direct kernel's 2.01: all three lost their A/Bs and are gone; profiles/HISTORY.md, profiles/r5_wino1d.md.)
 //
-// Round 6: the workgroups WALK the unit list (grid = resident workgroups; byolo_plan_opts.wino_split_persist).  A unit = 64 output
-// tiles x WINO_BN channels through all 16 points; the K-tile stream of a workgroup runs on across its units: while unit u multiplies
-// its last K-tiles, the V rows and U fragments of unit u + 1's first tiles are already being fetched, staged and read, so the pipeline
-// fill (5 loads + a barrier per unit) and the workgroup turn-over (dispatch, kernel arguments, address prologue: one workgroup per
-// CU, nothing covers it) are paid once per workgroup instead of once per unit.  Same K order, same arithmetic per output element:
-// the rows are the rows of the one-unit-per-workgroup launch bit for bit (wino_split_persist = 0; tools/rows_digest.py).  Numerics: emulated around the oracle before the kernel was built
-// (tests/test_split_numerics.py: 0.62 of the bound from float64 where float32 sits at 0.98).
+// Round 6: the workgroups can WALK the unit list (grid = resident workgroups; byolo_plan_opts.wino_split_persist = 1 | 2; VERDICT r5
+// item 1).  A unit = 64 output tiles x WINO_BN channels through all 16 points; the V stream of a workgroup then runs on across its
+// units: while unit u multiplies its last K-tiles, the V rows of unit u + 1's first tiles are already being fetched, staged and
+// read, so that the pipeline fill and the workgroup turn-over (dispatch, kernel arguments, address prologue: one workgroup per CU,
+// nothing covers it) are paid once per workgroup instead of once per unit.  Same K order, same arithmetic per output element: the
+// rows are the rows of the one-unit-per-workgroup launch bit for bit (tools/rows_digest.py).  MEASURED SLOWER, so it is not the
+// default (profiles/r6_wino_persist.md; same box, three interleaved runs each, ms per step of the six launches): one unit per
+// workgroup 7.126, units claimed from a per-XCD counter (2) 7.180 (+0.8 %), a static list (1) 7.304 (+2.5 %).  The hardware
+// dispatcher already hands the next unit to whichever CU is free -- units differ (edge tiles store 1 - 3 of their 4 outputs) and
+// CUs do not run in step, so a static list runs at the pace of its unluckiest workgroup -- and the ~3 us of fill + turn-over it
+// pays per unit are less than what a walking workgroup loses: its weight-fragment stream restarts behind every epilogue anyway
+// (32 registers that cannot live through it), and the epilogue runs with the prefetched V sets and the stream's scalars live.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "byolo_kernels.h"
@@ -136,6 +141,7 @@ __host__ __device__ constexpr int wino_cA(int a, int i) { return a == 0 ? (i < 3
 template <int WINO_BN>
 __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSplitParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ uint32_t s_claim;                          // persist == 2: the unit this workgroup has claimed for its next turn
     constexpr int WINO_BM = 64;
     using BT = SplitTile<WINO_BM, WINO_BN, 1, WINO_BN / 32>;
     constexpr int TM = BT::TM, A_LD = BT::A_LD;            // 2 row blocks of 32 per wave; 1 (8 waves) or 2 staging rows per thread
@@ -290,10 +296,20 @@ __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSp
         if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
     };
 
-    for (uint32_t k = slot; k < xn; k += ustep) {
+    // The walk.  Static (persist 1): unit k + (workgroups of the XCD) is next.  Dynamic (persist 2): the XCD's workgroups claim units
+    // from one counter as they get to them -- units differ (edge tiles store 1 - 3 of their 4 outputs, padding rows none) and CUs
+    // do not run in step, and a static list gives the whole launch the pace of its unluckiest workgroup (measured: +2.5 % per launch
+    // against one unit per workgroup, where the hardware dispatcher does exactly this balancing).  The claim is made at a unit's
+    // start and read after its first point: the V stream needs it 5 K-tiles before the unit's end.
+    const bool dyn = p.persist == 2;
+    for (uint32_t k = slot, k_next; k < xn; k = k_next) {
         uint32_t rt, ct; unit_of(k, rt, ct);
-        a_has_next = k + ustep < xn ? 1u : 0u;
-        { uint32_t rt2, ct2; unit_of(a_has_next ? k + ustep : k, rt2, ct2); a_next_base = rt2 * rt_bytes; }
+        k_next = k + ustep;
+        if (dyn) { if (threadIdx.x == 0) s_claim = ustep + atomicAdd(p.claims + xcd, 1u); a_has_next = 0; }
+        else {
+            a_has_next = k_next < xn ? 1u : 0u;
+            uint32_t rt2, ct2; unit_of(a_has_next ? k_next : k, rt2, ct2); a_next_base = rt2 * rt_bytes;
+        }
         // the unit's first weight fragments, and (again: the last K-tile of the unit before read them already, into registers the
         // epilogue then took) the activation fragments of its first K-tile, which sits in LDS buffer 0 since that K-tile's barrier
         __builtin_amdgcn_sched_barrier(0);
@@ -316,6 +332,11 @@ __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSp
             // bytes per lane (16 copies of the K loop, each with 160 accumulator registers live across it).
             for (int xi = 0; xi < 16; ++xi) {
                 run_point();
+                if (dyn && xi == 0) {                     // (every wave is past several barriers since thread 0 wrote the claim)
+                    k_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile uint32_t*>(&s_claim));
+                    a_has_next = k_next < xn ? 1u : 0u;
+                    uint32_t rt2, ct2; unit_of(a_has_next ? k_next : k, rt2, ct2); a_next_base = rt2 * rt_bytes;
+                }
                 if constexpr (WS_ABL & 2) { if (xi != 15) continue; }
                 const int I = xi >> 2, J = xi & 3;
 #pragma unroll

@@ -275,7 +275,6 @@ class TestingDataset:
         # 8 x 24 on a 64-thread one is not): at most the rank's share of the hardware threads (LOCAL_WORLD_SIZE: torchrun)
         local_world = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1))
         self.threads = max(1, min(self.threads, (os.cpu_count() or 1) // local_world))
-        self._per_call = self.threads
         self.prefetch = int(info.get('prefetch', 0))                         # batches decoded ahead (:199 prefetches 1); 0 = derive it (iter_shards_u8)
         self.placeholder = _model.Placeholder((self.batch_size,) + self.shape)
 
@@ -311,7 +310,7 @@ class TestingDataset:
         feats = parse_example(example)
         return decode_img(feats['image/encoded'][0], self.shape), self._filename(feats)
 
-    def _load_block(self, recs, buf):
+    def _load_block(self, recs, buf, threads=None):
         """The map stage for the records of one block: payload (+ CRC) -> Example -> PNG decoded into buf[j] ([H,W,C] uint8), on
         `cpu_thread_cnt` native threads in ONE call that holds no GIL (byolo_feed_records); returns the file names."""
         from byolo import _lib
@@ -329,7 +328,7 @@ class TestingDataset:
         h, w, c = self.shape
         assert buf.dtype == np.uint8 and buf.flags['C_CONTIGUOUS'] and buf.shape[0] >= n and tuple(buf.shape[1:]) == self.shape
         rc = _lib.lib.byolo_feed_records(fds, offs, lens, n, int(bool(self.verify_crc)), h, w, c, ctypes.c_void_p(buf.ctypes.data),
-                                         self._per_call, names, cap, status, found)
+                                         int(threads or self.threads), names, cap, status, found)
         if rc < 0:
             raise ValueError('byolo_feed_records: bad argument (full_img_size {})'.format(self.shape))
         out = []
@@ -382,7 +381,8 @@ class TestingDataset:
         cap = max(1, shard_range(self.batch_size, 0, world)[1])              # the largest block of a full batch
         prefetch = self.prefetch if self.prefetch > 0 else max(2, min(16, -(-self.threads // cap)))
         # `prefetch` calls decode at once: each gets its share of cpu_thread_cnt (a block of 64 images used to start 2 x 24 threads)
-        self._per_call = max(1, -(-self.threads // prefetch))
+        # (a LOCAL of this iterator: two iterators of one dataset -- another world, another prefetch -- keep their own)
+        per_call = max(1, -(-self.threads // prefetch))
         free = queue.Queue()
         for _ in range(prefetch + 1 + max(1, extra_buffers)):
             free.put(alloc((cap,) + self.shape))
@@ -400,7 +400,7 @@ class TestingDataset:
 
         def load(recs, buf, lo, n_glob):
             try:
-                return buf, len(recs), self._load_block(recs, buf), lo, n_glob
+                return buf, len(recs), self._load_block(recs, buf, threads=per_call), lo, n_glob
             except Exception as e:                                           # a failed record reaches the consumer in order
                 return buf, 0, e, lo, n_glob
 

@@ -202,12 +202,25 @@ def other_config_leg(num, device, steps=5, warmup=2, oracle="f32"):
         step(warmup + i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # a launch-sized configuration (configs[0]: 1.5 ms per step) is not measured by 5 steps: the first replays of its launch graph, the
+    # host's first trips through the binding.  Timed again over enough steps for ~0.3 s (round 5 quoted 628 img/s from 5 steps where
+    # 200 steps give 1 150: profiles/r6_small_configs.md)
+    if dt < 0.25:
+        done = warmup + steps
+        steps = int(min(400, max(steps, round(steps * 0.3 / max(dt, 1e-4)))))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(done + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     flags, layer = eng.status()
     peak = PEAK_F16_MFMA if eng.precision == "split" else PEAK_FP32_MFMA
     res = {"workload": "%s %dx%d T=%d, %d images/GPU, class-%s NMS" % (cfg["variant"], cfg["H"], cfg["W"], T, B, "wise 2-class" if cfg["nms"] else "agnostic"),
            "img_s": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup, "precision": eng.precision,
            "gflop_per_image": eng.flops(1, T) / 1e9, "end_to_end_frac": (B * steps / dt) * eng.flops(1, T) / peak,
-           "range_status": "ok" if flags == 0 else "RANGE (layer %d): invalid" % layer}
+           "range_status": "ok" if flags == 0 else "RANGE (layer %d): invalid" % layer,
+           "launch_graphs": eng.graph_stats() if hasattr(eng, "graph_stats") else None}
     if oracle:
         try:
             p = eng.get_params()
@@ -454,9 +467,10 @@ def main():
     ap.add_argument("--global-batch", type=int, default=64, help="strong scaling: images per step over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-launch hipEvents in the timed region")
-    ap.add_argument("--profile-every", type=int, default=4,
+    ap.add_argument("--profile-every", type=int, default=10,
                     help="per-launch hipEvents on every n-th step of the timed region (a recorded event costs the GPU ~3 us: ~95 per "
-                         "step are 1.3 %% of a config-4 step); 1 = every step")
+                         "step are 1.3 %% of a config-4 step -- and a recorded forward and its successor do not run beside another "
+                         "forward's heads, byolo_plan_opts.serialize_heads: 0.4 ms each); 1 = every step")
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many concurrent HIP streams")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="alternate whole steps over this many HIP streams (own workspace and output buffers each): the latency-bound "
@@ -703,7 +717,23 @@ def main():
             wino_ms = sum(acc[v][1] for v in (-2, -3, -4, -6) if v in acc)
             # fabric bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this same command
             # (tools/profile_round.sh + tools/pmc_traffic.py -> profiles/traffic_cfgN.json); null if absent / another kernel
-            traffic = tr_read = tr_write = measured_at = None
+            traffic = tr_read = tr_write = measured_at = refused = None
+
+            def fresh(tj):
+                """A traffic file belongs to the kernel it was measured on: tools/pmc_traffic.py records the SHA-256 of the kernel's
+                source files, and a file whose sources have changed since (or that carries none) is REFUSED, not quoted (VERDICT r5
+                "missing" 6: the round-5 line quoted the transform traffic of a kernel that had been replaced)."""
+                import hashlib
+                src = (tj.get("measured_at") or {}).get("sources")
+                if not src:
+                    return "no source hashes recorded (measured before round 6)"
+                for f, h in src.items():
+                    try:
+                        if hashlib.sha256(open(os.path.join(REPO, f), "rb").read()).hexdigest()[:16] != h:
+                            return "%s has changed since the measurement (%s)" % (f, (tj.get("measured_at") or {}).get("commit"))
+                    except OSError:
+                        return "%s is gone" % f
+                return None
             # one file per kernel that has been the dominant one: profiles/traffic_cfg<N>_<tag>.json
             tag = {4256: "b2b", 3128: "kx3", 140: "wino", 130: "wino_fused"}.get(dom, "v%d" % dom)
             tpath = os.path.join(REPO, "profiles", "traffic_cfg%d_%s.json" % (args.config, tag))
@@ -711,8 +741,10 @@ def main():
                 tj = json.load(open(tpath))
                 want = {4256: "conv_igemm_kernel<128, 256, 1, 8, true, true, 1", 3128: "conv_igemm_kernel<128, 128, 1, 4, true, true, 1", 140: "wino_split_kernel", 130: "wino_fused_kernel"}.get(dom)
                 if want and (want in tj.get("kernel", "") or tj.get("kernel", "") in want):
-                    traffic = tj.get("traffic_bytes_per_launch")
-                    tr_read, tr_write = tj.get("read_bytes_per_launch"), tj.get("write_bytes_per_launch")
+                    refused = fresh(tj)
+                    if refused is None:
+                        traffic = tj.get("traffic_bytes_per_launch")
+                        tr_read, tr_write = tj.get("read_bytes_per_launch"), tj.get("write_bytes_per_launch")
                     measured_at = tj.get("measured_at")
             ab_r, ab_w = abr / n, abw / n
             # the CONVOLUTION's own bytes per launch: input once + weights once + output once (for a Winograd
@@ -724,10 +756,12 @@ def main():
             tr_in = None                                              # the separate input-transform launch's measured traffic, if profiled
             ipath = os.path.join(REPO, "profiles", "traffic_cfg%d_wino_input.json" % args.config)
             if dom == 140 and os.path.exists(ipath) and traffic:
-                tr_in = json.load(open(ipath)).get("traffic_bytes_per_launch")
+                ij = json.load(open(ipath))
+                tr_in = ij.get("traffic_bytes_per_launch") if fresh(ij) is None else None
             line["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                                 "frac": ach / peak,
                                 "traffic": traffic, "traffic_read": tr_read, "traffic_write": tr_write, "traffic_measured_at": measured_at,
+                                "traffic_refused": refused,
                                 "algorithmic_bytes_per_launch": ab_r + ab_w,
                                 "algorithmic_read_bytes_per_launch": ab_r, "algorithmic_write_bytes_per_launch": ab_w,
                                 "traffic_vs_algorithmic": (traffic / (ab_r + ab_w)) if traffic else None,
@@ -738,7 +772,9 @@ def main():
                                 "read_amplification": (tr_read / ab_r) if tr_read else None,
                                 "write_amplification": (tr_write / ab_w) if tr_write else None,
                                 "kernel": KERNELS[dom],
-                                "launches": n, "profiled_steps": "%d of %d (every %d-th step of the timed region records per-launch hipEvents)" % (n_prof, args.steps, every),
+                                "launches": n, "profiled_steps": "%d of %d (every %d-th step of the timed region records per-launch hipEvents; a recorded forward and the one after it wait for the "
+                                                  "other stream's WHOLE convolution stack, so these launches run alone on the device -- the other steps run their heads beside the next "
+                                                  "step's backbone (byolo_plan_opts.serialize_heads: faster steps, longer single launches; tools/rocprof_summary.py lists both averages)" % (n_prof, args.steps, every),
                                 "avg_launch_ms": ms / n, "share_of_conv_flops": f / tot_f,
                                 "definition": "SURVEY.md 8(d): achieved = algorithmic fp32-equivalent FLOPs of the launches (2MNK of the convolution as written; a "
                                               "Winograd launch stands for the direct-convolution FLOPs of its samples; tile padding not counted), each counted ONCE, "

@@ -106,6 +106,10 @@ typedef struct byolo_plan_opts {
                                       that can be captured [BYOLO_GRAPHS]                                                             */
     int32_t serialize_convs;       /* forwards of one handle on several streams: convolution stacks one after the other: 0 never,
                                       1 forwards of >= 1 TFLOP (default), 2 always [BYOLO_SERIALIZE_CONVS]                            */
+    int32_t serialize_heads;       /* with serialize_convs in effect: only the HEADS wait for the other stream's convolution stack; this
+                                      forward's backbone (small launches that leave CUs idle) runs beside the previous forward's heads: 1
+                                      (default; +1.8 % img/s at configs[3]), 0 = the whole stack waits.  A forward recorded at profiling
+                                      level 2 and the one after it always wait as a whole [BYOLO_SERIALIZE_HEADS]                      */
     int32_t dedup;                 /* [pack] T-invariant de-duplication (a convolution over a T-fold tile runs once per image): 1
                                       [BYOLO_NO_DEDUP inverts]                                                                        */
     int32_t lowmain;               /* [pack] the 1x1 convolution over an upsampled source at the source's resolution: 1 [BYOLO_LOWMAIN] */
@@ -129,8 +133,14 @@ typedef struct byolo_plan_opts {
                                       [BYOLO_STREAMK]                                                                                 */
     int32_t plain_epilogue;        /* straight-line epilogues of the split-f16 convolutions (one decision per tile): 1; 0 = the general
                                       epilogue everywhere (A/B; the same bits) [BYOLO_PLAIN_EPILOGUE]                                 */
-    int32_t wino_split_persist;    /* the Winograd GEMM's workgroups walk the unit list themselves, next unit prefetched: 0 | 1
-                                      [BYOLO_WINO_SPLIT_PERSIST]                                                                      */
+    int32_t wshift_per_layer;      /* [pack] split-f16 weights: ONE power-of-two scale per layer instead of one per output channel: 0; 1 = the
+                                      A/B of tests/test_robustness.py (a filter far smaller than its neighbours loses bits)
+                                      [BYOLO_WSHIFT_PER_LAYER]                                                                        */
+    int32_t nms_general;           /* the tail's general path (sort + bit-matrix NMS over all candidates) for every image, never the
+                                      top-k fast path: 0; 1 = tests / soak runs of that path [BYOLO_NMS_GENERAL]                      */
+    int32_t wino_split_persist;    /* the Winograd GEMM's workgroups walk the unit list themselves, next unit prefetched: 0 one unit per
+                                      workgroup (default), 1 a static list, 2 units claimed from a per-XCD counter; the same bits, and
+                                      measured SLOWER: +2.5 % / +0.8 % per launch (profiles/r6_wino_persist.md) [BYOLO_WINO_SPLIT_PERSIST] */
     float   wino_split_min_gflop;  /* 200 [BYOLO_WINO_SPLIT_MIN_GFLOP]                                                                */
     float   wino_split_chunk_mb;   /* V bytes of one chunk: 1500 [BYOLO_WINO_SPLIT_CHUNK_MB]                                          */
     float   wino_min_gflop;        /* fp32 mode: 10 [BYOLO_WINO_MIN_GFLOP]                                                            */

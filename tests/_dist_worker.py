@@ -33,8 +33,13 @@ def main(rank, world, port, out_dir):
         p_kept[j, :k] = torch.arange(k, dtype=torch.int32) + 1000 * (lo + j)
         p_count[j] = k
     u_rows, u_kept = bdist.unpack_global(*bdist.allgather_boxes(p_rows, p_kept, p_count, world), n_glob, world)
+    # a step any rank may fail at (byolo/inference.py: building the fp32 twin handle): rank 1 fails, BOTH ranks get an exception back;
+    # nobody fails, nobody gets one
+    e_none = bdist.agree_on_any_error(None)
+    e_any = bdist.agree_on_any_error(MemoryError("out of device memory") if rank == world - 1 else None)
     torch.save({"rows": rows, "kept": kept, "count": count, "g_rows": g_rows, "g_kept": g_kept, "g_count": g_count,
-                "shard": bdist.shard_range(7, rank, world), "u_rows": u_rows, "u_kept": u_kept},
+                "shard": bdist.shard_range(7, rank, world), "u_rows": u_rows, "u_kept": u_kept,
+                "agree": (e_none is None, type(e_any).__name__, str(e_any))},
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

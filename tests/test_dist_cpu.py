@@ -32,6 +32,9 @@ def test_allgather_world2(tmp_path):
             want = torch.cat([res[0][k], res[1][k]], 0)
             assert torch.equal(res[r][gk], want), (r, k)
     assert res[0]["shard"] == (0, 4) and res[1]["shard"] == (4, 7)
+    # byolo.dist.agree_on_any_error: the failing rank keeps its own exception, its peer learns of it (the fp32 twin)
+    assert res[0]["agree"][0] and res[1]["agree"][0]
+    assert res[1]["agree"][1] == "MemoryError" and res[0]["agree"][1] == "RuntimeError" and "rank 1 failed" in res[0]["agree"][2]
     for r in range(2):                               # the short batch: global order, trimmed, identical on both ranks
         assert [t.shape[0] for t in res[r]["u_rows"]] == [1, 2, 3]
         for g in range(3):
@@ -106,7 +109,7 @@ def test_feed_prefetches_and_stops_cleanly(tmp_path):
     ds = du.TestingDataset(cfg)
     loaded = []
     orig = ds._load_block
-    ds._load_block = lambda recs, buf: (loaded.append(len(recs)), orig(recs, buf))[1]
+    ds._load_block = lambda recs, buf, **kw: (loaded.append(len(recs)), orig(recs, buf, **kw))[1]
     it = ds.iter_shards_u8(0, 1, extra_buffers=1)
     first = next(it)
     time.sleep(0.5)

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--launches", type=int, default=66, help="launches of the kernel in ONE bench step")
     ap.add_argument("--out", default=None)
     ap.add_argument("--tag", default=None, help="profile round the passes belong to (recorded in the output)")
+    ap.add_argument("--sources", nargs="*", default=None, help="source files of the kernel (repo-relative): their SHA-256 is recorded, and bench.py "
+                    "refuses the file once one of them has changed (a traffic figure belongs to the kernel it was measured on)")
     a = ap.parse_args()
     res = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -53,6 +55,10 @@ def main():
         commit = ""
     out["measured_at"] = {"commit": commit, "date": datetime.date.today().isoformat(), "profile": a.tag,
                           "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/profile_round.sh"}
+    if a.sources:
+        import hashlib
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out["measured_at"]["sources"] = {f: hashlib.sha256(open(os.path.join(repo, f), "rb").read()).hexdigest()[:16] for f in a.sources}
     print(json.dumps(out, indent=1))
     if a.out:
         json.dump(out, open(a.out, "w"), indent=1)

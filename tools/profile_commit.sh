@@ -14,9 +14,11 @@ if [ -n "$DB" ]; then
     echo >> profiles/${TAG}_bench_kernel_stats.md
     python tools/rocprof_summary.py "$DB" --steps 5 --launches-per-step 3 --kernel "conv_igemm_kernel<128, 256" | sed -n '/timed region/,$p' >> profiles/${TAG}_bench_kernel_stats.md
 fi
-python tools/pmc_traffic.py "$D" --kernel "wino_split_kernel" --launches 6 --tag "$TAG" --out profiles/traffic_cfg4_wino.json > /dev/null
-python tools/pmc_traffic.py "$D" --kernel "wino_split_input_kernel" --launches 6 --tag "$TAG" --out profiles/traffic_cfg4_wino_input.json > /dev/null
-python tools/pmc_traffic.py "$D" --kernel "conv_igemm_kernel<128, 256" --launches 3 --tag "$TAG" --out profiles/traffic_cfg4_b2b.json > /dev/null
+C=bayesian-yolov3_amd/csrc
+# (--sources: bench.py refuses a traffic file once the kernel it was measured on has changed)
+python tools/pmc_traffic.py "$D" --kernel "wino_split_kernel" --launches 6 --tag "$TAG" --sources $C/wino_split.hip $C/mfma_pipe.h $C/epilogue.h --out profiles/traffic_cfg4_wino.json > /dev/null
+python tools/pmc_traffic.py "$D" --kernel "wino_split_input2_kernel" --launches 6 --tag "$TAG" --sources $C/wino_split.hip --out profiles/traffic_cfg4_wino_input.json > /dev/null
+python tools/pmc_traffic.py "$D" --kernel "conv_igemm_kernel<128, 256" --launches 3 --tag "$TAG" --sources $C/conv_igemm.hip $C/mfma_pipe.h $C/epilogue.h --out profiles/traffic_cfg4_b2b.json > /dev/null
 python tools/pmc_sq_summary.py "$D" --kernel "wino_split_kernel" --launches 6 > profiles/${TAG}_pmc_sq_summary_wino.json
 python tools/pmc_sq_summary.py "$D" --kernel "conv_igemm_kernel<128, 256" --launches 3 > profiles/${TAG}_pmc_sq_summary_b2b.json
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* profiles/traffic_cfg4_wino.json profiles/traffic_cfg4_wino_input.json profiles/traffic_cfg4_b2b.json gpurun_out/profiles_$TAG/

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--launches-per-step", type=int, default=66)
     ap.add_argument("--kernel", default="conv_igemm_kernel<128, 128")
+    ap.add_argument("--profile-every", type=int, default=10, help="bench.py --profile-every of the profiled command: the steps whose launches "
+                    "carry per-launch hipEvents run in a quiet window (include/byolo.h byolo_plan_opts.serialize_heads)")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
@@ -37,6 +39,16 @@ def main():
         ds = [x[0] for x in d]
         print("\n## dominant kernel in the timed region (last %d dispatches of `%s...`)\n" % (len(ds), a.kernel))
         print("- launches: %d\n- total: %.3f ms\n- average launch duration: %.4f ms" % (len(ds), sum(ds) / 1e6, sum(ds) / len(ds) / 1e6))
+        # the steps bench.py records per-launch hipEvents on (i = 0, every, 2 * every, ...): their forwards wait for the other stream's
+        # WHOLE convolution stack and so does the forward after them -- the launches of these steps run alone on the device, the
+        # others beside the next step's backbone (which is what makes the step faster and a single launch longer)
+        ds_t = ds[::-1]                                   # oldest first
+        L = a.launches_per_step
+        quiet = [d for st in range(0, a.steps, max(1, a.profile_every)) for d in ds_t[st * L:(st + 1) * L]]
+        rest = [d for st in range(a.steps) if st % max(1, a.profile_every) for d in ds_t[st * L:(st + 1) * L]]
+        if quiet and rest:
+            print("- of these, the %d launches of the profiled step(s) (quiet window; what bench.py's hipEvents time): average %.4f ms" % (len(quiet), sum(quiet) / len(quiet) / 1e6))
+            print("- the other %d launches (their step's heads share the device with the next step's backbone): average %.4f ms" % (len(rest), sum(rest) / len(rest) / 1e6))
 
 
 if __name__ == "__main__":
