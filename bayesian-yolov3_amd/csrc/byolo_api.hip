@@ -1110,7 +1110,7 @@ static int32_t enqueue_forward(byolo_t* h, const FwdArgs& a, hipStream_t st, boo
     // (+1.8 %; profiles/r6_serialize_heads.md); the rows are the same bits (nothing but the order of independent launches changes).
     bool wait_pending = wait_convs && !capturing;
     if (wait_pending && !(heads_only && h->backbone_end >= 0)) { HIPCHK(h, hipStreamWaitEvent(st, h->ev_convs, 0)); wait_pending = false; }
-    HIPCHK(h, hipMemsetAsync(ws + h->plan.cnt_off, 0, h->plan.cnt_bytes, st));     // split-K arrival tickets
+    HIPCHK(h, launch_zero_words(ws + h->plan.cnt_off, (int64_t)(h->plan.cnt_bytes / 4), st));     // split-K arrival tickets, unit claims
     if (h->precision == 1 && h->img_split)
         HIPCHK(h, launch_f32_to_split(d_img, reinterpret_cast<float*>(ws + h->plan.img_split_off), (int64_t)B * h->cfg.img_h * h->cfg.img_w * h->cfg.img_c, ACT_SCALE, st, h->d_status));
     // everything a convolution step's launch needs, up to the launch itself: sources, epilogue flags, this call's dropout keys /

@@ -205,6 +205,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, int tile, hipStream_t st);
 // a route / upsample / stack view copied into a dense [M][C0 + C1] tensor (sources, extents and dst as in ConvParams)
 hipError_t launch_view_gather(const ConvParams& p, hipStream_t st);
 hipError_t launch_tensor_add(const float* a, const float* b, float* dst, int64_t n, bool split, hipStream_t st, unsigned* status = nullptr, int layer = 0);   // dst = a + b (split: all three in [4 hi | 4 lo] groups)
+hipError_t launch_zero_words(void* p, int64_t n_words, hipStream_t st);                    // the forward's ticket / claim words (a kernel, not a memset node: conv_kernels.hip)
 hipError_t launch_u8_to_f32(const uint8_t* src, float* dst, int64_t n, hipStream_t st);   // float(u8) * (1 / 255), fp32
 hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mul, hipStream_t st, unsigned* status = nullptr);   // hi/lo pairs of mul * src
 hipError_t launch_split_to_f32(const float* src, float* dst, int64_t n, float mul, hipStream_t st);   // dst[i] = mul * (hi + lo) of a split-f16 tensor

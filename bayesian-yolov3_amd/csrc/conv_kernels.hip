@@ -328,6 +328,18 @@ hipError_t launch_f32_to_split(const float* src, float* dst, int64_t n, float mu
                        reinterpret_cast<f32x4*>(dst), n / 4, mul, status);
     return hipGetLastError();
 }
+// The split-K tickets / unit claims of a forward, zeroed by a KERNEL of the library (not hipMemsetAsync): inside a captured launch
+// graph the runtime's memset node went wrong after ~8 192 graph operations of a process holding three or more executable graphs --
+// the ticket words then held garbage and every split-K / stream-K launch of a replayed forward reduced slabs nobody had written
+// (tools/graph_stress.py, profiles/r6_small_configs.md: onset at replay 274 with three handles, 206 with four, never with eager
+// launches or with one or two graphs).  A kernel node has no such history.
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0u;
+}
+hipError_t launch_zero_words(void* p, int64_t n_words, hipStream_t st) {
+    if (n_words > 0) hipLaunchKernelGGL(zero_words_kernel, dim3(grid_for(n_words)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), n_words);
+    return hipGetLastError();
+}
 hipError_t launch_u8_to_f32(const uint8_t* src, float* dst, int64_t n, hipStream_t st) {
     const int64_t n4 = n / 4;
     if (n4) hipLaunchKernelGGL(u8_to_f32_kernel, dim3(grid_for(n4)), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(src),

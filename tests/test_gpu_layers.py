@@ -204,3 +204,17 @@ def test_slab_handoff_stress_on_three_streams():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.main(150, verbose=True)
+
+
+def test_launch_graphs_of_four_handles_survive_three_hundred_replays():
+    """tools/graph_stress.py: four handles (K slices forced, stream-K forced, two planner plans) replay their captured forwards 300
+    times.  With the ticket words zeroed by a hipMemsetAsync NODE the split-K handles' rows turned to inf at replay 206 (~8 192 graph
+    operations of a process with >= 3 executable graphs; 274 with three) -- the forward zeroes them with a kernel of its own now."""
+    import importlib.util
+    import os
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("graph_stress", os.path.join(REPO, "tools", "graph_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run([0, 1, 2, 2], 300)
+    assert mod.LAST_BAD == 0

@@ -47,7 +47,7 @@ def one_case(rng, idx, a):
            "BYOLO_PRECISION": str(rng.choice(["", "", "f32"])),                    # default (split-f16) twice as often as the fp32 mode
            # round 3, default precision: Winograd in split arithmetic never / planner / every eligible layer, its workgroup shapes and
            # chunk budget (many chunks, odd tile paddings), the 1x1 loop on / off
-           "BYOLO_WINO_SPLIT": str(rng.choice(["", "0", "2", "2"])), "BYOLO_WINO_SPLIT_PERSIST": str(rng.choice(["", "0", "1"])),
+           "BYOLO_WINO_SPLIT": str(rng.choice(["", "0", "2", "2"])), "BYOLO_WINO_SPLIT_PERSIST": str(rng.choice(["", "0", "1", "2"])),
            "BYOLO_WINO_SPLIT_BN": str(rng.choice(["", "128", "256"])), "BYOLO_WINO_SPLIT_CHUNK_MB": str(rng.choice(["", "1", "4", "32"])),
            "BYOLO_P1": str(rng.choice(["", "", "0"]))}
     for k, v in env.items():
