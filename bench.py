@@ -65,6 +65,21 @@ PEAK_F16_MFMA = 2500e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, d
 SUSTAINED_F16_MFMA = 1756e12
 
 
+_STREAMS = {}
+
+
+def pipeline_streams(device, n=2):
+    """The HIP streams whole steps alternate over -- ONE set per process, created before the first engine runs and shared by the
+    headline loop and every `other_configs` leg.  (A leg that created its own two streams after the headline's engine had run sometimes
+    found them on one hardware queue: BASELINE configs[0] then read 630 img/s -- its one-stream rate -- where the same leg reads 1 150
+    in a fresh process or when called a second time; profiles/r6_small_configs.md.)"""
+    import torch
+    key = (int(device), int(n))
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device="cuda:%d" % device) for _ in range(n)]
+    return _STREAMS[key]
+
+
 def build(cfg, device, precision=None, params=None):
     """The benchmark's model: seeded random weights, BN statistics calibrated on the device (or `params`: the complete parameter
     set of an engine built here before -- the other precision of the same configuration computes on the SAME weights)."""
@@ -186,9 +201,9 @@ def other_config_leg(num, device, steps=5, warmup=2, oracle="f32"):
     x = torch.from_numpy(synth.synthetic_images(B, cfg["H"], cfg["W"], seed=1234)).to("cuda:%d" % device)
     N, D = eng.num_boxes()
     cap = eng.out_cap
-    pipes = [dict(st=torch.cuda.Stream(device=x.device),
+    pipes = [dict(st=st,
                   out={"rows": torch.empty((B, cap, D), device=x.device), "kept": torch.empty((B, cap), dtype=torch.int32, device=x.device),
-                       "count": torch.empty((B, 2), dtype=torch.int32, device=x.device)}) for _ in range(2)]
+                       "count": torch.empty((B, 2), dtype=torch.int32, device=x.device)}) for st in pipeline_streams(device, 2)]
 
     def step(i):
         pp = pipes[i % 2]
@@ -501,6 +516,7 @@ def main():
         sys.exit("rank %d: LOCAL_RANK=%d but only %d GPUs are visible" % (rank, local, torch.cuda.device_count()))
     pg = dist.is_initialized()         # world > 1, or a forced one-rank group (BYOLO_DIST_FORCE=1)
     torch.cuda.set_device(device)
+    pipeline_streams(device, max(2, args.pipeline))     # before any engine exists
     # preflight of the N > 1 path, before anything is built: what the BACKEND says the job is (not the environment), and one tiny
     # all-reduce over the link the all-gather will use -- a rank on the wrong GPU or a group of the wrong size shows up in the line
     # (`ranks[].nccl_world`, `ranks[].preflight_sum`) instead of as a hang in the timed region
@@ -540,8 +556,7 @@ def main():
     # --pipeline P: whole steps alternate over P streams (own workspace slot and output buffers each), so the
     # latency-bound tail of step i (decode, NMS) and its launch ramps overlap the convolutions of step i+1
     npipe = max(1, args.pipeline)
-    pipes = [dict(st=torch.cuda.Stream(device=x.device), out={n: torch.empty_like(t) for n, t in out.items()})
-             for _ in range(npipe)] if npipe > 1 else []
+    pipes = [dict(st=st, out={n: torch.empty_like(t) for n, t in out.items()}) for st in pipeline_streams(device, npipe)] if npipe > 1 else []
 
     def step(i):
         if npipe > 1:

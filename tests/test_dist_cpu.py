@@ -354,3 +354,5 @@ def test_bench_line_two_ranks_with_real_engines_on_one_device():
     assert two["n_gpus"] == 2 and [r["first_image"] for r in two["ranks"]] == [0, 2] and [r["images"] for r in two["ranks"]] == [2, 2]
     assert two["config"]["images_per_gpu"] == 2 and len(two["kept_checksum_per_image_of_one_more_step"]) == 4
     assert two["value"] > 0 and two["scaling"] == "weak" and two["range_status"].startswith("ok")
+    # the preflight of the N > 1 path: what the BACKEND says the job is, before anything was built
+    assert [r["nccl_world"] for r in two["ranks"]] == [2, 2] and [r["preflight_sum"] for r in two["ranks"]] == [2, 2] and {r["backend"] for r in two["ranks"]} == {"gloo"}

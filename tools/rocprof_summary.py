@@ -32,24 +32,31 @@ def main():
     for n, cnt, tot, avg, mn, mx, vg, ag, sg, lds in rows:
         print("| `%s` | %d | %.3f | %.1f | %.1f | %.1f | %.2f | %s | %s | %s | %s |"
               % (n.split("(")[0], cnt, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total, vg, ag, sg, lds))
-    k = a.steps * a.launches_per_step
+    # bench.py runs, after the K timed steps, ONE more step (the kept-index checksum of the line) with per-launch recording on: the last
+    # (K + 1) * L dispatches of the kernel are steps 0 .. K - 1 of the timed region and that extra step.
+    L, K, every = a.launches_per_step, a.steps, max(1, a.profile_every)
     d = c.execute("select duration from kernels where name like ? order by start desc limit ?",
-                  ("%" + a.kernel + "%", k)).fetchall()
-    if d:
-        ds = [x[0] for x in d]
-        print("\n## dominant kernel in the timed region (last %d dispatches of `%s...`)\n" % (len(ds), a.kernel))
-        print("- launches: %d\n- total: %.3f ms\n- average launch duration: %.4f ms" % (len(ds), sum(ds) / 1e6, sum(ds) / len(ds) / 1e6))
-        # the steps bench.py records per-launch hipEvents on (i = 0, every, 2 * every, ...): their forwards wait for the other stream's
-        # WHOLE convolution stack and so does the forward after them -- the launches of these steps run alone on the device, the
-        # others beside the next step's backbone (which is what makes the step faster and a single launch longer)
-        ds_t = ds[::-1]                                   # oldest first
-        L = a.launches_per_step
-        quiet = [d for st in range(0, a.steps, max(1, a.profile_every)) for d in ds_t[st * L:(st + 1) * L]]
-        rest = [d for st in range(a.steps) if st % max(1, a.profile_every) for d in ds_t[st * L:(st + 1) * L]]
-        if quiet and rest:
-            print("- of these, the %d launches of the profiled step(s) (quiet window; what bench.py's hipEvents time): average %.4f ms" % (len(quiet), sum(quiet) / len(quiet) / 1e6))
+                  ("%" + a.kernel + "%", (K + 1) * L)).fetchall()
+    if len(d) == (K + 1) * L:
+        ds = [x[0] for x in d][::-1]                     # oldest first
+        timed = ds[:K * L]
+        print("\n## dominant kernel in the timed region (the %d dispatches of `%s...` in its %d steps)\n" % (len(timed), a.kernel, K))
+        print("- launches: %d\n- total: %.3f ms\n- average launch duration: %.4f ms" % (len(timed), sum(timed) / 1e6, sum(timed) / len(timed) / 1e6))
+        # A step's HEAD launches run alone on the device when the NEXT forward waits for the whole convolution stack, i.e. when this
+        # step or the next one records per-launch hipEvents (include/byolo.h byolo_plan_opts.serialize_heads: a recorded forward and
+        # its successor wait as a whole): the profiled steps i = 0, every, ... -- what bench.py's `roofline` times -- and the last
+        # timed step (the checksum step behind it is recorded).  The other steps' heads share the device with the next step's
+        # backbone: that is what makes the STEP faster and a single launch longer.
+        prof = [i for i in range(K) if i % every == 0]
+        quiet = sorted(set(prof) | {K - 1})
+        pq = [x for i in prof for x in timed[i * L:(i + 1) * L]]
+        qq = [x for i in quiet if i not in prof for x in timed[i * L:(i + 1) * L]]
+        rest = [x for i in range(K) if i not in quiet for x in timed[i * L:(i + 1) * L]]
+        print("- the %d launches of the profiled step(s) %s (bench.py's per-launch hipEvents time exactly these): average %.4f ms" % (len(pq), prof, sum(pq) / len(pq) / 1e6))
+        if qq:
+            print("- the %d launches of the last timed step (quiet as well: the checksum step behind it is recorded): average %.4f ms" % (len(qq), sum(qq) / len(qq) / 1e6))
+        if rest:
             print("- the other %d launches (their step's heads share the device with the next step's backbone): average %.4f ms" % (len(rest), sum(rest) / len(rest) / 1e6))
-
 
 if __name__ == "__main__":
     main()
