@@ -86,6 +86,9 @@ static void plan_opts_from_env(byolo_plan_opts& o) {
 }
 
 static void drop_graphs(byolo_t* h) {
+    bool any = false;
+    for (auto& g : h->graphs) any = any || g.exec;
+    if (any) (void)hipDeviceSynchronize();                  // an executable graph may still be replaying on some stream of the caller's
     for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();
 }
@@ -1031,7 +1034,7 @@ static int32_t forward_graph(byolo_t* h, const FwdArgs& a, hipStream_t st, bool*
         if (h->graphs.size() >= 8) {                                       // drop the least recently used
             size_t lru = 0;
             for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].used < h->graphs[lru].used) lru = i;
-            if (h->graphs[lru].exec) (void)hipGraphExecDestroy(h->graphs[lru].exec);
+            if (h->graphs[lru].exec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(h->graphs[lru].exec); }      // (it may still be replaying)
             h->graphs.erase(h->graphs.begin() + lru);
         }
         h->graphs.emplace_back();
@@ -1058,7 +1061,7 @@ static int32_t forward_graph(byolo_t* h, const FwdArgs& a, hipStream_t st, bool*
         if (e->exec) {
             hipGraphNode_t bad = nullptr; hipGraphExecUpdateResult ur;
             ok = hipGraphExecUpdate(e->exec, g, &bad, &ur) == hipSuccess;
-            if (ok) ++h->graph_updates; else { (void)hipGetLastError(); (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+            if (ok) ++h->graph_updates; else { (void)hipGetLastError(); (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
         }
         if (!ok) {
             ok = hipGraphInstantiate(&e->exec, g, nullptr, nullptr, 0) == hipSuccess;
