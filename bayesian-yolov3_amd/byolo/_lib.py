@@ -130,7 +130,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PNG_OK, PNG_UNSUPPORTED, PNG_SHAPE, PNG_CORRUPT, FEED_IO, FEED_CRC, FEED_PROTO = 0, 1, 2, 3, 4, 5, 6
 lib = _load()
 

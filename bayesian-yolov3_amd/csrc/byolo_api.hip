@@ -25,7 +25,7 @@ int32_t byolo_fail(byolo_t* h, int32_t code, const char* fmt, ...) {
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" const char* byolo_version(void) { return "byolo 0.6 (gfx950; fp32 MFMA and split-f16 MFMA; abi 6)"; }
+extern "C" const char* byolo_version(void) { return "byolo 0.7 (gfx950; fp32 MFMA and split-f16 MFMA; abi 7)"; }
 extern "C" int32_t byolo_abi_version(void) { return BYOLO_ABI_VERSION; }
 
 extern "C" const char* byolo_last_error(const byolo_t* h) { return h ? h->err.c_str() : g_err.c_str(); }

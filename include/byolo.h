@@ -86,8 +86,10 @@ BYOLO_API const char* byolo_version(void);
  * by byolo_layer_output are padded to a multiple of 4 floats; the host-side feed / writer entry points exist.  5: byolo_encode_gt,
  * byolo_loss (ground-truth encoding and training loss) exist.  6: the dropout stream byolo_forward draws from `seed` is redefined
  * (one hash + one derived word per group of four channels, csrc/byolo_rng.h): the same seed gives other masks than ABI 5 did; the
- * bit order of injected masks (d_mask_bits) is unchanged. */
-#define BYOLO_ABI_VERSION 6
+ * bit order of injected masks (d_mask_bits) is unchanged.  7: the plan of a handle is part of the ABI (byolo_plan_opts, byolo_get_plan_opts /
+ * byolo_set_plan_opts, byolo_graph_stats): the BYOLO_* plan variables are read ONCE, at byolo_create, and no longer reach an existing
+ * handle; a drop_prob whose 16-bit threshold rounds to 2^16 (rate 0) is the identity. */
+#define BYOLO_ABI_VERSION 7
 BYOLO_API int32_t byolo_abi_version(void);
 
 /* ---- the plan of a handle: which kernel carries which layer, and how a forward is put on the stream -------------------------------
