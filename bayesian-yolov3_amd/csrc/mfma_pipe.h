@@ -262,15 +262,18 @@ struct SplitTile {
 
 // One step (16 channels): hi*hi, hi*lo, lo*hi of every 32x32 block; product-major, so consecutive MFMAs go to different
 // accumulators (a dependent MFMA would wait out the 8 passes of its predecessor).
-template <int TM, int TN>
+// FIRST: the first product into each accumulator takes an inline-zero C operand instead of the accumulator -- the accumulators
+// need no clearing (the same bits: 0 + p).
+template <int TM, int TN, bool FIRST = false>
 __device__ __forceinline__ void mfma_step_split(f32x16 (&acc)[TM][TN], const f16x8 (&af)[TM][2], const f16x8 (&bf)[TN][2]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][pr == 2 ? 1 : 0], af[i][pr == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][pr == 2 ? 1 : 0], af[i][pr == 1 ? 1 : 0], (FIRST && pr == 0) ? zero : acc[i][j], 0, 0, 0);
 }
 
 // One K-tile (32 channels = 2 steps) of the split pipeline; tile t lives in LDS buffer BUF, the activation fragments of
@@ -282,7 +285,7 @@ __device__ __forceinline__ void mfma_step_split(f32x16 (&acc)[TM][TN], const f16
 //          | of step 0 of tile t+1
 // ABL = timing-ablation bits of the conv build (1: handled by the caller's loads, 2: by its store, 4 no barrier, 8 no
 // LDS fragment reads).
-template <int BUF, bool HN, int N_LDB, int N_LDA, int N_ST, int ABL = 0, class BT, class LB, class LA, class St>
+template <int BUF, bool HN, int N_LDB, int N_LDA, int N_ST, int ABL = 0, bool FIRST = false, class BT, class LB, class LA, class St>
 __device__ __forceinline__ void tile_body_split(const BT& t, f32x16 (&acc)[BT::TM][BT::TN], f16x8 (&af0)[BT::TM][2], f16x8 (&af1)[BT::TM][2],
                                                 const f16x8 (&bcur)[2][BT::TN][2], LB&& loads_b, LA&& loads_a, St&& store_next) {
     constexpr int G = BT::G;
@@ -292,7 +295,7 @@ __device__ __forceinline__ void tile_body_split(const BT& t, f32x16 (&acc)[BT::T
     if constexpr (N_LDB > 0) loads_b();
     if constexpr (FR) t.template read_frags<BUF, 1>(af1);
     if constexpr (HN) store_next();
-    mfma_step_split<BT::TM, BT::TN>(acc, af0, bcur[0]);
+    mfma_step_split<BT::TM, BT::TN, FIRST>(acc, af0, bcur[0]);
     sched_interleave<G, N_LDB, NFR, HN ? N_ST : 0>();
     __builtin_amdgcn_sched_barrier(0);
 

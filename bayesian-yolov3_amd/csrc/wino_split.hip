@@ -52,7 +52,7 @@ namespace byk {
 using namespace pipe;
 
 // Timing ablations (build.py --ablate-ws N -> libbyolo_ws<N>.so, loaded with BYOLO_LIB=...; results are WRONG by construction):
-// 1 no weight-fragment loads in the loop, 2 no fold, 4 no activation loads / LDS staging in the loop, 8 no accumulator clears,
+// 1 no weight-fragment loads in the loop, 2 no fold, 4 no activation loads / LDS staging in the loop, (8: gone with the clears),
 // 16 no workgroup barrier in the K-tile body, 32 no LDS fragment reads.
 #ifndef BYOLO_WS_ABLATE
 #define BYOLO_WS_ABLATE 0
@@ -221,22 +221,25 @@ __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSp
     // one K-tile in LDS buffer BUF: the uniform body of the split pipeline (mfma_pipe.h tile_body_split) -- stage tile t+1,
     // fetch tile t+1+NSET and the weight fragments of t+1
     // K-tile t: LDS buffer BUF = t & 1; tile t + 1 is staged from set SET = (t + 1) % NSET, which then receives tile t + 1 + NSET
-    auto ktile = [&](auto buf_tag, auto set_tag) __attribute__((always_inline)) {
+    auto ktile = [&](auto buf_tag, auto set_tag, auto first_tag) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
         using ST = decltype(set_tag);
-        pipe::tile_body_split<BUF, true, (WS_ABL & 1) ? 0 : BT::NBF, (WS_ABL & 4) ? 0 : A_LD, (WS_ABL & 4) ? 0 : A_LD, ((WS_ABL & 16) ? 4 : 0) | ((WS_ABL & 32) ? 8 : 0)>(
+        pipe::tile_body_split<BUF, true, (WS_ABL & 1) ? 0 : BT::NBF, (WS_ABL & 4) ? 0 : A_LD, (WS_ABL & 4) ? 0 : A_LD, ((WS_ABL & 16) ? 4 : 0) | ((WS_ABL & 32) ? 8 : 0), decltype(first_tag)::value>(
             bt, M, af0, af1, bfr[(WS_ABL & 1) ? 0 : BUF], [&]() __attribute__((always_inline)) { load_b(std::integral_constant<int, BUF ^ 1>{}); },
             [&]() __attribute__((always_inline)) { load_a(ST{}); }, [&]() __attribute__((always_inline)) { if constexpr (!(WS_ABL & 4)) bt.template store_a<BUF ^ 1>(a_reg[ST::value]); });
     };
+    // a point's K loop; its first K-tile's first products start the product accumulators from an inline zero (no clears: 32 vector
+    // moves per point that the matrix pipe would wait for)
     auto run_point = [&]() __attribute__((always_inline)) {
-        if constexpr (!(WS_ABL & 8)) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) M[i][0][r] = 0.f;
+        constexpr std::true_type first{};
+        constexpr std::false_type later{};
+        if constexpr (NSET == 4) {
+            ktile(c0{}, c1{}, first); ktile(c1{}, c2{}, later); ktile(c0{}, c3{}, later); ktile(c1{}, c0{}, later);
+            for (uint32_t kt = 4; kt < KT; kt += 4) { ktile(c0{}, c1{}, later); ktile(c1{}, c2{}, later); ktile(c0{}, c3{}, later); ktile(c1{}, c0{}, later); }
+        } else {
+            ktile(c0{}, c1{}, first); ktile(c1{}, c0{}, later);
+            for (uint32_t kt = 2; kt < KT; kt += 2) { ktile(c0{}, c1{}, later); ktile(c1{}, c0{}, later); }
         }
-        if constexpr (NSET == 4) { for (uint32_t kt = 0; kt < KT; kt += 4) { ktile(c0{}, c1{}); ktile(c1{}, c2{}); ktile(c0{}, c3{}); ktile(c1{}, c0{}); } }
-        else { for (uint32_t kt = 0; kt < KT; kt += 2) { ktile(c0{}, c1{}); ktile(c1{}, c0{}); } }
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
 

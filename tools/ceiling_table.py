@@ -76,7 +76,7 @@ def main():
               % (f, e["n"], e["flops"] / 1e12, e["bytes"] / 1e9, e["mm"], e["mem"], e["bound"], e["ms"], e["ms"] - e["bound"], 100 * (e["ms"] - e["bound"]) / tot["ms"]))
     print("| **sum of the convolution stack's launches** | | | | | **%.2f** | **%.2f** | %.2f | %.1f %% |" % (tot["bound"], tot["ms"], tot["ms"] - tot["bound"], 100 * (tot["ms"] - tot["bound"]) / tot["ms"]))
     if a.ms_per_step:
-        print("| wall - sum: decode + sort + NMS (0.6 ms) run under the next step's convolutions, and the UNPROFILED steps run their backbone beside the previous step's heads (the sum is of a profiled step, which runs alone) | | | | | 0 | %.2f | | |" % (a.ms_per_step - tot["ms"]))
+        print("| wall - sum: the tail (0.6 ms) runs under the next step's convolutions, and unprofiled steps run their backbone beside the previous step's heads (the sum is of a profiled step, which runs alone) | | | | | 0 | %.2f | | |" % (a.ms_per_step - tot["ms"]))
         print("| **`ms_per_step`** (wall) | | | | | **%.2f** | **%.2f** | | |" % (tot["bound"], a.ms_per_step))
 
 
