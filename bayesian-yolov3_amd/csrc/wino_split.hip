@@ -58,6 +58,10 @@ using namespace pipe;
 #define BYOLO_WS_ABLATE 0
 #endif
 static constexpr int WS_ABL = BYOLO_WS_ABLATE;
+#ifndef BYOLO_WS_FOLD_SKIP                               // 0: the A/B build that runs all 64 (point, output) folds
+#define BYOLO_WS_FOLD_SKIP 1
+#endif
+static constexpr bool WS_FOLD_SKIP = BYOLO_WS_FOLD_SKIP != 0;
 
 // ---------------------------------------------------------------------------------------------------------------------
 // input transform: thread = (sample, tile row, tile PAIR, 4 channels): 4 x 6 16-byte loads, 2 x 16 16-byte stores; hi/lo groups in
@@ -326,13 +330,14 @@ __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSp
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Y[o][i][r] = 0.f;
             // fold M into the four outputs: Y[a][b] += cA(a, i) * cA(b, j) * M for point xi = (i, j), cA = A^T = [1 1 1 0; 0 1 -1 -1].
-            // The coefficients (0, +-1) are block-uniform scalars and every point runs the SAME 4 x 32 fused multiply-adds, as packed
-            // fp32 operations (v_pk_fma_f32: two accumulators per instruction, IEEE per element): fp32 vector instructions are paid in full
-            // in matrix-pipe time on this part (tools/mfma_valu_coexec_probe.hip), the fold is 64 of them per point.  Only 36 of the 64
-            // (point, output) pairs are non-zero, but the two ways to issue just those both cost more than they save: a switch over
-            // specialised folds makes the register allocator copy the output accumulators at the join and spill (round 3); the point loop
-            // unrolled 16 x with compile-time coefficients (round 6) is 70 KB of code for a 64 KB instruction cache and still spilled 565
-            // bytes per lane (16 copies of the K loop, each with 160 accumulator registers live across it).
+            // The coefficients (0, +-1) are block-uniform scalars; an output's 16 packed fused multiply-adds (v_pk_fma_f32: two
+            // accumulators per instruction, IEEE per element) are SKIPPED by a scalar branch when its coefficient is zero -- 28 of the
+            // 64 (point, output) pairs: fp32 vector instructions are paid in full in matrix-pipe time on this part
+            // (tools/mfma_valu_coexec_probe.hip), the skip is -1.1 % on the kernel (profiles/r6_wino_zero_c.md), the same bits.  The
+            // branch sits between a point's K loop and the next, around vector code only: no accumulator is copied, nothing spills.
+            // What did NOT work: a switch over specialised folds (the register allocator copied the output accumulators at the join and
+            // spilled; round 3), the point loop unrolled 16 x with compile-time coefficients (70 KB of code for a 64 KB instruction
+            // cache, 565 bytes per lane spilled; round 6).
             for (int xi = 0; xi < 16; ++xi) {
                 run_point();
                 if (dyn && xi == 0) {                     // (every wave is past several barriers since thread 0 wrote the claim)
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSp
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const float c = (float)(wino_cA(o >> 1, I) * wino_cA(o & 1, J));
+                    if constexpr (WS_FOLD_SKIP) { if (c == 0.f) continue; }
                     const f32x2 cc = {c, c};
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
