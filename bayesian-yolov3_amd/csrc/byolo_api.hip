@@ -64,9 +64,9 @@ static void plan_opts_defaults(byolo_plan_opts& o) {
     memset(&o, 0, sizeof o);
     o.struct_bytes = (int32_t)sizeof o;
     o.graphs = 1; o.serialize_convs = 1; o.serialize_heads = 1; o.dedup = 1; o.lowmain = 1; o.kx3 = 1; o.p1 = 1; o.b2b = 1; o.kx3_wide = 0;
-    o.wino_split = 1; o.wino_split_min_c = 256; o.wino_split_bn = 256; o.wino_split_rounds = 0;
+    o.wino_split = 1; o.wino_split_min_c = 256; o.wino_split_bn = 0; o.wino_split_rounds = 0;
     o.winograd = 1; o.wino_fused = 1; o.stream1x1 = 1; o.gemm_stream = 1; o.ksplit = -1; o.streamk = 1; o.plain_epilogue = 1; o.wino_split_persist = 0;
-    o.wino_split_min_gflop = 200.f; o.wino_split_chunk_mb = 1500.f; o.wino_min_gflop = 10.f; o.wino_chunk_mb = 800.f; o.wino_min_ratio = 80.f;
+    o.wino_split_min_gflop = 30.f; o.wino_split_chunk_mb = 1500.f; o.wino_min_gflop = 10.f; o.wino_chunk_mb = 800.f; o.wino_min_ratio = 80.f;
 }
 // The environment is the default filler of a NEW handle and nothing else: the A/B scripts under tools/ and the tests set a variable,
 // then build their model.  No other translation unit of the library reads a plan variable.
@@ -105,7 +105,7 @@ extern "C" int32_t byolo_set_plan_opts(byolo_t* h, const byolo_plan_opts* o) {
     if (o->struct_bytes != (int32_t)sizeof *o) return fail(h, BYOLO_ERR_ARG, "byolo_set_plan_opts: struct_bytes %d, this library's byolo_plan_opts has %d (include/byolo.h)", o->struct_bytes, (int)sizeof *o);
     if (o->graphs < 0 || o->graphs > 2 || o->serialize_convs < 0 || o->serialize_convs > 2 || o->b2b < 0 || o->b2b > 2 || o->kx3_wide < 0 || o->kx3_wide > 2 ||
         o->wino_split < 0 || o->wino_split > 2 || o->winograd < 0 || o->winograd > 2 || o->wino_fused < 0 || o->wino_fused > 2 || o->stream1x1 < 0 || o->stream1x1 > 2 ||
-        o->streamk < 0 || o->streamk > 2 || o->ksplit < -1 || o->ksplit > 64 || (o->wino_split_bn != 128 && o->wino_split_bn != 256) ||
+        o->streamk < 0 || o->streamk > 2 || o->ksplit < -1 || o->ksplit > 64 || (o->wino_split_bn != 0 && o->wino_split_bn != 128 && o->wino_split_bn != 256) ||
         o->wino_split_rounds < 0 || o->wino_split_persist < 0 || o->wino_split_persist > 2 || !(o->wino_split_chunk_mb > 0.f) || !(o->wino_chunk_mb > 0.f) || !(o->wino_split_min_gflop >= 0.f) || !(o->wino_min_gflop >= 0.f) || !(o->wino_min_ratio >= 0.f))
         return fail(h, BYOLO_ERR_ARG, "byolo_set_plan_opts: a field outside its range (include/byolo.h)");
     const byolo_plan_opts& c = h->opts;
@@ -789,7 +789,7 @@ static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const C
         const uint64_t rows = (uint64_t)16 * w.P_pad;
         f.v = V; f.v_bytes = (uint32_t)(rows * c.C0 * 4); f.xi_stride = (uint32_t)((uint64_t)w.P_pad * c.C0 * 4);
         f.w = dptr(h, s.wino_off); f.w_bytes = (uint32_t)((size_t)16 * c.C0 * c.N * 4);
-        f.y = c.dst; f.scale = dptr(h, drop ? l.wscalek_off : l.wscale_off); f.shift = c.shift;
+        f.y = c.dst; f.residual = (c.flags & EPI_RESIDUAL) ? c.residual : nullptr; f.scale = dptr(h, drop ? l.wscalek_off : l.wscale_off); f.shift = c.shift;
         f.C = c.C0; f.N = c.N; f.KT = c.C0 / 32; f.n_tiles = c.N / wp.bn; f.bn = wp.bn;
         f.H = l.H; f.W = l.W; f.th = wp.th; f.tw = wp.tw; f.s0 = s0; f.P = w.P; f.P_pad = w.P_pad;
         f.bm = wp.bm; f.units = (w.P_pad / wp.bm) * f.n_tiles;
@@ -800,7 +800,7 @@ static int32_t run_wino_split(byolo_t* h, const Step& s, const Layer& l, const C
         f.flags = c.flags; f.k0 = c.k0; f.k1 = c.k1; f.thr = c.thr; f.idx_base = c.idx_base; f.mask_bits = c.mask_bits;
         f.status = c.status; f.layer_idx = c.layer_idx;
         f.d_ntiles = make_fastdiv((uint32_t)f.n_tiles); f.d_tt = w.d_tt; f.d_tw = w.d_tw;
-        if (prof && (rc = mark_launch(h, s.layer, 140, (int64_t)rows, c.N, c.C0, algo_flops * ns / S, st))) return rc;
+        if (prof && (rc = mark_launch(h, s.layer, 140, (int64_t)rows, c.N, c.C0, algo_flops * ns / S, st, 1, wp.bn))) return rc;   // (split_tiles of a Winograd entry: its channels per workgroup)
         HIPCHK(h, launch_wino_split(f, st));
     }
     return BYOLO_OK;

@@ -135,6 +135,7 @@ struct WinoSplitParams {
     uint32_t xi_stride;                   // bytes between consecutive transform points in V (P_pad * C * 4)
     const float* w; uint32_t w_bytes;     // U: 16 * C / 32 K-tiles in (point, chunk) order, split-f16 fragment order (mfma_pipe.h)
     float* y;                             // output [S,H,W,N], hi/lo groups
+    const float* residual;                // [S,H,W,N] hi/lo groups, added after the activation (layers.py:505-507), or null; not together with dropout
     const float* scale; const float* shift;
     int C, N, KT, n_tiles;                // KT = C / 32 (a multiple of 4), n_tiles = N / bn
     int H, W, th, tw, s0, P, P_pad;       // as WinoParams

@@ -168,33 +168,59 @@ void make_plan(byolo_t* h, int B, int T, bool inject) {
     // BYOLO_WINOGRAD=0 keeps every convolution direct.
     p.wino.assign(h->steps.size(), WinoPlan{});
     size_t wino_scratch = 0;
-    // Split precision: Winograd F(2x2,3x3) in split arithmetic (wino_split.hip) for the LARGE 3x3 / stride-1 convolutions -- the
-    // nine 3x3 convolutions of the heads at T >= ~10 samples.  The transform streams 5x the input through HBM, so small layers keep
-    // the shared-tap direct kernel.  opts.wino_split: 0 never, 1 layers of >= opts.wino_split_min_gflop (default 200), 2 every
-    // eligible layer (tests); opts.wino_split_bn: 256 | 128 channels per workgroup (64 output tiles; the 128-tile workgroup of rounds
-    // 3 - 5 lost both of its A/Bs -- 298 against 310 img/s, one wave per SIMD -- and is gone); opts.wino_split_chunk_mb: V bytes of a chunk.
+    // Split precision: Winograd F(2x2,3x3) in split arithmetic (wino_split.hip) for the 3x3 / stride-1 convolutions it is faster on.
+    // opts.wino_split: 0 never, 1 by the time model below (default), 2 every eligible layer (tests); opts.wino_split_bn: 0 the model
+    // picks 256 or 128 output channels per workgroup (default), 256 | 128 forced; opts.wino_split_min_gflop: a floor under the model;
+    // opts.wino_split_chunk_mb: V bytes of a chunk.
+    //
+    // The model (milliseconds; measured round 6 on 1024 x 1920 frames at batch 1 .. 11 and at config 4, profiles/r6_wino_small.md):
+    // a launch is `units` = row tiles (64 output tiles) x column tiles (bn channels) on 256 CUs; a 256-channel unit owns its CU
+    // (8 waves), two 128-channel units share one.  A round of 256-channel units takes a256(C); 128-channel units take s128(C) while
+    // each has a CU to itself (<= 256 of them) and b128(C) when two share; beyond two full rounds the 128-channel form pays ~9 %
+    // (measured 1.29 against 1.19 ms at config 4's 10.6 rounds).  The transform writes 4 x the input.  The direct shared-tap kernel
+    // runs at 390 - 425 TFLOP/s of algorithmic FLOPs behind ~0.03 ms.  A layer is transformed when the model says >= 3 % faster.
     if (h->precision == 1) {
         const int on = h->opts.wino_split;
         const double min_flops = on >= 2 ? 0.0 : (double)h->opts.wino_split_min_gflop * 1e9, budget = (double)h->opts.wino_split_chunk_mb * 1e6;
         const int bm = 64;
-        const int bn_pref = h->opts.wino_split_bn;             // measured at config 4: 1.29 -> 1.19 ms per fused launch
+        const int bn_pref = h->opts.wino_split_bn;
+        auto model_ms = [](int64_t row_tiles, int N, int C, int bn) -> double {
+            if (bn == 256) return (double)((row_tiles * (N / 256) + 255) / 256) * (0.030 + 0.000293 * C);
+            const int64_t units = row_tiles * (N / 128), full = units / 512, rem = units % 512;
+            const double t = (double)full * (0.012 + 0.000367 * C) + (rem == 0 ? 0.0 : rem <= 256 ? 0.024 + 0.00022 * C : 0.012 + 0.000367 * C);
+            return units > 1024 ? 1.09 * t : t;
+        };
         for (size_t si = 0; on && si < h->steps.size(); ++si) {
             const Step& s = h->steps[si];
             const Layer& l = h->layers[s.layer];
-            if (!s.wino_ok || !s.kx3 || s.mode != STEP_NORMAL || l.wshift_u.empty() || l.fused_residual >= 0 || p.fuse[si]) continue;
+            if (!s.wino_ok || !s.kx3 || s.mode != STEP_NORMAL || l.wshift_u.empty() || (l.fused_residual >= 0 && l.drop_ordinal >= 0) || p.fuse[si]) continue;   // (the kernel's residual epilogue carries no dropout)
             int M, KT; step_geometry(h, s, B, T, &M, &KT);
-            if (2.0 * M * l.filters * 9.0 * l.Cin < min_flops) continue;
+            const double flops = 2.0 * M * l.filters * 9.0 * l.Cin;
+            if (flops < min_flops) continue;
             // per transform point the K loop is only Cin / 32 tiles long, and the fold + the 5x input stream are paid per point:
             // measured at config 4 (direct -> transform + fused): Cin 512 2.00 -> 0.19 + 1.36 ms, 256 2.02 -> 0.35 + 1.37,
             // 128 2.15 -> 2 x (0.36 + 0.80) -- the 128-channel layers stay direct (BYOLO_WINO_SPLIT_MIN_C)
             if (on < 2 && l.Cin < h->opts.wino_split_min_c) continue;
-            WinoPlan& w = p.wino[si];
-            w.th = (l.H + 1) / 2; w.tw = (l.W + 1) / 2; w.bm = bm; w.fused = true;
-            w.bn = (bn_pref == 256 && bm == 64 && (l.filters % 256) == 0) ? 256 : 128;
-            const int S = M / (l.H * l.W);
-            const double per_sample = 16.0 * w.th * w.tw * l.Cin * 4.0;
+            const int th = (l.H + 1) / 2, tw = (l.W + 1) / 2, S = M / (l.H * l.W);
+            const double per_sample = 16.0 * th * tw * l.Cin * 4.0;
             const int nchunks = std::max(1, (int)std::ceil(S * per_sample / budget));          // equal chunks
-            w.chunk = (S + nchunks - 1) / nchunks;
+            const int chunk = (S + nchunks - 1) / nchunks;
+            const int64_t row_tiles = (int64_t)align_up((size_t)chunk * th * tw, 128) / bm;
+            const bool can256 = (l.filters % 256) == 0;
+            int bn = (bn_pref == 256 && can256) ? 256 : bn_pref == 128 ? 128 : 0;
+            if (bn_pref == 256 && !can256) bn = 128;
+            const double t256 = can256 ? model_ms(row_tiles, l.filters, l.Cin, 256) : 1e30, t128 = model_ms(row_tiles, l.filters, l.Cin, 128);
+            if (bn == 0) bn = t256 <= t128 ? 256 : 128;
+            if (on < 2) {
+                const double t_res = l.fused_residual >= 0 ? 4.0 * M * l.filters / 2.5e9 : 0.0;      // the residual epilogue's blocking reads (wino_split.hip epilogue_res)
+                const double t_wino = nchunks * ((bn == 256 ? t256 : t128) + 0.012 + (double)row_tiles * bm * per_sample / ((double)th * tw) / 4.5e9) + t_res;
+                const double t_direct = 0.028 + flops / ((l.Cin >= 512 ? 390.0 : 425.0) * 1e9);
+                if (t_wino > 0.97 * t_direct) continue;
+            }
+            WinoPlan& w = p.wino[si];
+            w.th = th; w.tw = tw; w.bm = bm; w.fused = true;
+            w.bn = bn;
+            w.chunk = chunk;
             // BYOLO_WINO_SPLIT_ROUNDS=k (experiment): chunks whose fused launch is k whole rounds of resident workgroups, so that a
             // chunk's V (<= ~140 MB per round) is still in the Infinity Cache when the GEMM reads it
             const int rounds = h->opts.wino_split_rounds;

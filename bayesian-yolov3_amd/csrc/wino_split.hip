@@ -62,6 +62,9 @@ static constexpr int WS_ABL = BYOLO_WS_ABLATE;
 #define BYOLO_WS_FOLD_SKIP 1
 #endif
 static constexpr bool WS_FOLD_SKIP = BYOLO_WS_FOLD_SKIP != 0;
+#ifndef BYOLO_WS_RES_AHEAD                               // residual epilogue: outputs the fetch runs ahead (2: 255 registers, measured +-0)
+#define BYOLO_WS_RES_AHEAD 1
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // input transform: thread = (sample, tile row, tile PAIR, 4 channels): 4 x 6 16-byte loads, 2 x 16 16-byte stores; hi/lo groups in
@@ -303,6 +306,69 @@ __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSp
         if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
     };
 
+    // ---- the same with a residual added after the activation and no dropout (the darknet blocks' `inputs + shortcut`, lib_yolo/layers.py:
+    // 505-507; byolo_plan.hip sends no layer with both here).  Straight line: every lane computes all of its 2 x 4 outputs at clamped
+    // addresses and only the STORE is predicated (a lane's `continue` saves nothing while its wave runs on), so that the residual groups
+    // of output o + 1 can be fetched, without a branch, as soon as those of output o have been added: a ring of four 16-byte groups,
+    // one output's arithmetic ahead of its use.  Measured on 1024 x 1920 x 11 frames (profiles/r6_wino_small.md): the residual costs
+    // 0.07 ms per launch of 173 MB (+22 % at 256 -> 512 channels, +8 % at 512 -> 1024) whatever the distance of the fetch -- all CUs
+    // reach their epilogues together and the round's 67 MB of residual reads, which block, join its 67 MB of writes, which do not.
+    auto epilogue_res = [&](uint32_t rt, uint32_t ct) __attribute__((always_inline)) {
+        const float slope = (p.flags & EPI_LEAKY) ? 0.1f : 1.f;
+        const uint32_t tt = (uint32_t)(p.th * p.tw);
+        int tid_e = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid_e));
+        const int e_wn = tid_e >> 6, e_li = tid_e & 31, e_lh = (tid_e >> 5) & 1;
+        const int nb = (int)(ct * WINO_BN) + e_wn * 32 + 4 * e_lh;
+        float vmax = 0.f;
+        f32x4 sc4[4], sf4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            sc4[g] = *reinterpret_cast<const f32x4*>(p.scale + nb + 8 * g);
+            sf4[g] = *reinterpret_cast<const f32x4*>(p.shift + nb + 8 * g);
+        }
+        const bool keep[4] = {true, true, true, true};
+        auto row_of = [&](int k, bool& ok) __attribute__((always_inline)) -> size_t {        // k = 4 i + o
+            const uint32_t t0 = rt * (uint32_t)WINO_BM + (uint32_t)(k >> 2) * 32u + (uint32_t)e_li;
+            const uint32_t t = t0 < (uint32_t)p.P ? t0 : (uint32_t)p.P - 1u;
+            const uint32_t s = fdiv(t, p.d_tt), r = t - s * tt;
+            const uint32_t ty = fdiv(r, p.d_tw), tx = r - ty * (uint32_t)p.tw;
+            const uint32_t oy0 = 2 * ty + (uint32_t)((k >> 1) & 1), ox0 = 2 * tx + (uint32_t)(k & 1);
+            ok = t0 < (uint32_t)p.P && oy0 < (uint32_t)p.H && ox0 < (uint32_t)p.W;
+            const uint32_t oy = oy0 < (uint32_t)p.H ? oy0 : (uint32_t)p.H - 1u, ox = ox0 < (uint32_t)p.W ? ox0 : (uint32_t)p.W - 1u;
+            return (size_t)(((uint64_t)(p.s0 + s) * p.H + oy) * p.W + ox) * p.N + nb;
+        };
+        constexpr int AHEAD = BYOLO_WS_RES_AHEAD;          // outputs the residual fetch runs ahead of the arithmetic
+        f32x4 rr4[AHEAD][4];
+        bool okv[AHEAD + 1]; size_t rowv[AHEAD + 1];
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) {
+            rowv[a] = row_of(a, okv[a]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rr4[a][g] = *reinterpret_cast<const f32x4*>(p.residual + rowv[a] + 8 * g);
+        }
+#pragma unroll
+        for (int k = 0; k < 4 * TM; ++k) {
+            if (k + AHEAD < 4 * TM) rowv[AHEAD] = row_of(k + AHEAD, okv[AHEAD]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = Y[k & 3][k >> 2][4 * g + q];
+                f32x4 v = epi::bn_act4_pk(a4, sc4[g], sf4[g], keep, slope);
+                v += epi::split_decode4(rr4[k % AHEAD][g]);
+                if (k + AHEAD < 4 * TM) rr4[k % AHEAD][g] = *reinterpret_cast<const f32x4*>(p.residual + rowv[AHEAD] + 8 * g);
+                if (okv[0]) {
+                    vmax = epi::absmax4(vmax, v);
+                    *reinterpret_cast<f32x4*>(p.y + rowv[0] + 8 * g) = epi::split_encode4(v);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < AHEAD; ++a) { okv[a] = okv[a + 1]; rowv[a] = rowv[a + 1]; }
+        }
+        if (p.status && vmax >= 65520.f) { atomicOr(p.status, 1u); atomicMin(p.status + 1, (unsigned)p.layer_idx); }
+    };
+
     // The walk.  Static (persist 1): unit k + (workgroups of the XCD) is next.  Dynamic (persist 2): the XCD's workgroups claim units
     // from one counter as they get to them -- units differ (edge tiles store 1 - 3 of their 4 outputs, padding rows none) and CUs
     // do not run in step, and a static list gives the whole launch the pace of its unluckiest workgroup (measured: +2.5 % per launch
@@ -361,7 +427,8 @@ __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSp
                         }
                 }
             }
-        if (!(p.flags & EPI_DROPOUT)) epilogue(std::integral_constant<int, 0>{}, rt, ct);
+        if (p.residual) epilogue_res(rt, ct);
+        else if (!(p.flags & EPI_DROPOUT)) epilogue(std::integral_constant<int, 0>{}, rt, ct);
         else if (p.mask_bits) epilogue(std::integral_constant<int, 2>{}, rt, ct);
         else epilogue(std::integral_constant<int, 1>{}, rt, ct);
     }
@@ -382,7 +449,7 @@ static hipError_t launch_wino_split_bn(const WinoSplitParams& p, hipStream_t st)
     return hipGetLastError();
 }
 hipError_t launch_wino_split(const WinoSplitParams& p, hipStream_t st) {
-    if (p.bm != 64) return hipErrorInvalidValue;
+    if (p.bm != 64 || (p.residual && (p.flags & EPI_DROPOUT))) return hipErrorInvalidValue;      // (no reference model drops out in front of a residual add: byolo_plan.hip keeps such a layer direct)
     return p.bn == 256 ? launch_wino_split_bn<256>(p, st) : launch_wino_split_bn<128>(p, st);
 }
 

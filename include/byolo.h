@@ -120,10 +120,12 @@ typedef struct byolo_plan_opts {
                                       (default), 2 every eligible pair [BYOLO_B2B]                                                    */
     int32_t kx3_wide;              /* the 8-wave 128 x 256 shared-tap tile without a follower: 0 (default; measured 4 % slower), 1, 2
                                       [BYOLO_KX3_WIDE]                                                                                */
-    int32_t wino_split;            /* Winograd F(2x2,3x3) in split-f16: 0 never, 1 layers >= wino_split_min_gflop with >=
-                                      wino_split_min_c input channels (default), 2 every eligible layer [BYOLO_WINO_SPLIT]            */
+    int32_t wino_split;            /* Winograd F(2x2,3x3) in split-f16: 0 never, 1 the layers with >= wino_split_min_c input channels the
+                                      planner's time model (byolo_plan.hip) expects >= 3 % faster than the direct kernel (default),
+                                      2 every eligible layer [BYOLO_WINO_SPLIT]                                                       */
     int32_t wino_split_min_c;      /* 256 [BYOLO_WINO_SPLIT_MIN_C]                                                                    */
-    int32_t wino_split_bn;         /* output channels per workgroup: 256 (8 waves; default) or 128 [BYOLO_WINO_SPLIT_BN]              */
+    int32_t wino_split_bn;         /* output channels per workgroup: 0 the time model picks per layer (default: 256 for launches of
+                                      many rounds, 128 where that fills more CUs), 256 (8 waves) or 128 forced [BYOLO_WINO_SPLIT_BN]  */
     int32_t wino_split_rounds;     /* experiment: chunks of k whole rounds of workgroups, 0 = off [BYOLO_WINO_SPLIT_ROUNDS]           */
     int32_t winograd;              /* fp32 mode: Winograd for the large 3x3 layers: 0, 1 (default), 2 every eligible [BYOLO_WINOGRAD] */
     int32_t wino_fused;            /* fp32 mode: GEMM + output transform in one kernel: 0, 1 (default), 2 [BYOLO_WINO_FUSED]          */
@@ -143,7 +145,7 @@ typedef struct byolo_plan_opts {
     int32_t wino_split_persist;    /* the Winograd GEMM's workgroups walk the unit list themselves, next unit prefetched: 0 one unit per
                                       workgroup (default), 1 a static list, 2 units claimed from a per-XCD counter; the same bits, and
                                       measured SLOWER: +2.5 % / +0.8 % per launch (profiles/r6_wino_persist.md) [BYOLO_WINO_SPLIT_PERSIST] */
-    float   wino_split_min_gflop;  /* 200 [BYOLO_WINO_SPLIT_MIN_GFLOP]                                                                */
+    float   wino_split_min_gflop;  /* a floor under the time model: 30 [BYOLO_WINO_SPLIT_MIN_GFLOP]                                   */
     float   wino_split_chunk_mb;   /* V bytes of one chunk: 1500 [BYOLO_WINO_SPLIT_CHUNK_MB]                                          */
     float   wino_min_gflop;        /* fp32 mode: 10 [BYOLO_WINO_MIN_GFLOP]                                                            */
     float   wino_chunk_mb;         /* fp32 mode: V + M bytes of one chunk: 800 [BYOLO_WINO_CHUNK_MB]                                  */
@@ -396,7 +398,8 @@ BYOLO_API int32_t byolo_step_profile(byolo_t* h, int32_t i, int32_t* layer, int3
                                      double* algo_flops);
 /* the same launch's split-K plan: K slices per tile of its last partial round of tiles (1 = not split) and how many
  * tiles were cut; a NEGATIVE ksplit -G = a stream-K launch: G workgroups share all tiles * K-tiles units evenly
- * (conv_igemm.hip; decided per (B, T) shape, deterministic) */
+ * (conv_igemm.hip; decided per (B, T) shape, deterministic).  A Winograd GEMM entry (variant 140): ksplit 1, split_tiles = the
+ * output channels per workgroup the planner chose (256 | 128). */
 BYOLO_API int32_t byolo_step_split(byolo_t* h, int32_t i, int32_t* ksplit, int32_t* split_tiles);
 /* analytic cost of one forward: conv FLOPs (2*MAC, graph as written) for B images x T samples */
 BYOLO_API int32_t byolo_flops(byolo_t* h, int32_t B, int32_t T, double* flops);

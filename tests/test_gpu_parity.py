@@ -704,7 +704,9 @@ def test_winograd_in_split_arithmetic_on_every_eligible_layer(variant, bn, persi
     torch.cuda.synchronize()
     v = [s["variant"] for s in m.engine.step_profile()]
     m.engine.set_profiling(0)
-    assert v.count(140) >= 9 and v.count(-4) == v.count(140), "fused Winograd launches: %s" % v
+    # the 9 head convolutions and (round 6: the kernel's residual epilogue) the 20 residual-block convolutions of Darknet-53 with >= 128
+    # input channels (`inputs + shortcut`, lib_yolo/layers.py:505-507)
+    assert v.count(140) >= 29 and v.count(-4) == v.count(140), "fused Winograd launches: %s" % v
     g = golden("fwd_%s.npz" % variant)
     gb = g["bbox"] if g["bbox"].ndim == 3 else g["bbox"][None]
     for k, dl in enumerate(m.det_layers):
