@@ -226,6 +226,13 @@ def test_reference_default_batched_workloads(cfgnum, rows_d):
     B = cfg["B"]
     assert B == 11 and out["boxes"].shape == (11, 120960, rows_d)
     print("config %d launch variants:" % cfgnum, _variants(launches))
+    # round 6: the planner's time model (csrc/byolo_plan.hip, profiles/r6_wino_small.md) sends this shape's 18 convolutions with >= 256
+    # input channels -- 199 GFLOP each, under the old 200-GFLOP threshold -- through the Winograd kernel: the 6 of the heads and,
+    # through the kernel's residual epilogue, the 12 of Darknet-53's residual blocks; 128 output channels per workgroup where 256 would
+    # leave the launch at 1.3 rounds of 256 CUs (512 -> 1024 at 32 x 60), 256 otherwise; what is compared below ran on that plan
+    wino = [s for s in launches if s["variant"] == 140]
+    assert len(wino) == 18 and sum(1 for s in launches if s["variant"] == -4) == 18, _variants(launches)
+    assert sorted(set((s["K"], s["split_tiles"]) for s in wino)) == [(256, 256), (512, 128)], [(s["layer"], s["K"], s["split_tiles"]) for s in wino]
     _compare(cfgnum, cfg, eng, imgs, out, (0, B - 1), 1000, "reference default %s workload (1024x1920 B=11)" % cfg["variant"], f64_all=True)
     counts = out["count"][:, 0].cpu().numpy()
     rows = out["rows"].cpu().numpy()
