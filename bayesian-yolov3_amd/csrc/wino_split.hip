@@ -73,6 +73,17 @@ static constexpr bool WS_FOLD_SKIP = BYOLO_WS_FOLD_SKIP != 0;
 // belongs to four patches and the L2 caught a third of the repeats).  The rows that pad V to P_pad are zeroed by the threads behind
 // the last pair.
 // ---------------------------------------------------------------------------------------------------------------------
+// V is written with NON-TEMPORAL stores (`global_store_dwordx4 ... nt`: a wave writes 1 KB runs, whole cache lines): the transform itself
+// is 1 % faster and the GEMM that reads V 1.3 - 5 % (config 4: 6.98 -> 6.90 ms per step over the six launches, +0.7 % img/s; the 1024 x 1920
+// workloads 6.46 -> 6.24; also where V would fit the Infinity Cache) -- profiles/r6_wino_small.md.  The same hint on the GEMM's OUTPUT
+// stores, which complete a 128-byte line over four instructions of two lanes, costs 23 % of that kernel.  0 = the A/B build.
+#ifndef BYOLO_WS_NT_STORE
+#define BYOLO_WS_NT_STORE 1
+#endif
+__device__ __forceinline__ void vstore(float* at, const f32x4 v) {
+    if constexpr (BYOLO_WS_NT_STORE != 0) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(at));
+    else *reinterpret_cast<f32x4*>(at) = v;
+}
 __global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams p, const FastDiv d_twp, const FastDiv d_ttp, const int twp) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t c4n = (uint32_t)p.C >> 2;
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams
         if (t >= (uint32_t)p.P_pad) return;
         float* v = p.v + (size_t)t * p.C + c4 * 4;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x4*>(v + (size_t)k * xi_stride) = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 16; ++k) vstore(v + (size_t)k * xi_stride, f32x4{0.f, 0.f, 0.f, 0.f});
         return;
     }
     const uint32_t s = fdiv(q, d_ttp), r = q - s * ttp;
@@ -119,10 +130,10 @@ __global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams
         const int o = 2 * k;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 0) * xi_stride) = epi::split_encode4((u[i][o + 0] - u[i][o + 2]) * m);
-            *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 1) * xi_stride) = epi::split_encode4((u[i][o + 1] + u[i][o + 2]) * m);
-            *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 2) * xi_stride) = epi::split_encode4((u[i][o + 2] - u[i][o + 1]) * m);
-            *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 3) * xi_stride) = epi::split_encode4((u[i][o + 1] - u[i][o + 3]) * m);
+            vstore(v + (size_t)(i * 4 + 0) * xi_stride, epi::split_encode4((u[i][o + 0] - u[i][o + 2]) * m));
+            vstore(v + (size_t)(i * 4 + 1) * xi_stride, epi::split_encode4((u[i][o + 1] + u[i][o + 2]) * m));
+            vstore(v + (size_t)(i * 4 + 2) * xi_stride, epi::split_encode4((u[i][o + 2] - u[i][o + 1]) * m));
+            vstore(v + (size_t)(i * 4 + 3) * xi_stride, epi::split_encode4((u[i][o + 1] - u[i][o + 3]) * m));
         }
     }
 }
