@@ -900,7 +900,11 @@ def main():
         legs = {"parity_note": line.get("parity_note")}
         legs.update({"other_configs/" + k: v.get("parity") for k, v in (line.get("other_configs") or {}).items() if isinstance(v, dict)})
         failed = sorted(k for k, v in legs.items() if isinstance(v, dict) and v.get("ok") is False)
-        line["parity_ok"] = not failed
+        checked = sorted(k for k, v in legs.items() if isinstance(v, dict) and v.get("ok") is not None)
+        # null, not true, when no leg ran (--no-cpu-baseline: the A/B scripts under tools/): a build that corrupted its activations
+        # read "parity_ok": true through such a run once (profiles/r6_wino_small.md); A/Bs are held to tools/rows_digest.py
+        line["parity_ok"] = (not failed) if checked else None
+        line["parity_legs_checked"] = len(checked)
         if failed:
             line["parity_failed"] = failed
         print(json.dumps(line))
