@@ -6,6 +6,17 @@
 #include "epilogue.h"
 
 namespace byk {
+// finish_upsampled_kernel's stores (a wave writes whole cache lines, 16 bytes per lane, to a tensor the next launch streams once): non-temporal,
+// like the Winograd transform's V (wino_split.hip vstore): 0.352 -> 0.323 ms per step at config 4, +0.25 % img/s; 0 = the A/B build.  The
+// stem's stores measured +-0 with the hint and keep the plain form.
+#ifndef BYOLO_NT_MISC
+#define BYOLO_NT_MISC 1
+#endif
+__device__ __forceinline__ void st4(float* at, const epi::f32x4 v) {
+    if constexpr (BYOLO_NT_MISC != 0) __builtin_nontemporal_store(v, reinterpret_cast<epi::f32x4*>(at));
+    else *reinterpret_cast<epi::f32x4*>(at) = v;
+}
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -251,8 +262,8 @@ __global__ __launch_bounds__(256) void finish_upsampled_kernel(const FinishParam
                 } else epi::keep4(drow, 0, p.k0, p.thr, keep);
             }
             const f32x4 v = epi::bn_act4(a4[o], sc4, sf4, keep, slope);
-            if constexpr (MODE == 2) { vmax = epi::absmax4(vmax, v); *reinterpret_cast<f32x4*>(d) = epi::split_encode4(v); }
-            else *reinterpret_cast<f32x4*>(d) = v;
+            if constexpr (MODE == 2) { vmax = epi::absmax4(vmax, v); st4(d, epi::split_encode4(v)); }
+            else st4(d, v);
         }
     }
     if constexpr (MODE == 2) {
