@@ -26,6 +26,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t wdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shr; }
 
 // thread = (tile p, 4 channels): 16 x 16-byte loads, 16 x 16-byte stores
+// V is written with non-temporal stores, as in wino_split.hip (there: the GEMM that reads V 1.3 - 5 % faster; here, fp32 mode at config 4:
+// 190.4 / 189.5 -> 191.1 / 191.7 img/s, inside the noise); BYOLO_WF_NT_STORE=0: the A/B build
+#ifndef BYOLO_WF_NT_STORE
+#define BYOLO_WF_NT_STORE 1
+#endif
+__device__ __forceinline__ void vstore(float* at, const f32x4 v) {
+    if constexpr (BYOLO_WF_NT_STORE != 0) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(at));
+    else *reinterpret_cast<f32x4*>(at) = v;
+}
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t c4n = (uint32_t)p.C >> 2;
@@ -57,10 +66,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     const size_t xi_stride = (size_t)p.P_pad * p.C;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                    // (B^T d) B
-        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 0) * xi_stride) = u[i][0] - u[i][2];
-        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 1) * xi_stride) = u[i][1] + u[i][2];
-        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 2) * xi_stride) = u[i][2] - u[i][1];
-        *reinterpret_cast<f32x4*>(v + (size_t)(i * 4 + 3) * xi_stride) = u[i][1] - u[i][3];
+        vstore(v + (size_t)(i * 4 + 0) * xi_stride, u[i][0] - u[i][2]);
+        vstore(v + (size_t)(i * 4 + 1) * xi_stride, u[i][1] + u[i][2]);
+        vstore(v + (size_t)(i * 4 + 2) * xi_stride, u[i][2] - u[i][1]);
+        vstore(v + (size_t)(i * 4 + 3) * xi_stride, u[i][1] - u[i][3]);
     }
 }
 
