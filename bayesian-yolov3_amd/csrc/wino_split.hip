@@ -77,6 +77,18 @@ static constexpr bool WS_FOLD_SKIP = BYOLO_WS_FOLD_SKIP != 0;
 // is 1 % faster and the GEMM that reads V 1.3 - 5 % (config 4: 6.98 -> 6.90 ms per step over the six launches, +0.7 % img/s; the 1024 x 1920
 // workloads 6.46 -> 6.24; also where V would fit the Infinity Cache) -- profiles/r6_wino_small.md.  The same hint on the GEMM's OUTPUT
 // stores, which complete a 128-byte line over four instructions of two lanes, costs 23 % of that kernel.  0 = the A/B build.
+// Layout of V inside a transform point's plane.  0: [tile][channel] (a row = one output tile, C channels).  1: K-TILE MAJOR -- [row tile of 64
+// output tiles][K-tile of 32 channels][64 rows][32 channels]: what a workgroup of the GEMM stages per K-tile is one contiguous 8 KB block
+// instead of 64 pieces of 128 bytes 4 C bytes apart (fewer DRAM page openings per byte).  Same rows; one box, three interleaved runs each:
+// config 4 381.5 -> 383.3 img/s, config 7 459.5 -> 461.7 (+0.5 % both), the GEMM's launches -0.6 % / -1.6 %, the transform's unchanged
+// (profiles/r6_wino_small.md).  0 = the A/B build.
+#ifndef BYOLO_WS_V_KTMAJOR
+#define BYOLO_WS_V_KTMAJOR 1
+#endif
+__device__ __forceinline__ size_t v_index(uint32_t t, uint32_t c, uint32_t C) {          // float index of (output tile t, channel c) inside a plane
+    if constexpr (BYOLO_WS_V_KTMAJOR != 0) return ((size_t)((t >> 6) * (C >> 5) + (c >> 5)) * 64u + (t & 63u)) * 32u + (c & 31u);
+    else return (size_t)t * C + c;
+}
 #ifndef BYOLO_WS_NT_STORE
 #define BYOLO_WS_NT_STORE 1
 #endif
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams
     if (q >= n_pairs) {
         const uint32_t t = (uint32_t)p.P + (q - n_pairs);
         if (t >= (uint32_t)p.P_pad) return;
-        float* v = p.v + (size_t)t * p.C + c4 * 4;
+        float* v = p.v + v_index(t, c4 * 4, (uint32_t)p.C);
 #pragma unroll
         for (int k = 0; k < 16; ++k) vstore(v + (size_t)k * xi_stride, f32x4{0.f, 0.f, 0.f, 0.f});
         return;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (k == 1 && !two) break;
-        float* v = p.v + (size_t)(t0 + k) * p.C + c4 * 4;
+        float* v = p.v + v_index(t0 + (uint32_t)k, c4 * 4, (uint32_t)p.C);
         const int o = 2 * k;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -180,7 +192,11 @@ __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSp
     // staging rows (V row = output tile index inside the chunk; every row of the padded extent exists)
     auto voff_of = [&](uint32_t rt, uint32_t (&v)[A_LD]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) v[j] = ((rt * (uint32_t)WINO_BM + (uint32_t)bt.a_r + (uint32_t)(BT::NT / 8) * j) * (uint32_t)p.C + (uint32_t)bt.a_q * 4u) * 4u;
+        for (int j = 0; j < A_LD; ++j) {
+            const uint32_t row = (uint32_t)bt.a_r + (uint32_t)(BT::NT / 8) * j;
+            if constexpr (BYOLO_WS_V_KTMAJOR != 0) v[j] = rt * (uint32_t)WINO_BM * (uint32_t)p.C * 4u + (row * 32u + (uint32_t)bt.a_q * 4u) * 4u;
+            else v[j] = ((rt * (uint32_t)WINO_BM + row) * (uint32_t)p.C + (uint32_t)bt.a_q * 4u) * 4u;
+        }
     };
     const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(p.v, p.v_bytes);
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, p.w_bytes);
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(WINO_BN * 2, 2) void wino_split_kernel(const WinoSp
         a_pt = roll ? 0u : a_pt;
         a_xi_base = roll ? 0u : a_xi_base;
         a_base = roll ? a_next_base : a_base;
-        a_soff = a_base + a_xi_base + a_kt * (BK * 4);
+        a_soff = a_base + a_xi_base + a_kt * (BYOLO_WS_V_KTMAJOR != 0 ? WINO_BM * BK * 4 : BK * 4);
     };
     // (the weight fragments do NOT run on across units: 32 registers that would have to live through the epilogue, which has none to
     //  spare -- the build with them spilled 1.2 KB per lane; a unit's first fragments are fetched behind the previous unit's epilogue:
