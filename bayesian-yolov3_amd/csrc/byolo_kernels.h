@@ -128,7 +128,7 @@ struct WinoParams {
     FastDiv d_tt, d_tw, d_c4, d_n4;   // th*tw, tw, C/4, N/4
     float vmul;                       // split precision (wino_split.hip): V = vmul * (B^T d B) of the stored hi + lo values
 };
-// Winograd F(2x2,3x3) in split-f16 arithmetic (wino_split.hip): V [16][P_pad][C] as hi/lo groups -> output [S,H,W,N] as hi/lo
+// Winograd F(2x2,3x3) in split-f16 arithmetic (wino_split.hip): V [16][P_pad x C, K-tile major inside a plane: v_index()] as hi/lo groups -> output [S,H,W,N] as hi/lo
 // groups, GEMM + output transform + epilogue in one launch of P_pad / 128 * N / 128 workgroups
 struct WinoSplitParams {
     const float* v; uint32_t v_bytes;     // V of this chunk; rows beyond v_bytes read 0
