@@ -89,6 +89,9 @@ __device__ __forceinline__ size_t v_index(uint32_t t, uint32_t c, uint32_t C) { 
     if constexpr (BYOLO_WS_V_KTMAJOR != 0) return ((size_t)((t >> 6) * (C >> 5) + (c >> 5)) * 64u + (t & 63u)) * 32u + (c & 31u);
     else return (size_t)t * C + c;
 }
+#ifndef BYOLO_WS_IN_COLMAJOR
+#define BYOLO_WS_IN_COLMAJOR 1
+#endif
 #ifndef BYOLO_WS_NT_STORE
 #define BYOLO_WS_NT_STORE 1
 #endif
@@ -96,7 +99,7 @@ __device__ __forceinline__ void vstore(float* at, const f32x4 v) {
     if constexpr (BYOLO_WS_NT_STORE != 0) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(at));
     else *reinterpret_cast<f32x4*>(at) = v;
 }
-__global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams p, const FastDiv d_twp, const FastDiv d_ttp, const int twp) {
+__global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams p, const FastDiv d_twp, const FastDiv d_ttp, const int twp, const FastDiv d_th) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t c4n = (uint32_t)p.C >> 2;
     const uint32_t q = fdiv(gid, p.d_c4), c4 = gid - q * c4n;
@@ -111,7 +114,12 @@ __global__ __launch_bounds__(256) void wino_split_input2_kernel(const WinoParams
         return;
     }
     const uint32_t s = fdiv(q, d_ttp), r = q - s * ttp;
-    const uint32_t ty = fdiv(r, d_twp), txp = r - ty * (uint32_t)twp;
+    // BYOLO_WS_IN_COLMAJOR: neighbouring threads take VERTICALLY adjacent tile pairs (their 4-row patches share two rows, half of what a
+    // thread reads) instead of horizontally adjacent ones (two of six columns): the transform's launches 1.594 -> 1.561 ms per step at
+    // config 4, 1.160 -> 1.127 at config 7 (one box, three interleaved runs each; img/s +0.15 % / +-0); 0 = the A/B build
+    uint32_t ty, txp;
+    if constexpr (BYOLO_WS_IN_COLMAJOR != 0) { txp = fdiv(r, d_th); ty = r - txp * (uint32_t)p.th; }
+    else { ty = fdiv(r, d_twp); txp = r - ty * (uint32_t)twp; }
     const uint32_t tx0 = 2u * txp;
     const bool two = tx0 + 1u < (uint32_t)p.tw;
     const float* img = p.x + ((size_t)(p.s0 + s) * p.H * p.W) * p.C + c4 * 4;
@@ -155,7 +163,7 @@ hipError_t launch_wino_split_input(const WinoParams& p, hipStream_t st) {
     const uint64_t rows = (uint64_t)(p.P / (p.th * p.tw)) * p.th * twp + (uint64_t)(p.P_pad - p.P);
     const uint64_t total = rows * (uint64_t)(p.C >> 2);
     hipLaunchKernelGGL(wino_split_input2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p,
-                       make_fastdiv((uint32_t)twp), make_fastdiv((uint32_t)(p.th * twp)), twp);
+                       make_fastdiv((uint32_t)twp), make_fastdiv((uint32_t)(p.th * twp)), twp, make_fastdiv((uint32_t)p.th));
     return hipGetLastError();
 }
 
